@@ -1,0 +1,286 @@
+"""ORACLE - test infrastructure, not product code.
+
+CPU restatement (PyTorch, dtype-generic, meant to be run in fp64) of the inference hot path of
+``/root/reference/models/mdgat.py``.  Only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import this module; the shipped package
+(``mdgat_matcher_amd``) never does and has no CPU fallback.
+
+Parity pin: the reference publishes no tests or golden vectors for this path,
+so the oracle is pinned against *outputs of the reference itself*: ``tools/make_goldens.py``
+imports ``/root/reference/models/mdgat.py`` in the build container, runs it in fp64 on seeded
+synthetic weights/inputs and commits the stage tensors under ``tests/golden/``;
+``tests/test_oracle_golden.py`` checks every function below against those fixtures.
+
+Every function cites the reference lines it restates.  The state dict uses the reference's
+parameter names, so a real checkpoint (``checkpoint['net']`` with the ``module.`` prefix
+stripped) can be fed in unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+BN_EPS = 1e-5          # torch.nn.BatchNorm1d default used by mdgat.py:43
+NUM_HEADS = 4          # mdgat.py:255
+
+
+# ----------------------------------------------------------------------------- per-point MLPs
+def _pointwise(w: torch.Tensor, b: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """Conv1d(kernel_size=1) on channel-major [B, Cin, N] (mdgat.py:39-40)."""
+    return torch.matmul(w[:, :, 0], x) + b[None, :, None]
+
+
+def _batchnorm_eval(sd, prefix, x):
+    """BatchNorm1d in eval mode: running statistics, affine (mdgat.py:43)."""
+    mean = sd[f'{prefix}.running_mean'][None, :, None]
+    var = sd[f'{prefix}.running_var'][None, :, None]
+    g = sd[f'{prefix}.weight'][None, :, None]
+    beta = sd[f'{prefix}.bias'][None, :, None]
+    return (x - mean) / torch.sqrt(var + BN_EPS) * g + beta
+
+
+def mlp(sd: Dict[str, torch.Tensor], prefix: str, x: torch.Tensor, n_layers: int) -> torch.Tensor:
+    """The reference's ``MLP`` stack (mdgat.py:34-46): conv at index 3i, BN at 3i+1, ReLU; the
+    last conv has neither BN nor ReLU."""
+    for i in range(n_layers):
+        x = _pointwise(sd[f'{prefix}.{3 * i}.weight'], sd[f'{prefix}.{3 * i}.bias'], x)
+        if i < n_layers - 1:
+            x = torch.relu(_batchnorm_eval(sd, f'{prefix}.{3 * i + 1}', x))
+    return x
+
+
+def _count_convs(sd, prefix):
+    n = 0
+    while f'{prefix}.{3 * n}.weight' in sd:
+        n += 1
+    return n
+
+
+def keypoint_encoder(sd, kpts, sigma):
+    """KeypointEncoder.forward (mdgat.py:184-188): MLP over [x, y, z, saliency]."""
+    inp = torch.cat([kpts.transpose(1, 2), sigma[:, None, :]], dim=1)
+    return mlp(sd, 'kenc.encoder', inp, _count_convs(sd, 'kenc.encoder'))
+
+
+def descriptor_encoder(sd, fpfh):
+    """DescriptorEncoder.forward (mdgat.py:152-155): MLP over the 33-D FPFH row."""
+    return mlp(sd, 'denc.encoder', fpfh.transpose(1, 2), _count_convs(sd, 'denc.encoder'))
+
+
+def encode(sd, kpts, sigma, fpfh):
+    """mdgat.py:392-393: descriptor encoding + keypoint encoding -> [B, D, N]."""
+    return descriptor_encoder(sd, fpfh) + keypoint_encoder(sd, kpts, sigma)
+
+
+# ----------------------------------------------------------------------------- attention
+def attention(q, k, v):
+    """mdgat.py:190-194.  q [B, dh, H, N], k/v [B, dh, H, M] -> message [B, dh, H, N], prob."""
+    dh = q.shape[1]
+    logits = torch.einsum('bdhn,bdhm->bhnm', q, k) / dh ** 0.5
+    prob = torch.softmax(logits, dim=-1)
+    return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob
+
+
+def dynamic_attention(q, k, v, topk: int):
+    """mdgat.py:196-210: per (batch, head, query) keep the ``topk`` largest logits, softmax over
+    those, zero probability elsewhere.  ``topk > M`` raises, as ``torch.topk`` does there."""
+    dh = q.shape[1]
+    m = k.shape[3]
+    if topk > m:
+        raise RuntimeError(f'selected index k out of range: k={topk} > {m} keys')
+    logits = torch.einsum('bdhn,bdhm->bhnm', q, k) / dh ** 0.5
+    top = logits.topk(topk, dim=3, largest=True, sorted=True)
+    prob = torch.zeros_like(logits)
+    prob.scatter_(3, top.indices, torch.softmax(top.values, dim=-1))
+    return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob
+
+
+def multi_head_attention(sd, prefix, x, source, topk: Optional[int]):
+    """MultiHeadedAttention.forward (mdgat.py:223-237).  The ``view(B, dh, H, -1)`` at 227/231
+    sends channel c to (d = c // H, h = c % H)."""
+    b, d_model, _ = x.shape
+    dh = d_model // NUM_HEADS
+    q = _pointwise(sd[f'{prefix}.proj.0.weight'], sd[f'{prefix}.proj.0.bias'], x).view(b, dh, NUM_HEADS, -1)
+    k = _pointwise(sd[f'{prefix}.proj.1.weight'], sd[f'{prefix}.proj.1.bias'], source).view(b, dh, NUM_HEADS, -1)
+    v = _pointwise(sd[f'{prefix}.proj.2.weight'], sd[f'{prefix}.proj.2.bias'], source).view(b, dh, NUM_HEADS, -1)
+    if topk is None:
+        msg, _ = attention(q, k, v)
+    else:
+        msg, _ = dynamic_attention(q, k, v, topk)
+    msg = msg.contiguous().view(b, d_model, -1)
+    return _pointwise(sd[f'{prefix}.merge.weight'], sd[f'{prefix}.merge.bias'], msg)
+
+
+def attentional_propagation(sd, prefix, x, source, topk):
+    """AttentionalPropagation.forward (mdgat.py:246-248): MLP([x ; message])."""
+    message = multi_head_attention(sd, f'{prefix}.attn', x, source, topk)
+    return mlp(sd, f'{prefix}.mlp', torch.cat([x, message], dim=1), 2)
+
+
+def layer_topk_schedule(L: int, k_list: List[Optional[int]]) -> List[Optional[int]]:
+    """mdgat.py:268-272: layer i (0-based over 2L) is dynamic with k_list[i - 2L + len] iff
+    i > 2L - 1 - len(k_list); ``None`` entries mean full attention."""
+    sched = []
+    for i in range(2 * L):
+        if i > 2 * L - 1 - len(k_list):
+            sched.append(k_list[i - 2 * L + len(k_list)])
+        else:
+            sched.append(None)
+    return sched
+
+
+def attentional_gnn(sd, desc0, desc1, k_list, L, capture=None):
+    """AttentionalGNN.forward (mdgat.py:259-276): alternating self/cross layers (352-353); both
+    frames use the same layer weights and the pre-update descriptors (270 before 274)."""
+    sched = layer_topk_schedule(L, k_list)
+    for i in range(2 * L):
+        cross = (i % 2 == 1)
+        src0, src1 = (desc1, desc0) if cross else (desc0, desc1)
+        p = f'gnn.layers.{i}'
+        delta0 = attentional_propagation(sd, p, desc0, src0, sched[i])
+        delta1 = attentional_propagation(sd, p, desc1, src1, sched[i])
+        desc0, desc1 = desc0 + delta0, desc1 + delta1
+        if capture is not None:
+            capture[f'layer{i}_desc0'] = desc0
+            capture[f'layer{i}_desc1'] = desc1
+    return desc0, desc1
+
+
+# ----------------------------------------------------------------------------- optimal transport
+def log_sinkhorn_iterations(Z, log_mu, log_nu, iters: int):
+    """mdgat.py:279-285: u-update then v-update, ``iters`` times, log domain."""
+    u = torch.zeros_like(log_mu)
+    v = torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v[:, None, :], dim=2)
+        v = log_nu - torch.logsumexp(Z + u[:, :, None], dim=1)
+    return Z + u[:, :, None] + v[:, None, :]
+
+
+def log_optimal_transport(scores, alpha, iters: int):
+    """mdgat.py:288-308: border the [B, N, M] scores with the dustbin score, run Sinkhorn with
+    marginals mu = [1..1, M] / (N + M), nu = [1..1, N] / (N + M), then subtract the norm."""
+    b, n, m = scores.shape
+    alpha = torch.as_tensor(alpha, dtype=scores.dtype, device=scores.device)
+    couplings = alpha * torch.ones(b, n + 1, m + 1, dtype=scores.dtype, device=scores.device)
+    couplings[:, :n, :m] = scores
+    norm = -math.log(n + m)
+    log_mu = torch.full((n + 1,), norm, dtype=scores.dtype, device=scores.device)
+    log_mu[n] = math.log(m) + norm
+    log_nu = torch.full((m + 1,), norm, dtype=scores.dtype, device=scores.device)
+    log_nu[m] = math.log(n) + norm
+    Z = log_sinkhorn_iterations(couplings, log_mu[None].expand(b, -1), log_nu[None].expand(b, -1), iters)
+    return Z - norm
+
+
+# ----------------------------------------------------------------------------- match extraction
+def extract_matches(Z, loss_method='triplet_loss', mutual_check=False, match_threshold=0.2):
+    """mdgat.py:441-483, all four branches.  Returns (matches0, matches1, mscores0, mscores1).
+
+    * ``loss_method == 'superglue'`` (444-458): arg-max over the inner N x M block, validity by
+      ``exp(max) > match_threshold`` (optionally after a mutual-nearest check).
+    * otherwise (461-481): arg-max including the dustbin column/row; a row is valid iff its
+      arg-max is not the dustbin (optionally also mutual).
+    ``torch.max`` returns the first maximal index on ties.  The reference's all-dustbin quirk
+    (465-467: integer zero scores) is reproduced as floating zeros of Z's dtype.
+    """
+    n, m = Z.shape[1] - 1, Z.shape[2] - 1
+    zero = Z.new_zeros(())
+    if loss_method == 'superglue':
+        inner = Z[:, :n, :m]
+        max0, max1 = inner.max(2), inner.max(1)
+        idx0, idx1 = max0.indices, max1.indices
+        e0, e1 = max0.values.exp(), max1.values.exp()
+        if mutual_check:
+            ar0 = torch.arange(n, device=Z.device)[None]
+            ar1 = torch.arange(m, device=Z.device)[None]
+            mutual0 = ar0 == idx1.gather(1, idx0)
+            mutual1 = ar1 == idx0.gather(1, idx1)
+            ms0 = torch.where(mutual0, e0, zero)
+            ms1 = torch.where(mutual1, ms0.gather(1, idx1), zero)
+            valid0 = mutual0 & (ms0 > match_threshold)
+            valid1 = mutual1 & valid0.gather(1, idx1)
+        else:
+            valid0, valid1 = e0 > match_threshold, e1 > match_threshold
+            ms0, ms1 = torch.where(valid0, e0, zero), torch.where(valid1, e1, zero)
+    else:
+        max0, max1 = Z[:, :n, :].max(2), Z[:, :, :m].max(1)
+        idx0, idx1 = max0.indices, max1.indices
+        valid0, valid1 = idx0 < m, idx1 < n
+        e0, e1 = max0.values.exp(), max1.values.exp()
+        if int(valid0.sum()) == 0:
+            ms0, ms1 = torch.zeros_like(e0), torch.zeros_like(e1)
+        elif mutual_check:
+            # 469-478: among valid rows, keep those whose partner points back
+            safe0 = torch.where(valid0, idx0, torch.zeros_like(idx0))
+            safe1 = torch.where(valid1, idx1, torch.zeros_like(idx1))
+            ar0 = torch.arange(n, device=Z.device)[None].expand_as(idx0)
+            ar1 = torch.arange(m, device=Z.device)[None].expand_as(idx1)
+            mutual0 = valid0 & (ar0 == idx1.gather(1, safe0))
+            mutual1 = valid1 & (ar1 == idx0.gather(1, safe1))
+            ms0, ms1 = torch.where(mutual0, e0, zero), torch.where(mutual1, e1, zero)
+        else:
+            ms0, ms1 = torch.where(valid0, e0, zero), torch.where(valid1, e1, zero)
+    matches0 = torch.where(valid0, idx0, torch.full_like(idx0, -1))
+    matches1 = torch.where(valid1, idx1, torch.full_like(idx1, -1))
+    return matches0, matches1, ms0, ms1
+
+
+# ----------------------------------------------------------------------------- dead-code kNN helpers
+def knn(x, src, k: int):
+    """mdgat.py:8-15: indices of the k nearest ``src`` columns for every ``x`` column
+    (x [B, C, N], src [B, C, M]) by negative squared distance, ``topk`` order."""
+    inner = -2.0 * torch.matmul(x.transpose(2, 1), src)
+    xx = (x ** 2).sum(dim=1, keepdim=True)
+    ss = (src ** 2).sum(dim=1, keepdim=True)
+    neg_dist = -xx.transpose(2, 1) - inner - ss
+    return neg_dist.topk(k=k, dim=-1)[1]
+
+
+def knn_adjacency(x, src, k: int, idx=None):
+    """mdgat.py:17-32 (get_graph_feature): dense 0/1 int64 adjacency [B, N, M] of the kNN graph."""
+    b, _, n = x.shape
+    m = src.shape[2]
+    if idx is None:
+        idx = knn(x, src, k)
+    adj = torch.zeros(b, n, m, dtype=torch.int64, device=x.device)
+    adj.scatter_(2, idx, 1)
+    return adj
+
+
+# ----------------------------------------------------------------------------- whole forward
+def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture: Optional[dict] = None):
+    """MDGAT.forward for ``descriptor == 'FPFH'`` (mdgat.py:369-483, 596-603), loss excluded.
+
+    ``capture`` (optional dict) receives the stage tensors the golden fixtures hold."""
+    dtype = sd['bin_score'].dtype
+    kpts0, kpts1 = data['keypoints0'].to(dtype), data['keypoints1'].to(dtype)
+    if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:          # mdgat.py:374-382
+        s0, s1 = kpts0.shape[:-1], kpts1.shape[:-1]
+        return {
+            'matches0': torch.full(s0, -1, dtype=torch.int32)[0],
+            'matches1': torch.full(s1, -1, dtype=torch.int32)[0],
+            'matching_scores0': torch.zeros(s0, dtype=dtype)[0],
+            'matching_scores1': torch.zeros(s1, dtype=dtype)[0],
+            'skip_train': True,
+        }
+    L = config['L']
+    d_model = config.get('descriptor_dim', 128)
+    desc0 = encode(sd, kpts0, data['scores0'].to(dtype), data['descriptors0'].to(dtype))
+    desc1 = encode(sd, kpts1, data['scores1'].to(dtype), data['descriptors1'].to(dtype))
+    if capture is not None:
+        capture['enc0'], capture['enc1'] = desc0, desc1
+    desc0, desc1 = attentional_gnn(sd, desc0, desc1, config['k'], L, capture)
+    mdesc0 = _pointwise(sd['final_proj.weight'], sd['final_proj.bias'], desc0)       # mdgat.py:397
+    mdesc1 = _pointwise(sd['final_proj.weight'], sd['final_proj.bias'], desc1)
+    scores = torch.einsum('bdn,bdm->bnm', mdesc0, mdesc1) / d_model ** 0.5           # mdgat.py:430-431
+    Z = log_optimal_transport(scores, sd['bin_score'], config.get('sinkhorn_iterations', 100))
+    if capture is not None:
+        capture['mdesc0'], capture['mdesc1'] = mdesc0, mdesc1
+        capture['scores'], capture['Z'] = scores, Z
+    m0, m1, s0, s1 = extract_matches(Z, config.get('loss_method', 'triplet_loss'),
+                                     config.get('mutual_check', False),
+                                     config.get('match_threshold', 0.2))
+    return {'matches0': m0, 'matches1': m1, 'matching_scores0': s0, 'matching_scores1': s1}

@@ -1,0 +1,159 @@
+"""Pin the CPU oracle (oracle/mdgat_oracle.py) to outputs of the real reference.
+
+The fixtures under tests/golden/ were produced by tools/make_goldens.py, which imports
+/root/reference/models/mdgat.py (fp64, CPU).  The reference ships no tests of its own
+(SURVEY.md section 4), so these are the only pins.  Everything here is fp64 vs fp64: the
+agreement must be at round-off level, and integer outputs must be identical."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from mdgat_matcher_amd import synth
+from oracle import mdgat_oracle as O
+
+FWD = ['fwd_n64_L1_S1', 'fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20']
+TOL = 1e-9
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _setup(g):
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    bin_score = float(g['bin_score']) if 'bin_score' in g else 1.0
+    sd = synth.make_state_dict(L=L, seed=seed, bin_score=bin_score)
+    data = synth.make_batch(B, n, m, first_pair=first_pair)
+    return sd, data, k, L, S, n, m
+
+
+@pytest.mark.parametrize('name', FWD)
+def test_forward_stage_tensors(golden_dir, name):
+    g = _load(golden_dir, name)
+    sd, data, k, L, S, n, m = _setup(g)
+    cap = {}
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
+    out = O.mdgat_forward(sd, cfg, data, cap)
+    keys = ['enc0', 'enc1', 'mdesc0', 'mdesc1', 'scores', 'Z'] + \
+           [f'layer{i}_desc{s}' for i in range(2 * L) for s in (0, 1)]
+    for key in keys:
+        err = np.abs(cap[key].numpy() - g[key]).max()
+        assert err < TOL, (key, err)
+    np.testing.assert_array_equal(out['matches0'].numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(out['matches1'].numpy(), g['default_matches1'])
+    np.testing.assert_allclose(out['matching_scores0'].numpy(), g['default_mscores0'], atol=TOL)
+    np.testing.assert_allclose(out['matching_scores1'].numpy(), g['default_mscores1'], atol=TOL)
+
+
+@pytest.mark.parametrize('name', FWD)
+def test_extraction_variants(golden_dir, name):
+    g = _load(golden_dir, name)
+    Z = torch.from_numpy(g['Z'])
+    for tag, (loss_method, mutual) in {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True),
+                                       'sg': ('superglue', False), 'sgmutual': ('superglue', True)}.items():
+        if f'{tag}_matches0' not in g:
+            continue
+        m0, m1, s0, s1 = O.extract_matches(Z, loss_method, mutual, 0.2)
+        np.testing.assert_array_equal(m0.numpy(), g[f'{tag}_matches0'], err_msg=tag)
+        np.testing.assert_array_equal(m1.numpy(), g[f'{tag}_matches1'], err_msg=tag)
+        np.testing.assert_allclose(s0.numpy(), g[f'{tag}_mscores0'], atol=TOL, err_msg=tag)
+        np.testing.assert_allclose(s1.numpy(), g[f'{tag}_mscores1'], atol=TOL, err_msg=tag)
+
+
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100'])
+def test_config_shapes(golden_dir, name):
+    g = _load(golden_dir, name)
+    sd, data, k, L, S, n, m = _setup(g)
+    cap = {}
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
+    torch.set_num_threads(os.cpu_count())
+    out = O.mdgat_forward(sd, cfg, data, cap)
+    Z = cap['Z']
+    assert np.abs(Z.numpy()[:, ::8, ::8] - g['Z_sub']).max() < 1e-8
+    assert np.abs(Z.numpy()[:, -1, :] - g['Z_lastrow']).max() < 1e-8
+    assert np.abs(Z.numpy()[:, :, -1] - g['Z_lastcol']).max() < 1e-8
+    assert np.abs(torch.logsumexp(Z, 2).numpy() - g['Z_row_lse']).max() < 1e-8
+    assert np.abs(torch.logsumexp(Z, 1).numpy() - g['Z_col_lse']).max() < 1e-8
+    np.testing.assert_array_equal(out['matches0'].numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(out['matches1'].numpy(), g['default_matches1'])
+    np.testing.assert_allclose(out['matching_scores0'].numpy(), g['default_mscores0'], atol=1e-9)
+
+
+def test_op_sinkhorn(golden_dir):
+    g = _load(golden_dir, 'op_vectors')
+    for tag in ('sk_7x5', 'sk_64x64', 'sk_48x64'):
+        iters, alpha = g[tag + '_meta']
+        Z = O.log_optimal_transport(torch.from_numpy(g[tag + '_scores']), float(alpha), int(iters))
+        assert np.abs(Z.numpy() - g[tag + '_Z']).max() < 1e-10, tag
+    iters, alpha = g['sk_512x512_meta']
+    s = torch.from_numpy(np.random.RandomState(int(g['sk_512x512_seed'][0])).standard_normal((1, 512, 512)) * 3.0)
+    Z = O.log_optimal_transport(s, float(alpha), int(iters)).numpy()
+    assert np.abs(Z[:, ::8, ::8] - g['sk_512x512_Z_sub']).max() < 1e-9
+    assert np.abs(Z[:, -1, :] - g['sk_512x512_Z_lastrow']).max() < 1e-9
+    assert np.abs(Z[:, :, -1] - g['sk_512x512_Z_lastcol']).max() < 1e-9
+
+
+def test_op_attention(golden_dir):
+    g = _load(golden_dir, 'op_vectors')
+    q, k, v = (torch.from_numpy(g[x]) for x in ('att_q', 'att_k', 'att_v'))
+    full, _ = O.attention(q, k, v)
+    assert np.abs(full.numpy() - g['att_full']).max() < 1e-12
+    for kk in (1, 8, 56):
+        dyn, prob = O.dynamic_attention(q, k, v, kk)
+        assert np.abs(dyn.numpy() - g[f'att_dyn{kk}']).max() < 1e-12
+        np.testing.assert_array_equal((prob > 0).sum(-1).numpy(), g[f'att_dyn{kk}_nnz'])
+    # k == M is full attention
+    assert np.abs(O.dynamic_attention(q, k, v, 56)[0].numpy() - g['att_full']).max() < 1e-12
+    with pytest.raises(RuntimeError):
+        O.dynamic_attention(q, k, v, 57)
+
+
+def test_op_knn(golden_dir):
+    g = _load(golden_dir, 'op_vectors')
+    for C in (3, 128):
+        x, s = torch.from_numpy(g[f'knn{C}_x']), torch.from_numpy(g[f'knn{C}_s'])
+        np.testing.assert_array_equal(O.knn(x, s, 9).numpy(), g[f'knn{C}_idx'])
+        np.testing.assert_array_equal(O.knn_adjacency(x, s, 9).numpy(), g[f'knn{C}_adj'])
+
+
+def test_layer_schedule():
+    # SURVEY.md section 3.2 [probe]: L=9, len(k)=8 -> layers 0-9 full; 10:128 11:None 12:128 13:None 14:64 15:None 16:64 17:None
+    s = O.layer_topk_schedule(9, synth.DEFAULT_K)
+    assert s == [None] * 10 + [128, None, 128, None, 64, None, 64, None]
+    assert O.layer_topk_schedule(4, synth.DEFAULT_K) == synth.DEFAULT_K
+    assert O.layer_topk_schedule(2, []) == [None] * 4
+
+
+def test_edge_cases(golden_dir):
+    g = _load(golden_dir, 'edge_cases')
+    L = 1
+    sd = synth.make_state_dict(L=L, seed=3)
+    cfg = synth.default_config(L=L, k=[], sinkhorn_iterations=5)
+    data = synth.make_batch(1, 8, 8)
+    data['keypoints0'] = data['keypoints0'][:, :0]
+    out = O.mdgat_forward(sd, cfg, data)
+    assert out['skip_train'] is True and bool(g['empty_skip'])
+    for a, b in (('matches0', 'empty_matches0'), ('matches1', 'empty_matches1'),
+                 ('matching_scores0', 'empty_mscores0'), ('matching_scores1', 'empty_mscores1')):
+        assert tuple(out[a].shape) == g[b].shape
+        np.testing.assert_array_equal(out[a].numpy(), g[b])
+    # k == M equals full attention end to end
+    data = synth.make_batch(1, 32, 32)
+    cap_full, cap_dyn = {}, {}
+    O.mdgat_forward(sd, synth.default_config(L=L, k=[], sinkhorn_iterations=10), data, cap_full)
+    O.mdgat_forward(sd, synth.default_config(L=L, k=[32, 32], sinkhorn_iterations=10), data, cap_dyn)
+    assert np.abs(cap_full['Z'].numpy() - g['keqM_Z_full']).max() < TOL
+    assert np.abs(cap_dyn['Z'].numpy() - g['keqM_Z_dyn']).max() < TOL
+    assert np.abs(g['keqM_Z_full'] - g['keqM_Z_dyn']).max() < 1e-9
+    # all-dustbin frame
+    sd_bin = synth.make_state_dict(L=L, seed=3, bin_score=50.0)
+    cap = {}
+    out = O.mdgat_forward(sd_bin, synth.default_config(L=L, k=[], sinkhorn_iterations=10), data, cap)
+    assert np.abs(cap['Z'].numpy() - g['alldust_Z']).max() < TOL
+    np.testing.assert_array_equal(out['matches0'].numpy(), g['alldust_matches0'])
+    np.testing.assert_array_equal(out['matches1'].numpy(), g['alldust_matches1'])
+    assert (out['matches0'] == -1).all()
+    np.testing.assert_array_equal(out['matching_scores0'].numpy(), g['alldust_mscores0'])

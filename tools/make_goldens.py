@@ -1,0 +1,270 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference (fp64, CPU) in the build container.
+
+Only runs where ``/root/reference`` exists (never on the GPU box).  ``models/mdgat.py`` is imported
+unmodified; because it hard-codes ``torch.device('cuda')`` (mdgat.py:25, 200, 466-467, 473-474)
+the module-level name ``torch`` *inside the imported module* is replaced by a thin proxy whose
+``device(...)`` answers CPU and whose ``zeros``/``zeros_like``/``arange`` drop a cuda ``device=``.
+No reference file is edited or copied; only inputs (by seed) and outputs are written.
+
+Fixtures (fp64 ``.npz``; weights are NOT stored - they are regenerated from the seed by
+``mdgat_matcher_amd.synth.make_state_dict``):
+
+* ``fwd_*``      full forward, tiny shapes: every stage tensor (encoder out, each layer, final
+                 projection, pre-OT scores, Z) + matches/mscores for the 4 extraction variants.
+* ``cfg_*``      BASELINE config shapes (N=256 L=4 S=20; N=512 L=9 S=100): matches, mscores,
+                 Z sub-sampled (every 8th row/col + dustbin row/col) and per-row LSE checksums.
+* ``op_*``       stand-alone ops: Sinkhorn, attention vs dynamic_attention, knn.
+* ``edge_*``     empty keypoints early-out, k == M, all-dustbin frame.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = os.environ.get('MDGAT_REFERENCE', '/root/reference')
+OUT = os.path.join(ROOT, 'tests', 'golden')
+
+from mdgat_matcher_amd import synth  # noqa: E402
+
+
+def import_reference():
+    sys.path.insert(0, REF)
+    import models.mdgat as M  # the reference, unmodified
+    cpu = torch.device('cpu')
+
+    class _TorchProxy(types.ModuleType):
+        def __getattr__(self, name):
+            return getattr(torch, name)
+
+    proxy = _TorchProxy('torch_cpu_proxy')
+    proxy.device = lambda *a, **k: cpu
+
+    def _strip(fn):
+        def inner(*a, **k):
+            if 'device' in k:
+                k['device'] = cpu
+            return fn(*a, **k)
+        return inner
+    for name in ('zeros', 'zeros_like', 'arange', 'ones', 'ones_like'):
+        setattr(proxy, name, _strip(getattr(torch, name)))
+    M.torch = proxy
+    return M
+
+
+def build_ref_net(M, cfg, sd):
+    net = M.MDGAT(cfg).double().eval()
+    missing = net.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return net
+
+
+def run_ref(M, net, data, capture=True):
+    """Forward with hooks capturing stage tensors."""
+    cap = {}
+    hooks = []
+    if capture:
+        hooks.append(net.kenc.register_forward_hook(lambda m, i, o: cap.setdefault('kenc', []).append(o.detach().clone())))
+        hooks.append(net.denc.register_forward_hook(lambda m, i, o: cap.setdefault('denc', []).append(o.detach().clone())))
+        hooks.append(net.final_proj.register_forward_hook(lambda m, i, o: cap.setdefault('mdesc', []).append(o.detach().clone())))
+        for li, layer in enumerate(net.gnn.layers):
+            hooks.append(layer.register_forward_hook(
+                lambda m, i, o, li=li: cap.setdefault(f'delta{li}', []).append((i[0].detach().clone(), o.detach().clone()))))
+    orig_lot = M.log_optimal_transport
+
+    def lot(scores, alpha, iters):
+        cap['scores'] = scores.detach().clone()
+        Z = orig_lot(scores, alpha, iters)
+        cap['Z'] = Z.detach().clone()
+        return Z
+    M.log_optimal_transport = lot
+    try:
+        with torch.no_grad():
+            d = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in data.items()}
+            out = net(d)
+    finally:
+        M.log_optimal_transport = orig_lot
+        for h in hooks:
+            h.remove()
+    return out, cap
+
+
+def stage_dict(cap, L):
+    st = {}
+    st['enc0'] = (cap['denc'][0] + cap['kenc'][0]).numpy()
+    st['enc1'] = (cap['denc'][1] + cap['kenc'][1]).numpy()
+    for li in range(2 * L):
+        (x0, d0), (x1, d1) = cap[f'delta{li}']
+        st[f'layer{li}_desc0'] = (x0 + d0).numpy()
+        st[f'layer{li}_desc1'] = (x1 + d1).numpy()
+    st['mdesc0'], st['mdesc1'] = cap['mdesc'][0].numpy(), cap['mdesc'][1].numpy()
+    st['scores'] = cap['scores'].numpy()
+    st['Z'] = cap['Z'].numpy()
+    return st
+
+
+def out_arrays(out, tag):
+    return {
+        f'{tag}_matches0': out['matches0'].numpy().astype(np.int64),
+        f'{tag}_matches1': out['matches1'].numpy().astype(np.int64),
+        f'{tag}_mscores0': out['matching_scores0'].numpy().astype(np.float64),
+        f'{tag}_mscores1': out['matching_scores1'].numpy().astype(np.float64),
+    }
+
+
+VARIANTS = {  # tag -> (loss_method, mutual_check)
+    'default': ('triplet_loss', False),
+    'mutual': ('triplet_loss', True),
+    'sg': ('superglue', False),
+    'sgmutual': ('superglue', True),
+}
+
+
+def gen_forward(M, name, B, n, m, L, S, k, seed=0, bin_score=1.0, first_pair=0):
+    sd = synth.make_state_dict(L=L, seed=seed, bin_score=bin_score)
+    data = synth.make_batch(B, n, m, first_pair=first_pair)
+    arrays = {'meta': np.array([B, n, m, L, S, seed, first_pair], dtype=np.int64),
+              'k': np.array([-1 if x is None else x for x in k], dtype=np.int64),
+              'bin_score': np.array(bin_score)}
+    for tag, (loss_method, mutual) in VARIANTS.items():
+        if mutual and B != 1:
+            continue  # reference's mutual branch of 469-478 only works for batch 1 (mask shape)
+        if n != m:
+            # the reference's triplet and superglue LOSS code (mdgat.py:494-539) raises a shape
+            # error when N != M; 'gap_loss' shares the default extraction branch (459-483) and
+            # its loss runs for ragged pairs, so ragged fixtures use it and skip 'superglue'.
+            if loss_method == 'superglue':
+                continue
+            loss_method = 'gap_loss'
+        cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual)
+        net = build_ref_net(M, cfg, sd)
+        # gt_matches are all -1 (synth.make_batch): every loss branch (487-594) then runs without
+        # an out-of-range index; the loss value itself is not captured (training-only, out of scope).
+        out, cap = run_ref(M, net, data, capture=(tag == 'default'))
+        if tag == 'default':
+            arrays.update(stage_dict(cap, L))
+        arrays.update(out_arrays(out, tag))
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    print('wrote', name, {k2: v.shape for k2, v in arrays.items() if k2 in ('Z', 'scores')})
+
+
+def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0):
+    sd = synth.make_state_dict(L=L, seed=seed)
+    data = synth.make_batch(B, n, m, first_pair=first_pair)
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
+    net = build_ref_net(M, cfg, sd)
+    out, cap = run_ref(M, net, data, capture=False)
+    Z = cap['Z'].numpy()
+    arrays = {'meta': np.array([B, n, m, L, S, seed, first_pair], dtype=np.int64),
+              'k': np.array([-1 if x is None else x for x in k], dtype=np.int64)}
+    arrays.update(out_arrays(out, 'default'))
+    arrays['Z_sub'] = Z[:, ::8, ::8].copy()
+    arrays['Z_lastrow'] = Z[:, -1, :].copy()
+    arrays['Z_lastcol'] = Z[:, :, -1].copy()
+    arrays['Z_row_lse'] = torch.logsumexp(cap['Z'], dim=2).numpy()
+    arrays['Z_col_lse'] = torch.logsumexp(cap['Z'], dim=1).numpy()
+    arrays['scores_sub'] = cap['scores'].numpy()[:, ::8, ::8].copy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    print('wrote', name, Z.shape)
+
+
+def gen_ops(M):
+    rs = np.random.RandomState(42)
+    arrays = {}
+    # Sinkhorn on random scores
+    for (n, m, iters, alpha) in ((7, 5, 20, 1.0), (64, 64, 100, 0.37), (48, 64, 50, 1.0), (512, 512, 100, 1.0)):
+        s = torch.from_numpy(rs.standard_normal((2, n, m)) * 3.0)
+        Z = M.log_optimal_transport(s, torch.tensor(alpha, dtype=torch.float64), iters)
+        tag = f'sk_{n}x{m}'
+        if n == 512:
+            arrays[tag + '_seed'] = np.array([4242])
+            s = torch.from_numpy(np.random.RandomState(4242).standard_normal((1, n, m)) * 3.0)
+            Z = M.log_optimal_transport(s, torch.tensor(alpha, dtype=torch.float64), iters)
+            arrays[tag + '_Z_sub'] = Z.numpy()[:, ::8, ::8].copy()
+            arrays[tag + '_Z_lastrow'] = Z.numpy()[:, -1, :].copy()
+            arrays[tag + '_Z_lastcol'] = Z.numpy()[:, :, -1].copy()
+        else:
+            arrays[tag + '_scores'] = s.numpy()
+            arrays[tag + '_Z'] = Z.numpy()
+        arrays[tag + '_meta'] = np.array([iters, alpha])
+    # attention / dynamic attention on random q/k/v, [B, dh, H, N]
+    q = torch.from_numpy(rs.standard_normal((2, 32, 4, 40)) * 1.5)
+    k = torch.from_numpy(rs.standard_normal((2, 32, 4, 56)) * 1.5)
+    v = torch.from_numpy(rs.standard_normal((2, 32, 4, 56)))
+    full, _ = M.attention(q, k, v)
+    arrays.update(att_q=q.numpy(), att_k=k.numpy(), att_v=v.numpy(), att_full=full.numpy())
+    for kk in (1, 8, 56):
+        dyn, prob = M.dynamic_attention(q, k, v, kk)
+        arrays[f'att_dyn{kk}'] = dyn.numpy()
+        arrays[f'att_dyn{kk}_nnz'] = (prob > 0).sum(-1).numpy()
+    # knn (dead code in the reference, named by north_star)
+    for C in (3, 128):
+        x = torch.from_numpy(rs.standard_normal((2, C, 50)))
+        s = torch.from_numpy(rs.standard_normal((2, C, 70)))
+        idx = M.knn(x, s, 9)
+        A = M.get_graph_feature(x, s, 9)
+        arrays[f'knn{C}_x'], arrays[f'knn{C}_s'] = x.numpy(), s.numpy()
+        arrays[f'knn{C}_idx'], arrays[f'knn{C}_adj'] = idx.numpy(), A.numpy()
+    np.savez_compressed(os.path.join(OUT, 'op_vectors.npz'), **arrays)
+    print('wrote op_vectors')
+
+
+def gen_edges(M):
+    arrays = {}
+    L = 1
+    sd = synth.make_state_dict(L=L, seed=3)
+    # empty keypoints early-out (mdgat.py:374-382)
+    cfg = synth.default_config(L=L, k=[], sinkhorn_iterations=5)
+    net = build_ref_net(M, cfg, sd)
+    data = synth.make_batch(1, 8, 8)
+    data['keypoints0'] = data['keypoints0'][:, :0]
+    with torch.no_grad():
+        out = net(data)
+    arrays['empty_matches0'] = out['matches0'].numpy()
+    arrays['empty_matches1'] = out['matches1'].numpy()
+    arrays['empty_mscores0'] = out['matching_scores0'].numpy()
+    arrays['empty_mscores1'] = out['matching_scores1'].numpy()
+    arrays['empty_skip'] = np.array(out['skip_train'])
+    # k == M: dynamic attention over all keys == full attention
+    cfg_full = synth.default_config(L=L, k=[], sinkhorn_iterations=10)
+    cfg_kM = synth.default_config(L=L, k=[32, 32], sinkhorn_iterations=10)
+    data = synth.make_batch(1, 32, 32)
+    o_full, c_full = run_ref(M, build_ref_net(M, cfg_full, sd), data, capture=False)
+    o_kM, c_kM = run_ref(M, build_ref_net(M, cfg_kM, sd), data, capture=False)
+    arrays['keqM_Z_full'] = c_full['Z'].numpy()
+    arrays['keqM_Z_dyn'] = c_kM['Z'].numpy()
+    # all-dustbin frame: a huge bin score sends every row to the dustbin (mdgat.py:465-467 quirk)
+    sd_bin = synth.make_state_dict(L=L, seed=3, bin_score=50.0)
+    o_bin, c_bin = run_ref(M, build_ref_net(M, cfg_full, sd_bin), data, capture=False)
+    arrays['alldust_Z'] = c_bin['Z'].numpy()
+    arrays['alldust_matches0'] = o_bin['matches0'].numpy()
+    arrays['alldust_matches1'] = o_bin['matches1'].numpy()
+    arrays['alldust_mscores0'] = o_bin['matching_scores0'].numpy().astype(np.float64)
+    arrays['alldust_mscores1'] = o_bin['matching_scores1'].numpy().astype(np.float64)
+    arrays['alldust_mscores_is_int'] = np.array(not o_bin['matching_scores0'].dtype.is_floating_point)
+    np.savez_compressed(os.path.join(OUT, 'edge_cases.npz'), **arrays)
+    print('wrote edge_cases', 'int-quirk:', arrays['alldust_mscores_is_int'])
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(os.cpu_count())
+    M = import_reference()
+    small_k = [16, None, 16, None, 8, None, 8, None]
+    gen_forward(M, 'fwd_n64_L1_S1', 1, 64, 64, 1, 1, small_k)
+    gen_forward(M, 'fwd_n64_L4_S20', 1, 64, 64, 4, 20, small_k)
+    gen_forward(M, 'fwd_n64_L5_S20', 2, 64, 64, 5, 20, small_k)
+    gen_forward(M, 'fwd_n48m64_L4_S20', 1, 48, 64, 4, 20, small_k, bin_score=0.37, first_pair=5)
+    gen_config(M, 'cfg_n256_L4_S20', 1, 256, 256, 4, 20, synth.DEFAULT_K)
+    gen_config(M, 'cfg_n512_L9_S100', 2, 512, 512, 9, 100, synth.DEFAULT_K)
+    gen_ops(M)
+    gen_edges(M)
+
+
+if __name__ == '__main__':
+    main()
