@@ -1,0 +1,144 @@
+/*
+ * mdgat_hip.h - C ABI of libmdgat_hip.so: the MI355X (gfx950) implementation of the inference
+ * hot path of MDGAT-matcher.
+ *
+ * The reference (nubot-nudt/MDGAT-matcher) is pure Python/PyTorch: it has NO native boundary.  The
+ * seam this library sits behind is the Python class models.mdgat.MDGAT
+ * (/root/reference/models/mdgat.py:315-603) as called from test.py:201 and
+ * test_registration_metric.py:202.  Each entry point below names the reference code it replaces.
+ * The Python host side (mdgat_matcher_amd/mdgat.py) binds these with ctypes; INTEGRATION.md shows
+ * the stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every data pointer is DEVICE memory unless stated otherwise;
+ *   - all tensors are owned by the caller (PyTorch); the library keeps only its packed weights;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - return 0 on success, a negative mdgat_status otherwise; mdgat_last_error() gives the text;
+ *   - a handle is bound to one device and is not re-entrant (the Python wrapper serialises calls).
+ *
+ * Layouts (fp32, row-major, innermost last)
+ *   keypoints  kpts  [B][N][3]      saliency sigma [B][N]      FPFH fpfh [B][N][33]
+ *   descriptors x    [B][P][128]    P = N + M, frame-0 points first, then frame-1 points
+ *   q/k/v      qkv   [B][P][3][4][32]  (which, head, dim) - heads de-interleaved, see pack.py
+ *   scores           [B][N][M]      couplings / Z  [B][N+1][M+1]
+ *   matches    int64 [B][N] / [B][M]    matching scores fp32 [B][N] / [B][M]
+ */
+#ifndef MDGAT_HIP_H
+#define MDGAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MDGAT_MAX_LAYERS 64 /* 2L <= 64 */
+#define MDGAT_D 128         /* descriptor_dim (mdgat.py:317) */
+#define MDGAT_HEADS 4       /* mdgat.py:255 */
+#define MDGAT_FPFH 33       /* mdgat.py:148 */
+
+typedef enum {
+    MDGAT_OK = 0,
+    MDGAT_ERR_BAD_ARG = -1,     /* e.g. top-k larger than the number of keys (torch.topk raises there) */
+    MDGAT_ERR_HIP = -2,         /* a HIP runtime call failed */
+    MDGAT_ERR_UNSUPPORTED = -3, /* shape / config outside what the kernels implement */
+    MDGAT_ERR_NO_WEIGHTS = -4
+} mdgat_status;
+
+/* match-extraction variants of mdgat.py:441-483 */
+typedef enum {
+    MDGAT_EXTRACT_DUSTBIN = 0,        /* loss_method != 'superglue', mutual_check False (461-464, 480-483) */
+    MDGAT_EXTRACT_DUSTBIN_MUTUAL = 1, /* loss_method != 'superglue', mutual_check True  (469-478) */
+    MDGAT_EXTRACT_THRESHOLD = 2,      /* loss_method == 'superglue', mutual_check False (444, 455-458) */
+    MDGAT_EXTRACT_THRESHOLD_MUTUAL = 3 /* loss_method == 'superglue', mutual_check True (447-453) */
+} mdgat_extract_mode;
+
+/* Replaces the config dict of MDGAT.__init__ (mdgat.py:325-367) for descriptor == 'FPFH'. */
+typedef struct {
+    int32_t L;                         /* config['L']: 2L alternating self/cross layers (352-353) */
+    int32_t sinkhorn_iters;            /* config['sinkhorn_iterations'] (321) */
+    int32_t topk[MDGAT_MAX_LAYERS];    /* per layer 0..2L-1: 0 = attention() (190-194), k > 0 =
+                                          dynamic_attention(k) (196-210); schedule of 268-272 is
+                                          resolved by the host */
+    int32_t extract_mode;              /* mdgat_extract_mode */
+    float match_threshold;             /* config['match_threshold'] (322) */
+} mdgat_config;
+
+typedef struct mdgat_handle mdgat_handle;
+
+/* Optional taps for parity tests: any pointer may be NULL. */
+typedef struct {
+    float* x_enc;    /* [B][P][128]        encoder sum (mdgat.py:392-393) */
+    float* x_layers; /* [2L][B][P][128]    descriptors after every layer (mdgat.py:274) */
+    float* mdesc;    /* [B][P][128]        final_proj output (mdgat.py:397) */
+    float* scores;   /* [B][N][M]          pre-OT scores (mdgat.py:430-431) */
+} mdgat_taps;
+
+/* ---- lifetime ------------------------------------------------------------------------------ */
+
+/* MDGAT(config).to(device) (test.py:156, 172).  Fails with MDGAT_ERR_UNSUPPORTED unless the
+ * device is gfx950. */
+int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out);
+
+/* net.load_state_dict(...) (test.py:159) after host-side packing (BN folded into the convs, heads
+ * de-interleaved, merge folded into mlp.0; mdgat_matcher_amd/pack.py).  `blob` holds
+ * mdgat_blob_floats(L) fp32 values; `on_device` != 0 when it is device memory (e.g. received by
+ * an RCCL broadcast), else host memory. */
+int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device);
+size_t mdgat_blob_floats(int L);
+
+/* Device pointer to the handle's packed weights (for an RCCL broadcast from rank 0). */
+float* mdgat_weights_device_ptr(mdgat_handle* h);
+
+void mdgat_destroy(mdgat_handle* h);
+const char* mdgat_last_error(void);
+
+/* ---- whole forward ---------------------------------------------------------------------------- */
+
+/* Scratch the caller must provide to mdgat_forward for a batch of B pairs with N / M keypoints. */
+size_t mdgat_workspace_bytes(const mdgat_handle* h, int B, int N, int M);
+
+/* MDGAT.forward (mdgat.py:369-483) for descriptor == 'FPFH', loss excluded.
+ * Z (optional, may be NULL) receives log_optimal_transport's output [B][N+1][M+1]. */
+int mdgat_forward(mdgat_handle* h, int B, int N, int M,
+                  const float* kpts0, const float* sigma0, const float* fpfh0,
+                  const float* kpts1, const float* sigma1, const float* fpfh1,
+                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
+                  float* Z, const mdgat_taps* taps,
+                  void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
+
+/* log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308): scores [B][N][M] -> Z. */
+int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, int iters,
+                   float* Z, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdgat_sinkhorn_workspace_bytes(int B, int N, int M);
+
+/* match extraction (mdgat.py:441-483) from Z [B][N+1][M+1]. */
+int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_threshold,
+                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
+                  void* stream);
+
+/* attention / dynamic_attention (mdgat.py:190-210) on projected q/k/v in the library layout
+ * [B][P][3][4][32]; `cross` selects the other frame as source (mdgat.py:263-266); topk 0 = full.
+ * msg [B][P][128] with channel = head*32 + dim. */
+int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg,
+                    void* stream);
+
+/* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
+ * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */
+int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw,
+                    const float* bias, int relu, const float* R, int ldr, float* C, int ldc,
+                    void* stream);
+
+/* knn() / get_graph_feature() (mdgat.py:8-32; dead code there, named by the north star):
+ * x [B][N][C], src [B][M][C] (point-major) -> idx int64 [B][N][k] in topk order (nearest first),
+ * and, if adj != NULL, the dense 0/1 int64 adjacency [B][N][M]. */
+int mdgat_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx,
+              int64_t* adj, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MDGAT_HIP_H */

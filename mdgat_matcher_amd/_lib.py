@@ -1,0 +1,91 @@
+"""ctypes binding of libmdgat_hip.so (C ABI in include/mdgat_hip.h).
+
+The library is hand-written HIP for gfx950; there is no CPU or PyTorch fallback: if the shared
+object is missing, importing the product path raises immediately."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmdgat_hip.so')
+
+MAX_LAYERS = 64
+
+EXTRACT_DUSTBIN = 0
+EXTRACT_DUSTBIN_MUTUAL = 1
+EXTRACT_THRESHOLD = 2
+EXTRACT_THRESHOLD_MUTUAL = 3
+
+OK = 0
+ERR_BAD_ARG = -1
+ERR_HIP = -2
+ERR_UNSUPPORTED = -3
+ERR_NO_WEIGHTS = -4
+
+
+class MdgatConfig(C.Structure):
+    _fields_ = [
+        ('L', C.c_int32),
+        ('sinkhorn_iters', C.c_int32),
+        ('topk', C.c_int32 * MAX_LAYERS),
+        ('extract_mode', C.c_int32),
+        ('match_threshold', C.c_float),
+    ]
+
+
+class MdgatTaps(C.Structure):
+    _fields_ = [('x_enc', C.c_void_p), ('x_layers', C.c_void_p), ('mdesc', C.c_void_p), ('scores', C.c_void_p)]
+
+
+# name -> (restype, argtypes); every symbol include/mdgat_hip.h declares
+SIGNATURES = {
+    'mdgat_create': (C.c_int, [C.POINTER(MdgatConfig), C.c_int, C.POINTER(C.c_void_p)]),
+    'mdgat_load_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    'mdgat_blob_floats': (C.c_size_t, [C.c_int]),
+    'mdgat_weights_device_ptr': (C.c_void_p, [C.c_void_p]),
+    'mdgat_destroy': (None, [C.c_void_p]),
+    'mdgat_last_error': (C.c_char_p, []),
+    'mdgat_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    'mdgat_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p] * 4 +
+                      [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_sinkhorn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_size_t, C.c_void_p]),
+    'mdgat_sinkhorn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'mdgat_extract': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
+    'mdgat_attention': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mdgat_pointwise': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                  C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'mdgat_knn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                            C.c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built - there is no fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f'{LIB_PATH} is missing: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+            f'or `make -C mdgat_matcher_amd/csrc`.  mdgat_matcher_amd has no CPU / PyTorch fallback.')
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load().mdgat_last_error().decode('utf-8', 'replace')
+
+
+def check(rc: int, what: str = 'libmdgat_hip'):
+    """Raise like the reference would: RuntimeError carrying the library's message."""
+    if rc != OK:
+        raise RuntimeError(f'{what} failed (status {rc}): {last_error()}')

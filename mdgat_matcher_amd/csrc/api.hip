@@ -1,0 +1,282 @@
+// C ABI of libmdgat_hip.so (see include/mdgat_hip.h) and the launch sequence of one forward.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "common.hpp"
+
+// ---------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = "";
+
+void mdgat_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int mdgat_check_hip(hipError_t e, const char* what) {
+    if (e == hipSuccess) return MDGAT_OK;
+    mdgat_set_error("%s: %s", what, hipGetErrorString(e));
+    return MDGAT_ERR_HIP;
+}
+
+extern "C" const char* mdgat_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------- blob layout
+BlobLayout mdgat_blob_layout(int L) {
+    BlobLayout b{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 3) & ~size_t(3); return r; };
+    b.kenc0_w = take(32 * 4);    b.kenc0_b = take(32);
+    b.denc0_w = take(64 * 33);   b.denc0_b = take(64);
+    b.kenc1_w = take(64 * 32);   b.kenc1_b = take(64);
+    b.kenc2_w = take(128 * 64);  b.kenc2_b = take(128);
+    b.denc1_w = take(128 * 64);  b.denc1_b = take(128);
+    b.encl_w = take(128 * 256);  b.encl_b = take(128);
+    b.layer0 = o;
+    size_t lo = 0;
+    auto ltake = [&](size_t n) { size_t r = lo; lo += (n + 3) & ~size_t(3); return r; };
+    b.qkv_w = ltake(384 * 128);  b.qkv_b = ltake(384);
+    b.mlp1_w = ltake(256 * 256); b.mlp1_b = ltake(256);
+    b.mlp2_w = ltake(128 * 256); b.mlp2_b = ltake(128);
+    b.layer_stride = lo;
+    o += lo * (size_t)(2 * L);
+    b.final_w = take(128 * 128); b.final_b = take(128);
+    b.bin_score = take(1);
+    b.total = o;
+    return b;
+}
+
+extern "C" size_t mdgat_blob_floats(int L) { return mdgat_blob_layout(L).total; }
+
+// ---------------------------------------------------------------------------------- handle
+struct mdgat_handle {
+    mdgat_config cfg;
+    int device;
+    BlobLayout bl;
+    float* weights;   // device
+    bool loaded;
+};
+
+extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
+    if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->L < 0 || 2 * cfg->L > MDGAT_MAX_LAYERS) { mdgat_set_error("mdgat_create: L=%d out of range", cfg->L); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->extract_mode < 0 || cfg->extract_mode > 3) { mdgat_set_error("mdgat_create: bad extract_mode %d", cfg->extract_mode); return MDGAT_ERR_BAD_ARG; }
+    for (int i = 0; i < 2 * cfg->L; ++i)
+        if (cfg->topk[i] < 0) { mdgat_set_error("mdgat_create: topk[%d] < 0", i); return MDGAT_ERR_BAD_ARG; }
+    hipDeviceProp_t prop;
+    if (int rc = mdgat_check_hip(hipGetDeviceProperties(&prop, device), "hipGetDeviceProperties")) return rc;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        mdgat_set_error("mdgat_create: device %d is %s; this library is built for gfx950 (MI355X) only", device, prop.gcnArchName);
+        return MDGAT_ERR_UNSUPPORTED;
+    }
+    mdgat_handle* h = new (std::nothrow) mdgat_handle();
+    if (!h) { mdgat_set_error("mdgat_create: out of host memory"); return MDGAT_ERR_HIP; }
+    h->cfg = *cfg;
+    h->device = device;
+    h->bl = mdgat_blob_layout(cfg->L);
+    h->weights = nullptr;
+    h->loaded = false;
+    int prev = 0;
+    hipGetDevice(&prev);
+    int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
+    if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
+    hipSetDevice(prev);
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return MDGAT_OK;
+}
+
+extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device) {
+    if (!h || !blob) { mdgat_set_error("mdgat_load_weights: null argument"); return MDGAT_ERR_BAD_ARG; }
+    if (n_floats != h->bl.total) {
+        mdgat_set_error("mdgat_load_weights: blob has %zu floats, expected %zu for L=%d", n_floats, h->bl.total, h->cfg.L);
+        return MDGAT_ERR_BAD_ARG;
+    }
+    if (blob != h->weights) {
+        if (int rc = mdgat_check_hip(hipMemcpy(h->weights, blob, n_floats * sizeof(float),
+                                               on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice),
+                                     "hipMemcpy(weights)"))
+            return rc;
+    }
+    h->loaded = true;
+    return MDGAT_OK;
+}
+
+extern "C" float* mdgat_weights_device_ptr(mdgat_handle* h) { return h ? h->weights : nullptr; }
+
+extern "C" void mdgat_destroy(mdgat_handle* h) {
+    if (!h) return;
+    if (h->weights) hipFree(h->weights);
+    delete h;
+}
+
+// ---------------------------------------------------------------------------------- workspace
+namespace {
+struct Workspace {
+    float *x, *qkv, *hid, *msg, *scores, *Z;
+    size_t total;   // floats
+};
+Workspace carve(float* base, int B, int N, int M) {
+    const size_t R = (size_t)B * (N + M);
+    Workspace w{};
+    size_t o = 0;
+    auto take = [&](size_t n) { size_t r = o; o += (n + 63) & ~size_t(63); return base ? base + r : nullptr; };
+    w.x = take(R * 128);
+    w.qkv = take(R * 384);   // qkv and hid are contiguous: the encoder uses them as one scratch area
+    w.hid = take(R * 256);
+    w.msg = take(R * 128);
+    w.scores = take((size_t)B * N * M);
+    w.Z = take((size_t)B * (N + 1) * (M + 1));
+    w.total = o;
+    return w;
+}
+}  // namespace
+
+extern "C" size_t mdgat_workspace_bytes(const mdgat_handle*, int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return carve(nullptr, B, N, M).total * sizeof(float);
+}
+
+// ---------------------------------------------------------------------------------- forward
+static GemmArgs pointwise(const float* A, int lda, int K, const float* W, const float* bias, int relu, float* C, int ldc,
+                          int rows, int cout) {
+    GemmArgs g{};
+    g.A0 = A; g.lda0 = lda; g.K0 = K; g.A1 = nullptr; g.lda1 = 0;
+    g.W = W; g.ldw = K; g.bias = bias; g.R = nullptr; g.ldr = 0;
+    g.C = C; g.ldc = ldc; g.M = rows; g.N = cout; g.K = K; g.relu = relu; g.scale = 1.f;
+    g.batch = 1; g.sA = g.sW = g.sC = 0;
+    return g;
+}
+
+extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
+                             const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
+                             int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                             const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
+    if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
+    if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
+    if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1 || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
+        mdgat_set_error("mdgat_forward: null pointer argument");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    const size_t need = mdgat_workspace_bytes(h, B, N, M);
+    if (workspace_bytes < need) { mdgat_set_error("mdgat_forward: workspace %zu < %zu bytes", workspace_bytes, need); return MDGAT_ERR_BAD_ARG; }
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) { mdgat_set_error("mdgat_forward: workspace must be 256-byte aligned"); return MDGAT_ERR_BAD_ARG; }
+    const int L2 = 2 * h->cfg.L;
+    for (int i = 0; i < L2; ++i) {
+        const int k = h->cfg.topk[i];
+        if (k > 0 && (k > N || k > M)) {   // torch.topk raises (mdgat.py:202)
+            mdgat_set_error("layer %d: dynamic attention k=%d exceeds the number of keys (N=%d, M=%d)", i, k, N, M);
+            return MDGAT_ERR_BAD_ARG;
+        }
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const BlobLayout& bl = h->bl;
+    const float* w = h->weights;
+    Workspace ws = carve(static_cast<float*>(workspace), B, N, M);
+    const int P = N + M;
+    const int R = B * P;
+    int rc;
+
+    // ---- encoders (mdgat.py:392-393) ----
+    float* scr = ws.qkv;                 // R*640 floats of scratch (qkv + hid)
+    float* hk0 = scr;                    // [R][32]
+    float* hd0 = hk0 + (size_t)R * 32;   // [R][64]
+    float* hk1 = hd0 + (size_t)R * 64;   // [R][64]
+    float* hk2 = hk1 + (size_t)R * 64;   // [R][128]
+    float* hd1 = hk2 + (size_t)R * 128;  // [R][128]
+    if ((rc = launch_encode_l0(B, N, P, 0, kpts0, sigma0, fpfh0, w, bl, hk0, hd0, s))) return rc;
+    if ((rc = launch_encode_l0(B, M, P, N, kpts1, sigma1, fpfh1, w, bl, hk0, hd0, s))) return rc;
+    if ((rc = launch_gemm(pointwise(hk0, 32, 32, w + bl.kenc1_w, w + bl.kenc1_b, 1, hk1, 64, R, 64), s))) return rc;
+    if ((rc = launch_gemm(pointwise(hk1, 64, 64, w + bl.kenc2_w, w + bl.kenc2_b, 1, hk2, 128, R, 128), s))) return rc;
+    if ((rc = launch_gemm(pointwise(hd0, 64, 64, w + bl.denc1_w, w + bl.denc1_b, 1, hd1, 128, R, 128), s))) return rc;
+    {
+        GemmArgs g = pointwise(hd1, 128, 256, w + bl.encl_w, w + bl.encl_b, 0, ws.x, 128, R, 128);
+        g.K0 = 128; g.A1 = hk2; g.lda1 = 128;
+        if ((rc = launch_gemm(g, s))) return rc;
+    }
+    if (taps && taps->x_enc)
+        if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
+
+    // ---- 2L attentional propagation layers (mdgat.py:259-276) ----
+    for (int i = 0; i < L2; ++i) {
+        const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
+        const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
+        // q, k, v of every point from its own descriptor (proj[0..2], mdgat.py:227-232)
+        if ((rc = launch_gemm(pointwise(ws.x, 128, 128, lw + bl.qkv_w, lw + bl.qkv_b, 0, ws.qkv, 384, R, 384), s))) return rc;
+        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], ws.qkv, ws.msg, s))) return rc;
+        // hidden = relu(BN(W1 [x ; merge(msg)])) with merge and BN folded into W1 (mdgat.py:237, 247-248)
+        {
+            GemmArgs g = pointwise(ws.x, 128, 256, lw + bl.mlp1_w, lw + bl.mlp1_b, 1, ws.hid, 256, R, 256);
+            g.K0 = 128; g.A1 = ws.msg; g.lda1 = 128;
+            if ((rc = launch_gemm(g, s))) return rc;
+        }
+        // x += W2 hidden + b2 (mdgat.py:248, 274)
+        {
+            GemmArgs g = pointwise(ws.hid, 256, 256, lw + bl.mlp2_w, lw + bl.mlp2_b, 0, ws.x, 128, R, 128);
+            g.R = ws.x; g.ldr = 128;
+            if ((rc = launch_gemm(g, s))) return rc;
+        }
+        if (taps && taps->x_layers)
+            if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_layers + (size_t)i * R * 128, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_layers"))) return rc;
+    }
+
+    // ---- final projection (mdgat.py:397) and score matrix (430-431) ----
+    float* mdesc = ws.msg;
+    if ((rc = launch_gemm(pointwise(ws.x, 128, 128, w + bl.final_w, w + bl.final_b, 0, mdesc, 128, R, 128), s))) return rc;
+    if (taps && taps->mdesc)
+        if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
+    {
+        GemmArgs g{};
+        g.A0 = mdesc; g.lda0 = 128; g.K0 = 128; g.W = mdesc + (size_t)N * 128; g.ldw = 128;
+        g.C = ws.scores; g.ldc = M; g.M = N; g.N = M; g.K = 128; g.relu = 0;
+        g.scale = 0.08838834764831845f;   // 1 / sqrt(128)
+        g.batch = B; g.sA = (long long)P * 128; g.sW = (long long)P * 128; g.sC = (long long)N * M;
+        if ((rc = launch_gemm(g, s))) return rc;
+    }
+    if (taps && taps->scores)
+        if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;
+
+    // ---- optimal transport (mdgat.py:434-436) and match extraction (441-483) ----
+    float* Zout = Z ? Z : ws.Z;
+    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, s))) return rc;
+    return launch_extract(B, N, M, Zout, h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, s);
+}
+
+// ---------------------------------------------------------------------------------- per-op entry points
+extern "C" size_t mdgat_sinkhorn_workspace_bytes(int, int, int) { return 0; }
+
+extern "C" int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, int iters, float* Z, void*, size_t,
+                              void* stream) {
+    if (!scores || !Z) { mdgat_set_error("mdgat_sinkhorn: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    return launch_sinkhorn(B, N, M, scores, nullptr, bin_score, iters, Z, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_threshold, int64_t* matches0,
+                             int64_t* matches1, float* mscores0, float* mscores1, void* stream) {
+    if (!Z || !matches0 || !matches1 || !mscores0 || !mscores1) { mdgat_set_error("mdgat_extract: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    return launch_extract(B, N, M, Z, mode, match_threshold, matches0, matches1, mscores0, mscores1, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, void* stream) {
+    if (!qkv || !msg) { mdgat_set_error("mdgat_attention: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (topk < 0) { mdgat_set_error("mdgat_attention: topk < 0"); return MDGAT_ERR_BAD_ARG; }
+    return launch_attention(B, N, M, cross, topk, qkv, msg, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
+                               int relu, const float* R, int ldr, float* C, int ldc, void* stream) {
+    if (!A || !W || !C) { mdgat_set_error("mdgat_pointwise: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    GemmArgs g = pointwise(A, lda, K, W, bias, relu, C, ldc, M, N);
+    g.ldw = ldw; g.R = R; g.ldr = ldr;
+    return launch_gemm(g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
+                         void* stream) {
+    if (!x || !src || !idx) { mdgat_set_error("mdgat_knn: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    return launch_knn(B, C, N, M, k, x, src, idx, adj, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,70 @@
+// Shared declarations for libmdgat_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/mdgat_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define MDGAT_LOG2E 1.4426950408889634f
+#define MDGAT_LN2 0.6931471805599453f
+
+// row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
+// (cdna_hip_programming.md section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).
+__device__ __forceinline__ constexpr int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
+
+void mdgat_set_error(const char* fmt, ...);
+int mdgat_check_hip(hipError_t e, const char* what);
+
+// ---- packed-weight blob layout (must match mdgat_matcher_amd/pack.py) --------------------------
+struct BlobLayout {
+    // encoders (BN folded)
+    size_t kenc0_w, kenc0_b;   // [32][4], [32]
+    size_t denc0_w, denc0_b;   // [64][33], [64]
+    size_t kenc1_w, kenc1_b;   // [64][32], [64]
+    size_t kenc2_w, kenc2_b;   // [128][64], [128]
+    size_t denc1_w, denc1_b;   // [128][64], [128]
+    size_t encl_w, encl_b;     // [128][256] = [denc.6 | kenc.9], [128]
+    size_t layer0;             // start of layer 0
+    size_t layer_stride;
+    // per layer (relative to layer start)
+    size_t qkv_w, qkv_b;       // [384][128] rows = which*128 + head*32 + dim, [384]
+    size_t mlp1_w, mlp1_b;     // [256][256] cols = [x | head-major message (merge folded)], [256]
+    size_t mlp2_w, mlp2_b;     // [128][256], [128]
+    size_t final_w, final_b;   // [128][128], [128]
+    size_t bin_score;          // [1] (+3 pad)
+    size_t total;
+};
+BlobLayout mdgat_blob_layout(int L);
+
+// ---- kernel launchers (all asynchronous on `stream`) --------------------------------------------
+struct GemmArgs {
+    const float* A0; int lda0; int K0;   // columns [0, K0) of the input come from A0
+    const float* A1; int lda1;           // columns [K0, K) from A1 (unused when K0 == K)
+    const float* W; int ldw;             // [N][K]
+    const float* bias;                   // [N] or nullptr
+    const float* R; int ldr;             // residual [M][N] or nullptr
+    float* C; int ldc;
+    int M, N, K;
+    int relu;
+    float scale;                         // applied to the accumulator before bias
+    int batch;                           // grid.z
+    long long sA, sW, sC;                // batch strides (elements) of A0, W, C
+};
+int launch_gemm(const GemmArgs& a, hipStream_t s);
+
+int launch_encode_l0(int B, int N, int P, int off, const float* kpts, const float* sigma, const float* fpfh,
+                     const float* w, const BlobLayout& bl, float* hk0, float* hd0, hipStream_t s);
+
+int launch_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, hipStream_t s);
+
+int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
+                    int iters, float* Z, hipStream_t s);
+
+int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,
+                   float* s0, float* s1, hipStream_t s);
+
+int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
+               hipStream_t s);

@@ -1,0 +1,325 @@
+"""Drop-in ``MDGAT`` module and ``match()`` API over the gfx950 HIP library.
+
+Host-side mirror of ``/root/reference/models/mdgat.py:315-603`` (class ``MDGAT``) for the
+``descriptor == 'FPFH'`` inference path:
+
+* same constructor config dict (``test.py:137-151``), same parameter and buffer names and shapes, so
+  ``load_state_dict(checkpoint['net'])`` works (also through ``torch.nn.DataParallel``, whose keys carry a
+  ``module.`` prefix - ``test.py:158-159``);
+* same ``forward(data: dict) -> dict`` contract: keys ``keypoints0/1, descriptors0/1, scores0/1`` in,
+  ``matches0/1`` (int64, -1 = unmatched), ``matching_scores0/1`` (module dtype) and ``loss`` out, the
+  empty-keypoint early-out of ``mdgat.py:374-382`` included;
+* tolerant of ``net.double().eval()`` (``test.py:193``): the kernels compute in fp32, results are cast
+  back to the module's dtype.
+
+All arithmetic happens in ``libmdgat_hip.so``; PyTorch only owns device memory and streams.  There is no
+CPU path: tensors that are not on a gfx950 device raise.  Training (loss / backward) is out of scope:
+``loss`` is returned as a zero scalar and ``train()`` mode raises in ``forward``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import threading
+import weakref
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from . import _lib, pack
+
+_D = 128
+
+
+def _mlp_modules(channels):
+    """Parameter container with the reference's Sequential indices (conv 3i, BN 3i+1, ReLU 3i+2)."""
+    mods = []
+    last = len(channels) - 1
+    for i in range(1, len(channels)):
+        mods.append(nn.Conv1d(channels[i - 1], channels[i], kernel_size=1, bias=True))
+        if i < last:
+            mods.append(nn.BatchNorm1d(channels[i]))
+            mods.append(nn.ReLU())
+    return nn.Sequential(*mods)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, cin, hidden, cout):
+        super().__init__()
+        self.encoder = _mlp_modules([cin, *hidden, cout])
+        nn.init.constant_(self.encoder[-1].bias, 0.0)
+
+
+class _Attn(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.merge = nn.Conv1d(d, d, kernel_size=1)
+        self.proj = nn.ModuleList([nn.Conv1d(d, d, kernel_size=1) for _ in range(3)])
+
+
+class _Propagation(nn.Module):
+    def __init__(self, d):
+        super().__init__()
+        self.attn = _Attn(d)
+        self.mlp = _mlp_modules([2 * d, 2 * d, d])
+        nn.init.constant_(self.mlp[-1].bias, 0.0)
+
+
+class _GNN(nn.Module):
+    def __init__(self, d, n_layers):
+        super().__init__()
+        self.layers = nn.ModuleList([_Propagation(d) for _ in range(n_layers)])
+
+
+class _DeviceState:
+    """Per-device library handle + packed weights + scratch (one per (module, device))."""
+
+    def __init__(self, handle, device):
+        self.handle = handle
+        self.device = device
+        self.workspace = None
+        self.lock = threading.Lock()
+
+    def close(self):
+        if self.handle:
+            _lib.load().mdgat_destroy(self.handle)
+            self.handle = None
+
+
+def _close_states(states):
+    for st in list(states.values()):
+        st.close()
+    states.clear()
+
+
+class MDGAT(nn.Module):
+    default_config = {
+        'descriptor_dim': 128,
+        'keypoint_encoder': [32, 64, 128],
+        'descritor_encoder': [64, 128],
+        'GNN_layers': ['self', 'cross'] * 9,
+        'sinkhorn_iterations': 100,
+        'match_threshold': 0.2,
+    }
+
+    def __init__(self, config):
+        super().__init__()
+        self.config = {**self.default_config, **config}
+        # the reference reads these with config[...] and raises KeyError when absent (mdgat.py:329, 353, 362-367)
+        self.descriptor = config['descriptor']
+        self.lr = config['lr']
+        self.loss_method = config['loss_method']
+        self.k = config['k']
+        self.mutual_check = config['mutual_check']
+        self.triplet_loss_gamma = config['triplet_loss_gamma']
+        self.train_step = config['train_step']
+        L = self.config['L']
+        if self.descriptor != 'FPFH':
+            raise NotImplementedError(
+                f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
+                "(pointnet / FPFH_gloabal / FPFH_only variants are out of scope, see DESIGN.md)")
+        d = self.config['descriptor_dim']
+        if d != _D or list(self.config['keypoint_encoder']) != [32, 64, 128] or \
+                list(self.config['descritor_encoder']) != [64, 128]:
+            raise NotImplementedError('the HIP kernels implement the default widths: descriptor_dim=128, '
+                                      'keypoint_encoder=[32,64,128], descritor_encoder=[64,128]')
+        self.kenc = _Encoder(4, self.config['keypoint_encoder'], d)
+        self.denc = _Encoder(33, self.config['descritor_encoder'], d)
+        self.gnn = _GNN(d, 2 * L)
+        self.final_proj = nn.Conv1d(d, d, kernel_size=1, bias=True)
+        self.register_parameter('bin_score', nn.Parameter(torch.tensor(1.)))
+        # shared (by reference) with DataParallel replicas: device index -> _DeviceState
+        self._states: Dict[int, _DeviceState] = {}
+        self._states_lock = threading.Lock()
+        self._sig_holder = [None]
+        # replicas never run __init__, so only the original module owns (and finally frees) the handles
+        weakref.finalize(self, _close_states, self._states)
+
+    # ------------------------------------------------------------------ cache invalidation
+    def _invalidate(self):
+        with self._states_lock:
+            for st in self._states.values():
+                st.close()
+            self._states.clear()
+
+    def _signature(self):
+        ts = list(self.parameters()) + list(self.buffers())
+        return tuple((t.data_ptr(), t._version, t.dtype, t.device) for t in ts)
+
+    def _invalidate_if_changed(self):
+        # test.py:193 calls net.double().eval() before EVERY forward: a cast that changes nothing must not
+        # throw the packed weights away
+        sig = self._signature()
+        if sig != self._sig_holder[0]:
+            self._sig_holder[0] = sig
+            self._invalidate()
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)
+        if hasattr(self, '_sig_holder'):
+            self._invalidate_if_changed()
+        return out
+
+    def load_state_dict(self, state_dict, *a, **k):
+        out = super().load_state_dict(state_dict, *a, **k)
+        self._invalidate_if_changed()
+        return out
+
+    def repack(self):
+        """Call after modifying parameters in place (nothing else tracks in-place edits)."""
+        self._invalidate()
+
+    # ------------------------------------------------------------------ library state
+    def _extract_mode(self):
+        if self.loss_method == 'superglue':
+            return _lib.EXTRACT_THRESHOLD_MUTUAL if self.mutual_check else _lib.EXTRACT_THRESHOLD
+        return _lib.EXTRACT_DUSTBIN_MUTUAL if self.mutual_check else _lib.EXTRACT_DUSTBIN
+
+    def _topk_schedule(self):
+        return pack.resolve_topk_schedule(self.config['L'], list(self.k))
+
+    def packed_weights(self):
+        """fp32 blob (numpy) of the current parameters in the library's layout."""
+        return pack.pack_state_dict(self.state_dict(), self.config['L'])
+
+    def _state_for(self, device: torch.device, blob_device_tensor: Optional[torch.Tensor] = None) -> _DeviceState:
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._states_lock:
+            st = self._states.get(idx)
+            if st is not None:
+                return st
+            lib = _lib.load()
+            L = self.config['L']
+            cfg = _lib.MdgatConfig()
+            cfg.L = L
+            cfg.sinkhorn_iters = int(self.config['sinkhorn_iterations'])
+            sched = self._topk_schedule()
+            for i, kk in enumerate(sched):
+                cfg.topk[i] = kk
+            cfg.extract_mode = self._extract_mode()
+            cfg.match_threshold = float(self.config['match_threshold'])
+            handle = C.c_void_p()
+            _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
+            st = _DeviceState(handle, idx)
+            try:
+                if blob_device_tensor is not None:
+                    n = blob_device_tensor.numel()
+                    _lib.check(lib.mdgat_load_weights(handle, C.c_void_p(blob_device_tensor.data_ptr()), n, 1),
+                               'mdgat_load_weights')
+                else:
+                    blob = self.packed_weights()
+                    assert blob.size == lib.mdgat_blob_floats(L), (blob.size, lib.mdgat_blob_floats(L))
+                    _lib.check(lib.mdgat_load_weights(handle, blob.ctypes.data_as(C.c_void_p), blob.size, 0),
+                               'mdgat_load_weights')
+            except Exception:
+                st.close()
+                raise
+            self._states[idx] = st
+            return st
+
+    def load_packed(self, blob: torch.Tensor):
+        """Install an already packed fp32 blob that lives on a GPU (e.g. received by an RCCL broadcast,
+        see shard.broadcast_weights) instead of packing this module's own parameters."""
+        assert blob.is_cuda and blob.dtype == torch.float32 and blob.is_contiguous()
+        idx = blob.device.index
+        with self._states_lock:
+            old = self._states.pop(idx, None)
+        if old is not None:
+            old.close()
+        return self._state_for(blob.device, blob)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, data):
+        kpts0, kpts1 = data['keypoints0'], data['keypoints1']
+        out_dtype = self.bin_score.dtype
+        if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:      # mdgat.py:374-382
+            shape0, shape1 = kpts0.shape[:-1], kpts1.shape[:-1]
+            return {
+                'matches0': kpts0.new_full(shape0, -1, dtype=torch.int)[0],
+                'matches1': kpts1.new_full(shape1, -1, dtype=torch.int)[0],
+                'matching_scores0': kpts0.new_zeros(shape0, dtype=torch.float64)[0],
+                'matching_scores1': kpts1.new_zeros(shape1, dtype=torch.float64)[0],
+                'skip_train': True,
+            }
+        if self.training:
+            raise NotImplementedError('mdgat_matcher_amd implements inference only: call .eval() (training, the '
+                                      'losses of mdgat.py:486-594 and backward are out of scope)')
+        res = self._run(kpts0, data['scores0'], data['descriptors0'], kpts1, data['scores1'], data['descriptors1'])
+        m0, m1, s0, s1 = res[:4]
+        return {
+            'matches0': m0,
+            'matches1': m1,
+            'matching_scores0': s0.to(out_dtype),
+            'matching_scores1': s1.to(out_dtype),
+            'loss': s0.new_zeros((), dtype=out_dtype),     # losses are training-only: not computed
+        }
+
+    @staticmethod
+    def _f32(t, device):
+        return t.to(device=device, dtype=torch.float32).contiguous()
+
+    def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None):
+        if not kpts0.is_cuda:
+            raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
+                               'device; there is no CPU fallback')
+        dev = kpts0.device
+        B, N = kpts0.shape[0], kpts0.shape[1]
+        M = kpts1.shape[1]
+        if fpfh0.shape[-1] != 33 or fpfh1.shape[-1] != 33 or kpts0.shape[-1] != 3 or kpts1.shape[-1] != 3:
+            raise ValueError('expected keypoints [B, N, 3] and 33-D FPFH descriptors [B, N, 33]')
+        k0, g0, f0 = self._f32(kpts0, dev), self._f32(sigma0, dev), self._f32(fpfh0, dev)
+        k1, g1, f1 = self._f32(kpts1, dev), self._f32(sigma1, dev), self._f32(fpfh1, dev)
+        st = self._state_for(dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev), st.lock:
+            need = lib.mdgat_workspace_bytes(st.handle, B, N, M)
+            if st.workspace is None or st.workspace.numel() < need:
+                st.workspace = None
+                st.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            m0 = torch.empty((B, N), dtype=torch.int64, device=dev)
+            m1 = torch.empty((B, M), dtype=torch.int64, device=dev)
+            s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
+            s1 = torch.empty((B, M), dtype=torch.float32, device=dev)
+            Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=dev) if want_Z else None
+            tap_struct = None
+            if taps is not None:
+                tap_struct = _lib.MdgatTaps()
+                for name in ('x_enc', 'x_layers', 'mdesc', 'scores'):
+                    t = taps.get(name)
+                    setattr(tap_struct, name, t.data_ptr() if t is not None else None)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            rc = lib.mdgat_forward(
+                st.handle, B, N, M,
+                k0.data_ptr(), g0.data_ptr(), f0.data_ptr(), k1.data_ptr(), g1.data_ptr(), f1.data_ptr(),
+                m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(),
+                Z.data_ptr() if Z is not None else None,
+                C.byref(tap_struct) if tap_struct is not None else None,
+                st.workspace.data_ptr(), st.workspace.numel(), stream)
+            _lib.check(rc, 'mdgat_forward')
+        return m0, m1, s0, s1, Z
+
+    # ------------------------------------------------------------------ match() API
+    @torch.no_grad()
+    def match(self, kpts0, desc0, kpts1, desc1, scores0=None, scores1=None, return_scores=False):
+        """``match(kpts0, desc0, kpts1, desc1)`` convenience API named by the north star.
+
+        kpts [B, N, 3] (or [N, 3]), desc = 33-D FPFH rows (L2-normalised as load_data.py:290-292 does),
+        scores = per-keypoint saliency, which the keypoint encoder consumes (mdgat.py:184-188) and is
+        therefore required.  Returns ``(matches0, matches1, mscores0, mscores1[, Z])``; ``Z`` is the
+        (N+1) x (M+1) log assignment matrix of log_optimal_transport."""
+        if scores0 is None or scores1 is None:
+            raise ValueError('match() needs the keypoint saliency scores0/scores1 (KeypointEncoder input)')
+        single = kpts0.dim() == 2
+        if single:
+            kpts0, desc0, kpts1, desc1 = kpts0[None], desc0[None], kpts1[None], desc1[None]
+            scores0, scores1 = scores0[None], scores1[None]
+        m0, m1, s0, s1, Z = self._run(kpts0, scores0, desc0, kpts1, scores1, desc1, want_Z=return_scores)
+        outs = [m0, m1, s0, s1] + ([Z] if return_scores else [])
+        if single:
+            outs = [o[0] for o in outs]
+        return tuple(outs)
+
+
+def match(model: MDGAT, kpts0, desc0, kpts1, desc1, scores0=None, scores1=None, return_scores=False):
+    """Functional form of :meth:`MDGAT.match`."""
+    return model.match(kpts0, desc0, kpts1, desc1, scores0, scores1, return_scores=return_scores)

@@ -1,0 +1,95 @@
+"""Per-op Python bindings over the C ABI (torch tensors in, torch tensors out; all on a gfx950 device).
+
+These call the same kernels ``mdgat_forward`` launches; they exist for unit parity tests and for
+callers that want a single stage (e.g. Sinkhorn on their own score matrix)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if not t.is_cuda:
+            raise RuntimeError('mdgat_matcher_amd ops run on MI355X only (no CPU fallback)')
+
+
+def sinkhorn(scores: torch.Tensor, bin_score: float, iters: int) -> torch.Tensor:
+    """log_optimal_transport (mdgat.py:288-308): scores [B, N, M] -> Z [B, N+1, M+1] (fp32)."""
+    _need_cuda(scores)
+    s = scores.to(torch.float32).contiguous()
+    B, N, M = s.shape
+    Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=s.device)
+    with torch.cuda.device(s.device):
+        _lib.check(_lib.load().mdgat_sinkhorn(B, N, M, s.data_ptr(), float(bin_score), int(iters), Z.data_ptr(),
+                                              None, 0, _stream(s)), 'mdgat_sinkhorn')
+    return Z
+
+
+def extract(Z: torch.Tensor, mode: int = _lib.EXTRACT_DUSTBIN, match_threshold: float = 0.2):
+    """Match extraction (mdgat.py:441-483) from Z [B, N+1, M+1]."""
+    _need_cuda(Z)
+    z = Z.to(torch.float32).contiguous()
+    B, N, M = z.shape[0], z.shape[1] - 1, z.shape[2] - 1
+    m0 = torch.empty((B, N), dtype=torch.int64, device=z.device)
+    m1 = torch.empty((B, M), dtype=torch.int64, device=z.device)
+    s0 = torch.empty((B, N), dtype=torch.float32, device=z.device)
+    s1 = torch.empty((B, M), dtype=torch.float32, device=z.device)
+    with torch.cuda.device(z.device):
+        _lib.check(_lib.load().mdgat_extract(B, N, M, z.data_ptr(), int(mode), float(match_threshold), m0.data_ptr(),
+                                             m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), _stream(z)), 'mdgat_extract')
+    return m0, m1, s0, s1
+
+
+def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0) -> torch.Tensor:
+    """attention / dynamic_attention (mdgat.py:190-210).  qkv [B, N+M, 3, 4, 32] -> message [B, N+M, 128]."""
+    _need_cuda(qkv)
+    x = qkv.to(torch.float32).contiguous()
+    B, P = x.shape[0], x.shape[1]
+    assert P == N + M and tuple(x.shape[2:]) == (3, 4, 32)
+    msg = torch.empty((B, P, 128), dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mdgat_attention(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
+                                               _stream(x)), 'mdgat_attention')
+    return msg
+
+
+def pointwise(A: torch.Tensor, W: torch.Tensor, bias=None, relu=False, residual=None) -> torch.Tensor:
+    """Conv1d(k=1) over points: A [rows, K] x W [Cout, K]^T (+bias, ReLU, +residual) -> [rows, Cout]."""
+    _need_cuda(A, W)
+    a = A.to(torch.float32).contiguous()
+    w = W.to(torch.float32).contiguous()
+    rows, K = a.shape
+    cout = w.shape[0]
+    assert w.shape[1] == K
+    b = bias.to(torch.float32).contiguous() if bias is not None else None
+    r = residual.to(torch.float32).contiguous() if residual is not None else None
+    out = torch.empty((rows, cout), dtype=torch.float32, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().mdgat_pointwise(rows, cout, K, a.data_ptr(), K, w.data_ptr(), K,
+                                               b.data_ptr() if b is not None else None, int(relu),
+                                               r.data_ptr() if r is not None else None, cout, out.data_ptr(), cout,
+                                               _stream(a)), 'mdgat_pointwise')
+    return out
+
+
+def knn(x: torch.Tensor, src: torch.Tensor, k: int, adjacency: bool = False):
+    """knn / get_graph_feature (mdgat.py:8-32).  Channel-major inputs like the reference: x [B, C, N], src [B, C, M]."""
+    _need_cuda(x, src)
+    xp = x.to(torch.float32).transpose(1, 2).contiguous()
+    sp = src.to(torch.float32).transpose(1, 2).contiguous()
+    B, N, Cc = xp.shape
+    M = sp.shape[1]
+    idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
+    adj = torch.empty((B, N, M), dtype=torch.int64, device=x.device) if adjacency else None
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.load().mdgat_knn(B, Cc, N, M, int(k), xp.data_ptr(), sp.data_ptr(), idx.data_ptr(),
+                                         adj.data_ptr() if adj is not None else None, _stream(x)), 'mdgat_knn')
+    return (idx, adj) if adjacency else idx

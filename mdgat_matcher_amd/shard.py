@@ -1,0 +1,90 @@
+"""Multi-GPU sharding of frame-pair batches: one process per GPU, no data-path collective.
+
+The reference's only multi-GPU mechanism is single-process ``torch.nn.DataParallel``
+(``test.py:158``, ``train.py:192-196``): it re-broadcasts all parameters and scatters/gathers the batch
+on EVERY forward.  Frame pairs are independent (no exchange step inside a pair), so here every rank owns
+a contiguous slice of the pair list and the only collective is a one-time RCCL broadcast (over xGMI) of
+the packed fp32 weight blob (~11 MB) from rank 0 - a single latency-bound message, after which the
+steady state has no cross-GPU dependency at all.  ``gather_matches`` is optional result consolidation
+(~12 KB per pair)."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(n_gpus_requested: int = 1, backend: str | None = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29531')
+        if backend is None:
+            backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' IS RCCL on ROCm
+        if backend == 'nccl':
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def partition(n_pairs: int, rank: int, world: int):
+    """Contiguous shard [first, first + count) of the pair list for ``rank`` (sizes differ by at most 1)."""
+    base, rem = divmod(n_pairs, world)
+    count = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    return first, count
+
+
+def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.broadcast(blob, src=src)
+    return blob
+
+
+def broadcast_weights(net, device, rank: int, world: int):
+    """Rank 0 packs its parameters (BN fold etc., pack.py); the packed blob travels once by RCCL broadcast
+    and every rank installs it into its library handle.  At world 1 the module just packs lazily."""
+    if world == 1:
+        return None
+    from . import pack
+    n = pack.blob_layout(net.config['L'])['total']
+    if rank == 0:
+        blob = torch.from_numpy(net.packed_weights()).to(device)
+    else:
+        blob = torch.empty(n, dtype=torch.float32, device=device)
+    broadcast_blob(blob, 0)
+    if blob.is_cuda:
+        net.load_packed(blob)
+    return blob
+
+
+def barrier(world: int):
+    if world > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device, world: int) -> float:
+    if world == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_matches(local: torch.Tensor, world: int):
+    """Optional: concatenate per-rank results on every rank (equal shard sizes)."""
+    if world == 1:
+        return local
+    outs = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(outs, local)
+    return torch.cat(outs, dim=0)
+
+
+def finalize(world: int):
+    if world > 1 and dist.is_initialized():
+        dist.destroy_process_group()

@@ -108,7 +108,7 @@ def make_state_dict(L=9, seed=0, bin_score=1.0, dtype=torch.float64, feature_dim
     sd['bin_score'] = np.asarray(bin_score, dtype=np.float64)
     out = {}
     for k, v in sd.items():
-        t = torch.from_numpy(np.ascontiguousarray(v))
+        t = torch.from_numpy(np.ascontiguousarray(v)).reshape(np.shape(v))
         out[k] = t if t.dtype == torch.int64 else t.to(dtype)
     return out
 

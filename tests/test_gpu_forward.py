@@ -1,0 +1,194 @@
+"""End-to-end GPU parity of the drop-in MDGAT module (HIP path through the C ABI) against the golden
+vectors captured from the real reference, plus size-independent properties at the bench shape."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
+from oracle import mdgat_oracle as O  # noqa: E402
+
+DEV = 'cuda:0'
+Z_TOL = 1e-4        # north star: soft-assignment matrix within 1e-4 (fp32 kernels vs fp64 reference)
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def _build(g, **cfg_over):
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    bin_score = float(g['bin_score']) if 'bin_score' in g else 1.0
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, **cfg_over)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=L, seed=seed, bin_score=bin_score))
+    net = net.double().eval().to(DEV)
+    data = synth.make_batch(B, n, m, first_pair=first_pair, device=DEV)
+    return net, data, (B, n, m, L)
+
+
+def _to_lib(x):
+    """reference [B, 128, N] -> [B, N, 128]"""
+    return np.transpose(x, (0, 2, 1))
+
+
+@pytest.mark.parametrize('name', ['fwd_n64_L1_S1', 'fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20'])
+def test_forward_stages_golden(golden_dir, name):
+    g = _g(golden_dir, name)
+    net, data, (B, n, m, L) = _build(g)
+    P = n + m
+    taps = {
+        'x_enc': torch.empty(B, P, 128, device=DEV),
+        'x_layers': torch.empty(2 * L, B, P, 128, device=DEV),
+        'mdesc': torch.empty(B, P, 128, device=DEV),
+        'scores': torch.empty(B, n, m, device=DEV),
+    }
+    m0, m1, s0, s1, Z = net._run(data['keypoints0'], data['scores0'], data['descriptors0'],
+                                 data['keypoints1'], data['scores1'], data['descriptors1'], want_Z=True, taps=taps)
+    torch.cuda.synchronize()
+    enc = taps['x_enc'].cpu().double().numpy()
+    assert np.abs(enc[:, :n] - _to_lib(g['enc0'])).max() < 1e-5
+    assert np.abs(enc[:, n:] - _to_lib(g['enc1'])).max() < 1e-5
+    xl = taps['x_layers'].cpu().double().numpy()
+    for i in range(2 * L):
+        e0 = np.abs(xl[i][:, :n] - _to_lib(g[f'layer{i}_desc0'])).max()
+        e1 = np.abs(xl[i][:, n:] - _to_lib(g[f'layer{i}_desc1'])).max()
+        assert max(e0, e1) < 5e-5, (i, e0, e1)
+    md = taps['mdesc'].cpu().double().numpy()
+    assert np.abs(md[:, :n] - _to_lib(g['mdesc0'])).max() < 5e-5
+    assert np.abs(taps['scores'].cpu().double().numpy() - g['scores']).max() < Z_TOL
+    assert np.abs(Z.cpu().double().numpy() - g['Z']).max() < Z_TOL
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+    assert np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max() < Z_TOL
+    assert np.abs(s1.cpu().double().numpy() - g['default_mscores1']).max() < Z_TOL
+
+
+@pytest.mark.parametrize('name', ['fwd_n64_L4_S20', 'fwd_n48m64_L4_S20'])
+def test_forward_dict_contract_and_variants(golden_dir, name):
+    g = _g(golden_dir, name)
+    for tag, (loss_method, mutual) in {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True),
+                                       'sg': ('superglue', False), 'sgmutual': ('superglue', True)}.items():
+        if f'{tag}_matches0' not in g:
+            continue
+        net, data, _ = _build(g, loss_method=loss_method, mutual_check=mutual)
+        with torch.no_grad():
+            out = net(data)
+        assert set(out) >= {'matches0', 'matches1', 'matching_scores0', 'matching_scores1', 'loss'}
+        assert out['matches0'].dtype == torch.int64 and out['matching_scores0'].dtype == torch.float64
+        np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g[f'{tag}_matches0'], err_msg=tag)
+        np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g[f'{tag}_matches1'], err_msg=tag)
+        assert np.abs(out['matching_scores0'].cpu().numpy() - g[f'{tag}_mscores0']).max() < Z_TOL, tag
+        assert np.abs(out['matching_scores1'].cpu().numpy() - g[f'{tag}_mscores1']).max() < Z_TOL, tag
+
+
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100'])
+def test_config_shapes_golden(golden_dir, name):
+    g = _g(golden_dir, name)
+    net, data, (B, n, m, L) = _build(g)
+    m0, m1, s0, s1, Z = net.match(data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'],
+                                  data['scores0'], data['scores1'], return_scores=True)
+    Zc = Z.cpu().double().numpy()
+    assert np.abs(Zc[:, ::8, ::8] - g['Z_sub']).max() < Z_TOL
+    assert np.abs(Zc[:, -1, :] - g['Z_lastrow']).max() < Z_TOL
+    assert np.abs(Zc[:, :, -1] - g['Z_lastcol']).max() < Z_TOL
+    assert np.abs(torch.logsumexp(Z.double(), 2).cpu().numpy() - g['Z_row_lse']).max() < Z_TOL
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+    assert np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max() < Z_TOL
+
+
+def test_dataparallel_dropin_like_test_py(golden_dir):
+    """The call sequence of test.py:156-201: DataParallel wrapper, 'module.'-prefixed checkpoint,
+    net.double().eval() before every forward, dict in -> dict out."""
+    g = _g(golden_dir, 'fwd_n64_L4_S20')
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    net = MDGAT(synth.default_config(L=L, k=k, sinkhorn_iterations=S))
+    net = torch.nn.DataParallel(net)
+    net.load_state_dict({'module.' + kk: v for kk, v in synth.make_state_dict(L=L, seed=seed).items()})
+    net.to(DEV)
+    with torch.no_grad():
+        for _ in range(2):
+            net.double().eval()
+            pred = synth.make_batch(B, n, m, first_pair=first_pair)
+            pred = {kk: v.cuda() for kk, v in pred.items()}
+            data = net(pred)
+            np.testing.assert_array_equal(data['matches0'][0].cpu().detach().numpy(), g['default_matches0'][0])
+            np.testing.assert_array_equal(data['matches1'][0].cpu().detach().numpy(), g['default_matches1'][0])
+
+
+def test_empty_keypoints_and_errors(golden_dir):
+    g = _g(golden_dir, 'edge_cases')
+    net = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=5))
+    net.load_state_dict(synth.make_state_dict(L=1, seed=3))
+    net = net.double().eval().to(DEV)
+    data = synth.make_batch(1, 8, 8, device=DEV)
+    data['keypoints0'] = data['keypoints0'][:, :0]
+    out = net(data)
+    assert out['skip_train'] is True
+    for a, b in (('matches0', 'empty_matches0'), ('matches1', 'empty_matches1'),
+                 ('matching_scores0', 'empty_mscores0'), ('matching_scores1', 'empty_mscores1')):
+        assert tuple(out[a].shape) == g[b].shape
+        np.testing.assert_array_equal(out[a].cpu().numpy(), g[b])
+    # k larger than the number of keypoints raises like torch.topk does in the reference
+    net2 = MDGAT(synth.default_config(L=1, k=[16, None], sinkhorn_iterations=5))
+    net2.load_state_dict(synth.make_state_dict(L=1, seed=3))
+    net2 = net2.eval().to(DEV)
+    with pytest.raises(RuntimeError, match='exceeds the number of keys'):
+        net2(synth.make_batch(1, 8, 8, device=DEV))
+    # k == M behaves as full attention
+    data = synth.make_batch(1, 32, 32, device=DEV)
+    net3 = MDGAT(synth.default_config(L=1, k=[32, 32], sinkhorn_iterations=10))
+    net3.load_state_dict(synth.make_state_dict(L=1, seed=3))
+    net3 = net3.eval().to(DEV)
+    Z = net3.match(data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'],
+                   data['scores0'], data['scores1'], return_scores=True)[4]
+    assert np.abs(Z.cpu().double().numpy() - g['keqM_Z_dyn']).max() < Z_TOL
+    # all-dustbin frame
+    net4 = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=10))
+    net4.load_state_dict(synth.make_state_dict(L=1, seed=3, bin_score=50.0))
+    net4 = net4.eval().to(DEV)
+    out = net4(data)
+    np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g['alldust_matches0'])
+    assert (out['matching_scores0'] == 0).all() and (out['matching_scores1'] == 0).all()
+
+
+def test_bench_shape_properties():
+    """Full BASELINE size (B=64, N=M=512, L=9, S=100): properties that need no CPU oracle."""
+    B, n, L = 64, 512, 9
+    net = MDGAT(synth.default_config(L=L))
+    net.load_state_dict(synth.make_state_dict(L=L, seed=0))
+    net = net.eval().to(DEV)
+    data = synth.make_batch(B, n, n, device=DEV, dtype=torch.float32)
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
+    # (1) determinism: a second run is bit-identical
+    m0b, m1b, s0b, s1b, Zb = net.match(*args, return_scores=True)
+    assert torch.equal(m0, m0b) and torch.equal(Z, Zb)
+    # (2) batch independence: pair 5 alone gives the same bits as inside the batch
+    sl = [a[5:6] for a in args]
+    m0s, m1s, s0s, s1s, Zs = net.match(*sl, return_scores=True)
+    assert torch.equal(m0s[0], m0[5]) and torch.equal(Zs[0], Z[5])
+    # (3) column marginals of the transport plan are exact after the final v-update
+    col = torch.logsumexp(Z.double(), dim=1)
+    assert col[:, :n].abs().max() < 1e-4 and (col[:, n] - np.log(n)).abs().max() < 1e-4
+    # (4) matches are consistent with Z: arg-max rows / dustbin rule, scores = exp(max)
+    r0, r1, rs0, rs1 = O.extract_matches(Z[:4].cpu().double())
+    assert torch.equal(r0, m0[:4].cpu()) and torch.equal(r1, m1[:4].cpu())
+    assert (rs0 - s0[:4].cpu().double()).abs().max() < 1e-5
+    # (5) permutation equivariance: permuting frame-1 keypoints permutes the assignment
+    perm = torch.randperm(n, device=DEV, generator=torch.Generator(DEV).manual_seed(3))
+    argsp = (args[0][:2], args[1][:2], args[2][:2, perm], args[3][:2, perm], args[4][:2], args[5][:2, perm])
+    m0p, m1p, s0p, s1p, Zp = net.match(*argsp, return_scores=True)
+    assert (Zp[:, :, :n] - Z[:2][:, :, perm]).abs().max() < 1e-3
+    # (6) a pinned oracle run of two pairs of the same batch agrees within the north-star tolerance
+    cap = {}
+    sd = synth.make_state_dict(L=L, seed=0)
+    cpu = {k: v[:2].cpu().double() for k, v in data.items()}
+    O.mdgat_forward(sd, synth.default_config(L=L), cpu, cap)
+    assert (cap['Z'] - Z[:2].cpu().double()).abs().max() < 1e-4

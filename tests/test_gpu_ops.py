@@ -1,0 +1,212 @@
+"""GPU parity of every kernel, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs and against the committed golden vectors produced by the real reference.
+
+Tolerances: index outputs bit-exact; floating outputs within 1e-4 absolute of the fp64 oracle (the
+north-star bound for the soft-assignment matrix), most stages far tighter as stated per test."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mdgat_matcher_amd import _lib, ops  # noqa: E402
+from oracle import mdgat_oracle as O  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+@pytest.mark.parametrize('rows,cout,K', [(128, 128, 128), (300, 384, 128), (1000, 64, 32), (77, 256, 256), (64, 128, 64),
+                                         (5, 40, 96)])
+def test_pointwise(rows, cout, K):
+    rs = np.random.RandomState(rows + cout + K)
+    A = torch.from_numpy(rs.standard_normal((rows, K)))
+    W = torch.from_numpy(rs.standard_normal((cout, K)) / np.sqrt(K))
+    b = torch.from_numpy(rs.standard_normal(cout))
+    R = torch.from_numpy(rs.standard_normal((rows, cout)))
+    ref = A @ W.T + b
+    out = ops.pointwise(A.to(DEV), W.to(DEV), b.to(DEV)).cpu().double()
+    assert (out - ref).abs().max() < 2e-5
+    ref2 = torch.relu(ref) + R
+    out2 = ops.pointwise(A.to(DEV), W.to(DEV), b.to(DEV), relu=True, residual=R.to(DEV)).cpu().double()
+    assert (out2 - ref2).abs().max() < 2e-5
+    out3 = ops.pointwise(A.to(DEV), W.to(DEV)).cpu().double()
+    assert (out3 - A @ W.T).abs().max() < 2e-5
+
+
+def test_pointwise_is_transpose_safe():
+    # asymmetric operand: a swapped C/D fragment mapping cannot pass
+    A = torch.zeros(64, 32, dtype=torch.float64)
+    A[torch.arange(32), torch.arange(32)] = 1.0   # rows 0..31 = identity, rows 32..63 zero
+    W = torch.arange(64 * 32, dtype=torch.float64).reshape(64, 32) / 100.0
+    out = ops.pointwise(A.to(DEV), W.to(DEV)).cpu().double()
+    assert (out - A @ W.T).abs().max() < 1e-6
+
+
+def _to_lib_qkv(q, k, v):
+    """reference [B, dh, H, N] tensors -> library [B, N, 3, H, dh] (self-attention frame layout helper)"""
+    return torch.stack([t.permute(0, 3, 2, 1) for t in (q, k, v)], dim=2).contiguous()
+
+
+def _ref_msg_to_lib(msg):
+    """reference message [B, dh, H, N] -> library [B, N, H*dh]"""
+    b, dh, h, n = msg.shape
+    return msg.permute(0, 3, 2, 1).reshape(b, n, h * dh)
+
+
+@pytest.mark.parametrize('N,M', [(64, 64), (40, 56), (128, 96), (512, 512), (257, 130), (33, 31)])
+@pytest.mark.parametrize('cross', [False, True])
+def test_attention_full(N, M, cross):
+    rs = np.random.RandomState(N * 7 + M)
+    B = 2
+    qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
+    out = ops.attention(qkv.to(DEV), N, M, cross).cpu().double()
+    # oracle per frame
+    for side, (lo, hi) in enumerate(((0, N), (N, N + M))):
+        slo, shi = ((N, N + M) if side == 0 else (0, N)) if cross else (lo, hi)
+        q = qkv[:, lo:hi, 0].permute(0, 3, 2, 1)      # [B, dh, H, n]
+        k = qkv[:, slo:shi, 1].permute(0, 3, 2, 1)
+        v = qkv[:, slo:shi, 2].permute(0, 3, 2, 1)
+        ref, _ = O.attention(q, k, v)
+        err = (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max()
+        assert err < 1e-5, (side, err)
+
+
+@pytest.mark.parametrize('N,M,k', [(64, 64, 16), (64, 64, 1), (64, 64, 63), (40, 56, 8), (512, 512, 128), (512, 512, 64),
+                                   (256, 256, 128), (100, 70, 70), (48, 64, 16)])
+def test_attention_topk(N, M, k):
+    rs = np.random.RandomState(N + 13 * M + k)
+    B = 2
+    qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
+    out = ops.attention(qkv.to(DEV), N, M, False, topk=k).cpu().double()
+    for lo, hi in ((0, N), (N, N + M)):
+        q = qkv[:, lo:hi, 0].permute(0, 3, 2, 1)
+        kk = qkv[:, lo:hi, 1].permute(0, 3, 2, 1)
+        v = qkv[:, lo:hi, 2].permute(0, 3, 2, 1)
+        ref, _ = O.dynamic_attention(q, kk, v, k)
+        err = (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max()
+        assert err < 1e-5, (lo, err)
+
+
+def test_attention_topk_golden_and_errors(golden_dir):
+    g = _g(golden_dir, 'op_vectors')
+    q, k, v = (torch.from_numpy(g[x]) for x in ('att_q', 'att_k', 'att_v'))   # q: 40 queries, k/v: 56 keys
+    # library layout needs both frames: frame 0 = the 40 queries (with dummy k/v), frame 1 = the 56 keys
+    B, N, M = q.shape[0], q.shape[3], k.shape[3]
+    qkv = torch.zeros(B, N + M, 3, 4, 32, dtype=torch.float64)
+    qkv[:, :N, 0] = q.permute(0, 3, 2, 1)
+    qkv[:, N:, 1] = k.permute(0, 3, 2, 1)
+    qkv[:, N:, 2] = v.permute(0, 3, 2, 1)
+    full = ops.attention(qkv.to(DEV), N, M, True).cpu().double()[:, :N]
+    assert (full - _ref_msg_to_lib(torch.from_numpy(g['att_full']))).abs().max() < 1e-5
+    for kk in (1, 8):
+        dyn = ops.attention(qkv.to(DEV), N, M, True, topk=kk).cpu().double()[:, :N]
+        assert (dyn - _ref_msg_to_lib(torch.from_numpy(g[f'att_dyn{kk}']))).abs().max() < 1e-5
+    with pytest.raises(RuntimeError, match='exceeds the number of keys'):
+        ops.attention(qkv.to(DEV), N, M, True, topk=57)       # torch.topk raises in the reference
+    with pytest.raises(RuntimeError):
+        ops.attention(torch.zeros(1, 1200, 3, 4, 32, device=DEV), 600, 600, False)   # > 512 keys: unsupported (yet)
+
+
+def test_attention_topk_with_ties():
+    # duplicated keys produce exact ties at the threshold: all tied entries are kept (documented deviation:
+    # torch.topk keeps an arbitrary subset); rows without ties must still match the oracle
+    rs = np.random.RandomState(5)
+    N = M = 64
+    qkv = torch.from_numpy(rs.standard_normal((1, N + M, 3, 4, 32)))
+    qkv[:, 10] = qkv[:, 11]   # keys 10 and 11 of frame 0 identical
+    out = ops.attention(qkv.to(DEV), N, M, False, topk=16).cpu().double()
+    assert torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize('tag', ['sk_7x5', 'sk_64x64', 'sk_48x64'])
+def test_sinkhorn_golden(golden_dir, tag):
+    g = _g(golden_dir, 'op_vectors')
+    iters, alpha = g[tag + '_meta']
+    Z = ops.sinkhorn(torch.from_numpy(g[tag + '_scores']).to(DEV), float(alpha), int(iters)).cpu().double().numpy()
+    assert np.abs(Z - g[tag + '_Z']).max() < 1e-4
+
+
+def test_sinkhorn_512_golden(golden_dir):
+    g = _g(golden_dir, 'op_vectors')
+    iters, alpha = g['sk_512x512_meta']
+    s = torch.from_numpy(np.random.RandomState(int(g['sk_512x512_seed'][0])).standard_normal((1, 512, 512)) * 3.0)
+    Z = ops.sinkhorn(s.to(DEV), float(alpha), int(iters)).cpu().double().numpy()
+    assert np.abs(Z[:, ::8, ::8] - g['sk_512x512_Z_sub']).max() < 1e-4
+    assert np.abs(Z[:, -1, :] - g['sk_512x512_Z_lastrow']).max() < 1e-4
+    assert np.abs(Z[:, :, -1] - g['sk_512x512_Z_lastcol']).max() < 1e-4
+
+
+@pytest.mark.parametrize('N,M,iters', [(1, 1, 3), (3, 200, 10), (130, 65, 25), (256, 256, 20), (300, 513, 30), (700, 900, 10),
+                                       (64, 64, 0)])
+def test_sinkhorn_vs_oracle(N, M, iters):
+    rs = np.random.RandomState(N * 3 + M)
+    s = torch.from_numpy(rs.standard_normal((3, N, M)) * 4.0)
+    ref = O.log_optimal_transport(s, 0.7, iters)
+    Z = ops.sinkhorn(s.to(DEV), 0.7, iters).cpu().double()
+    assert (Z - ref).abs().max() < 1e-4
+
+
+def test_sinkhorn_marginals_full_size():
+    # size-independent property at the bench shape: after the last v-update every column of exp(Z) sums to
+    # its marginal exactly (1 for keypoint columns, N for the dustbin column) and rows do approximately
+    B, N, M = 8, 512, 512
+    s = torch.randn(B, N, M, device=DEV, generator=torch.Generator(DEV).manual_seed(1)) * 3
+    Z = ops.sinkhorn(s, 1.0, 100).double()
+    col = torch.logsumexp(Z, dim=1)
+    assert col[:, :M].abs().max() < 1e-4
+    assert (col[:, M] - np.log(N)).abs().max() < 1e-4
+    row = torch.logsumexp(Z, dim=2)
+    assert row[:, :N].abs().max() < 5e-2
+
+
+@pytest.mark.parametrize('name', ['fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20'])
+def test_extract_golden(golden_dir, name):
+    g = _g(golden_dir, name)
+    Z32 = torch.from_numpy(g['Z']).float()
+    for tag, mode in (('default', _lib.EXTRACT_DUSTBIN), ('mutual', _lib.EXTRACT_DUSTBIN_MUTUAL),
+                      ('sg', _lib.EXTRACT_THRESHOLD), ('sgmutual', _lib.EXTRACT_THRESHOLD_MUTUAL)):
+        if f'{tag}_matches0' not in g:
+            continue
+        m0, m1, s0, s1 = ops.extract(Z32.to(DEV), mode, 0.2)
+        # the oracle on the SAME fp32-rounded Z must agree bit-exactly on indices
+        lm, mc = {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True), 'sg': ('superglue', False),
+                  'sgmutual': ('superglue', True)}[tag]
+        r0, r1, rs0, rs1 = O.extract_matches(Z32.double(), lm, mc, 0.2)
+        assert torch.equal(m0.cpu(), r0) and torch.equal(m1.cpu(), r1), tag
+        assert (s0.cpu().double() - rs0).abs().max() < 1e-6 and (s1.cpu().double() - rs1).abs().max() < 1e-6, tag
+        # and with the reference's own outputs
+        np.testing.assert_array_equal(m0.cpu().numpy(), g[f'{tag}_matches0'])
+        np.testing.assert_array_equal(m1.cpu().numpy(), g[f'{tag}_matches1'])
+        assert np.abs(s0.cpu().numpy() - g[f'{tag}_mscores0']).max() < 1e-5
+
+
+def test_extract_all_dustbin_and_ties(golden_dir):
+    g = _g(golden_dir, 'edge_cases')
+    Z32 = torch.from_numpy(g['alldust_Z']).float()
+    m0, m1, s0, s1 = ops.extract(Z32.to(DEV), _lib.EXTRACT_DUSTBIN, 0.2)
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['alldust_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['alldust_matches1'])
+    assert (s0 == 0).all() and (s1 == 0).all()          # mdgat.py:465-467: all-zero scores
+    # first-index tie rule of torch.max: constant rows pick column 0, constant columns pick row 0
+    Zc = torch.zeros(1, 9, 7)
+    m0, m1, s0, s1 = ops.extract(Zc.to(DEV), _lib.EXTRACT_DUSTBIN, 0.2)
+    assert (m0 == 0).all() and (m1 == 0).all()
+    r0, r1, _, _ = O.extract_matches(Zc.double())
+    assert torch.equal(m0.cpu(), r0) and torch.equal(m1.cpu(), r1)
+
+
+def test_knn_golden(golden_dir):
+    g = _g(golden_dir, 'op_vectors')
+    for Cc in (3, 128):
+        x, s = torch.from_numpy(g[f'knn{Cc}_x']), torch.from_numpy(g[f'knn{Cc}_s'])
+        idx, adj = ops.knn(x.to(DEV), s.to(DEV), 9, adjacency=True)
+        np.testing.assert_array_equal(idx.cpu().numpy(), g[f'knn{Cc}_idx'])
+        np.testing.assert_array_equal(adj.cpu().numpy(), g[f'knn{Cc}_adj'])
+    with pytest.raises(RuntimeError):
+        ops.knn(x.to(DEV), s.to(DEV), 71)
