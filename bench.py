@@ -91,10 +91,10 @@ def kernel_breakdown(dev, B, n, L, S, topk_sched, reps=5):
     return rows
 
 
-def cpu_baseline(n, L, S, budget_s=12.0, max_pairs=16):
+def cpu_baseline(n, L, S, budget_s=15.0, max_pairs=64):
     """The CPU oracle (oracle/: fp64 PyTorch restatement pinned to the reference) on this box's cores."""
     from oracle import mdgat_oracle as O
-    cores = os.cpu_count() or 1
+    cores = synth.effective_cpu_count()
     torch.set_num_threads(cores)
     sd = synth.make_state_dict(L=L, seed=0)
     cfg = synth.default_config(L=L, sinkhorn_iterations=S)

@@ -21,6 +21,25 @@ import torch
 DEFAULT_K = [128, None, 128, None, 64, None, 64, None]
 
 
+def effective_cpu_count() -> int:
+    """Cores this process may really use: min(os.cpu_count(), affinity mask, cgroup v2 CPU quota).
+    (The GPU boxes report 256 CPUs but run under a 16-core quota; 256 OpenMP threads there are
+    ~2000x slower than 16.)"""
+    import os
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()
+        if quota != 'max':
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def default_config(L=9, k=None, sinkhorn_iterations=100, **over):
     """Config dict with the keys ``test.py:137-151`` passes to ``MDGAT(config)``."""
     cfg = {

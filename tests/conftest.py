@@ -12,6 +12,9 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    import torch
+    from mdgat_matcher_amd.synth import effective_cpu_count
+    torch.set_num_threads(effective_cpu_count())      # the CPU oracle: never oversubscribe a cgroup quota
 
 
 @pytest.fixture(scope='session')

@@ -69,7 +69,6 @@ def test_config_shapes(golden_dir, name):
     sd, data, k, L, S, n, m = _setup(g)
     cap = {}
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
-    torch.set_num_threads(os.cpu_count())
     out = O.mdgat_forward(sd, cfg, data, cap)
     Z = cap['Z']
     assert np.abs(Z.numpy()[:, ::8, ::8] - g['Z_sub']).max() < 1e-8
