@@ -80,10 +80,10 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights = nullptr;
     h->loaded = false;
     int prev = 0;
-    hipGetDevice(&prev);
+    (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
-    hipSetDevice(prev);
+    (void)hipSetDevice(prev);
     if (rc) { delete h; return rc; }
     *out = h;
     return MDGAT_OK;
@@ -109,14 +109,15 @@ extern "C" float* mdgat_weights_device_ptr(mdgat_handle* h) { return h ? h->weig
 
 extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (!h) return;
-    if (h->weights) hipFree(h->weights);
+    if (h->weights) (void)hipFree(h->weights);
     delete h;
 }
 
 // ---------------------------------------------------------------------------------- workspace
 namespace {
 struct Workspace {
-    float *x, *qkv, *hid, *msg, *scores, *Z;
+    float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
+    size_t sk_bytes;
     size_t total;   // floats
 };
 Workspace carve(float* base, int B, int N, int M) {
@@ -130,6 +131,8 @@ Workspace carve(float* base, int B, int N, int M) {
     w.msg = take(R * 128);
     w.scores = take((size_t)B * N * M);
     w.Z = take((size_t)B * (N + 1) * (M + 1));
+    w.sk_bytes = mdgat_sinkhorn_ws_bytes_impl(B, N, M);
+    w.sk = take((w.sk_bytes + 3) / 4);
     w.total = o;
     return w;
 }
@@ -242,17 +245,18 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
 
     // ---- optimal transport (mdgat.py:434-436) and match extraction (441-483) ----
     float* Zout = Z ? Z : ws.Z;
-    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, s))) return rc;
+    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, s))) return rc;
     return launch_extract(B, N, M, Zout, h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, s);
 }
 
 // ---------------------------------------------------------------------------------- per-op entry points
-extern "C" size_t mdgat_sinkhorn_workspace_bytes(int, int, int) { return 0; }
+extern "C" size_t mdgat_sinkhorn_workspace_bytes(int B, int N, int M) { return mdgat_sinkhorn_ws_bytes_impl(B, N, M); }
 
-extern "C" int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, int iters, float* Z, void*, size_t,
-                              void* stream) {
+extern "C" int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, int iters, float* Z, void* workspace,
+                              size_t workspace_bytes, void* stream) {
     if (!scores || !Z) { mdgat_set_error("mdgat_sinkhorn: null pointer"); return MDGAT_ERR_BAD_ARG; }
-    return launch_sinkhorn(B, N, M, scores, nullptr, bin_score, iters, Z, static_cast<hipStream_t>(stream));
+    // without (enough, 256-byte aligned) workspace the streaming kernel is used instead of the cluster kernel
+    return launch_sinkhorn(B, N, M, scores, nullptr, bin_score, iters, Z, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_threshold, int64_t* matches0,

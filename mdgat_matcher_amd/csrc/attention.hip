@@ -238,11 +238,11 @@ int launch_attention(int B, int N, int M, int cross, int topk, const float* qkv,
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     if (dyn) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<true>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<true>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(attention_kernel<true>, grid, dim3(256), lds, s, a);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<false>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(attention_kernel<false>, grid, dim3(256), lds, s, a);
     }

@@ -61,7 +61,8 @@ int launch_encode_l0(int B, int N, int P, int off, const float* kpts, const floa
 int launch_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, hipStream_t s);
 
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, hipStream_t s);
+                    int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s);
+size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,
                    float* s0, float* s1, hipStream_t s);

@@ -159,6 +159,279 @@ __global__ __launch_bounds__(NW * 64) void sinkhorn_kernel(SkArgs a) {
     for (int j = tid; j <= M; j += NW * 64) zl[j] = (alpha + uN + v[j]) * MDGAT_LN2 - norm;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Register-resident cluster kernel (N, M <= 512): the pair's score block never leaves the register file.
+//
+// G workgroups (1024 threads = 16 waves each, one per CU, co-resident: cooperative launch) share one pair:
+// workgroup j owns rows [128 j, 128 j + 128), wave w of it 8 of those rows, lane l the 8 contiguous columns
+// 8 l .. 8 l + 7 of each - a lane holds an 8 x 8 block of S (64 VGPRs) for all iterations.
+//   row update   : per row, 8 in-lane terms + a 6-step DPP wave reduction for max and for sum-of-exp2;
+//   column update: per column, in-lane over the wave's 8 rows -> (max, sum) pairs merged across the 16
+//                  waves through LDS -> ONE float per column and workgroup (its local log-sum-exp) is
+//                  exchanged with the G-1 partner workgroups through L2 as 8-byte {epoch, value} granules
+//                  (single relaxed agent-scope 8-byte stores/loads: the data is the flag, no fence; two
+//                  slot sets alternate by epoch parity) and merged with the closed-form dustbin terms.
+// The blockIdx -> (pair group, j) map keeps the G partners on one XCD (blockIdx % 8), a pure speed choice:
+// the protocol is placement independent.  Spins are bounded; a timeout poisons the error word.
+struct SkcArgs {
+    const float* scores;
+    const float* alpha_dev;
+    float alpha_host;
+    float* Z;
+    unsigned long long* slots;   // [ngroups][2][G][SLOT_STRIDE] granules, zeroed before every launch
+    unsigned* error_word;
+    int B, N, M, iters, ngroups;
+};
+
+constexpr int SLOT_STRIDE = 520;
+constexpr int CL_WAVES = 8;                 // waves per workgroup (2 per SIMD: 256-VGPR budget)
+constexpr int CL_THREADS = CL_WAVES * 64;
+constexpr int CL_RPW = 128 / CL_WAVES;      // rows per wave
+constexpr int CLUSTER_LDS_FLOATS = 516 + 2 * CL_WAVES * 512 + CL_WAVES + 4;
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float identity, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+// wave-wide reductions on the VALU (DPP row shifts + row broadcasts); result broadcast from lane 63
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    v = fmaxf(v, dpp_move<0x111, 0xf>(NEG_BIG, v));   // row_shr:1
+    v = fmaxf(v, dpp_move<0x112, 0xf>(NEG_BIG, v));   // row_shr:2
+    v = fmaxf(v, dpp_move<0x114, 0xf>(NEG_BIG, v));   // row_shr:4
+    v = fmaxf(v, dpp_move<0x118, 0xf>(NEG_BIG, v));   // row_shr:8
+    v = fmaxf(v, dpp_move<0x142, 0xa>(NEG_BIG, v));   // row_bcast:15 -> rows 1, 3
+    v = fmaxf(v, dpp_move<0x143, 0xc>(NEG_BIG, v));   // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    v += dpp_move<0x111, 0xf>(0.f, v);
+    v += dpp_move<0x112, 0xf>(0.f, v);
+    v += dpp_move<0x114, 0xf>(0.f, v);
+    v += dpp_move<0x118, 0xf>(0.f, v);
+    v += dpp_move<0x142, 0xa>(0.f, v);
+    v += dpp_move<0x143, 0xc>(0.f, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+
+typedef __attribute__((address_space(1))) unsigned long long gu64;
+
+template <int G>
+__global__ __launch_bounds__(CL_THREADS) void sinkhorn_cluster_kernel(SkcArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // CLUSTER_LDS_FLOATS
+    float* v = lds;                       // [M+1] (<= 513), padded to 516
+    float* pm = lds + 516;                // [CL_WAVES][512] per-wave column maxima
+    float* ps = pm + CL_WAVES * 512;      // [CL_WAVES][512] per-wave column sums
+    float* pu = ps + CL_WAVES * 512;      // [CL_WAVES] per-wave LSE of the row potentials
+    float* misc = pu + CL_WAVES;          // [0] = u_N
+
+    const int N = a.N, M = a.M;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int group, j;
+    if ((a.ngroups & 7) == 0) {           // partners share blockIdx % 8 (observed: the XCD)
+        const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
+        j = q % G;
+        group = (q / G) * 8 + xcd;
+    } else {
+        group = blockIdx.x / G;
+        j = blockIdx.x % G;
+    }
+    const float alpha = (a.alpha_dev ? *a.alpha_dev : a.alpha_host) * MDGAT_LOG2E;
+    const float norm = -logf((float)(N + M));
+    const float lmu = norm * MDGAT_LOG2E;
+    const float lmuN = (logf((float)M) + norm) * MDGAT_LOG2E;
+    const float lnu = lmu;
+    const float lnuM = (logf((float)N) + norm) * MDGAT_LOG2E;
+    const int row0 = j * 128 + wave * CL_RPW;   // first row of this wave
+    const int col0 = lane * 8;                // first column of this lane
+    gu64* slots = (gu64*)(a.slots) + (size_t)group * 2 * G * SLOT_STRIDE;
+    unsigned epoch = 0;
+    bool failed = false;
+
+    for (int pair = group; pair < a.B; pair += a.ngroups) {
+        const float* S = a.scores + (size_t)pair * N * M;
+        // ---- the CL_RPW x 8 block of this lane, base-2 log domain (clamped addresses + selects: no branches) ----
+        float s[CL_RPW][8];
+        const bool vec_ok = (M & 3) == 0 && col0 + 8 <= M;
+#pragma unroll
+        for (int r = 0; r < CL_RPW; ++r) {
+            const int i = row0 + r;
+            const float* row = S + (size_t)min(i, N - 1) * M;
+            if (vec_ok) {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + col0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + col0 + 4);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    s[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
+                    s[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float x = row[min(col0 + c, M - 1)];
+                    s[r][c] = (i < N && col0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
+                }
+            }
+        }
+        __syncthreads();                       // previous pair's readers of v are done
+        for (int t = tid; t <= M; t += CL_THREADS) v[t] = 0.f;
+        if (tid == 0) misc[0] = 0.f;
+        float u[CL_RPW];
+#pragma unroll
+        for (int r = 0; r < CL_RPW; ++r) u[r] = 0.f;
+        __syncthreads();
+
+        for (int it = 0; it < a.iters; ++it) {
+            ++epoch;
+            // ---- row update (mdgat.py:283) ----
+            float vr[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) vr[c] = (col0 + c < M) ? v[col0 + c] : 0.f;
+            const float bM = alpha + v[M];
+            if (wave == CL_WAVES - 1) {
+                const float lse = alpha + wave_lse2(v, M, v[M], lane);
+                if (lane == 0) misc[0] = lmuN - lse;
+            }
+            float mx[CL_RPW];
+#pragma unroll
+            for (int r = 0; r < CL_RPW; ++r) {
+                float m = s[r][0] + vr[0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) m = fmaxf(m, s[r][c] + vr[c]);
+                mx[r] = m;
+            }
+#pragma unroll
+            for (int r = 0; r < CL_RPW; ++r) mx[r] = fmaxf(wave_max_dpp(mx[r]), bM);
+#pragma unroll
+            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(vr[c]));   // recompute s + v below: do not keep 128 sums live
+            float ex[CL_RPW];
+#pragma unroll
+            for (int r = 0; r < CL_RPW; ++r) {
+                float e = 0.f;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) e += ex2(s[r][c] + vr[c] - mx[r]);
+                ex[r] = e;
+            }
+#pragma unroll
+            for (int r = 0; r < CL_RPW; ++r) {
+                const float e = wave_sum_dpp(ex[r]) + ex2(bM - mx[r]);
+                u[r] = lmu - (mx[r] + lg2(e));
+            }
+            // ---- column update, wave-local part (mdgat.py:284) ----
+            float cmx[8], csm[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                float m = s[0][c] + u[0];
+#pragma unroll
+                for (int r = 1; r < CL_RPW; ++r) m = fmaxf(m, s[r][c] + u[r]);
+                asm volatile("" : "+v"(m));
+                float e = 0.f;
+#pragma unroll
+                for (int r = 0; r < CL_RPW; ++r) e += ex2(s[r][c] + u[r] - m);
+                cmx[c] = m; csm[c] = e;
+            }
+            {
+                f32x4* pmw = reinterpret_cast<f32x4*>(pm + wave * 512 + col0);
+                f32x4* psw = reinterpret_cast<f32x4*>(ps + wave * 512 + col0);
+                pmw[0] = f32x4{cmx[0], cmx[1], cmx[2], cmx[3]}; pmw[1] = f32x4{cmx[4], cmx[5], cmx[6], cmx[7]};
+                psw[0] = f32x4{csm[0], csm[1], csm[2], csm[3]}; psw[1] = f32x4{csm[4], csm[5], csm[6], csm[7]};
+            }
+            {   // LSE of this wave's valid row potentials (for the dustbin column)
+                float m = NEG_BIG;
+#pragma unroll
+                for (int r = 0; r < CL_RPW; ++r) if (row0 + r < N) m = fmaxf(m, u[r]);
+                float e = 0.f;
+#pragma unroll
+                for (int r = 0; r < CL_RPW; ++r) if (row0 + r < N) e += ex2(u[r] - m);
+                if (lane == 0) pu[wave] = (e > 0.f) ? m + lg2(e) : NEG_BIG;
+            }
+            __syncthreads();
+            // ---- merge the 16 waves, exchange with the partner workgroups, new column potentials ----
+            for (int t = tid; t <= M; t += CL_THREADS) {
+                float loc;
+                if (t < M) {
+                    float m = pm[t];
+#pragma unroll
+                    for (int w = 1; w < CL_WAVES; ++w) m = fmaxf(m, pm[w * 512 + t]);
+                    float e = 0.f;
+#pragma unroll
+                    for (int w = 0; w < CL_WAVES; ++w) e += ps[w * 512 + t] * ex2(pm[w * 512 + t] - m);
+                    loc = m + lg2(e);
+                } else {
+                    float m = pu[0];
+#pragma unroll
+                    for (int w = 1; w < CL_WAVES; ++w) m = fmaxf(m, pu[w]);
+                    float e = 0.f;
+#pragma unroll
+                    for (int w = 0; w < CL_WAVES; ++w) e += ex2(pu[w] - m);
+                    loc = m + lg2(e);
+                }
+                float vals[G];
+                vals[0] = loc;
+                if (G > 1) {
+                    gu64* mine = slots + ((size_t)(epoch & 1) * G + j) * SLOT_STRIDE + t;
+                    __hip_atomic_store(mine, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, loc),
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int p = 0; p < G; ++p) {
+                        if (p == j) { vals[p] = loc; continue; }
+                        gu64* theirs = slots + ((size_t)(epoch & 1) * G + p) * SLOT_STRIDE + t;
+                        unsigned long long x = 0;
+                        unsigned spins = 0;
+                        while (true) {
+                            x = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if ((unsigned)(x >> 32) == epoch || failed) break;
+                            if (++spins > (1u << 22)) { failed = true; atomicOr(a.error_word, 1u); break; }
+                            __builtin_amdgcn_s_sleep(2);
+                        }
+                        vals[p] = __builtin_bit_cast(float, (unsigned)x);
+                    }
+                }
+                const float uN = misc[0];
+                const float extra = (t < M) ? alpha + uN : uN;     // dustbin-row term
+                float m = extra;
+#pragma unroll
+                for (int p = 0; p < G; ++p) m = fmaxf(m, vals[p]);
+                float e = ex2(extra - m);
+#pragma unroll
+                for (int p = 0; p < G; ++p) e += ex2(vals[p] - m);
+                const float lse = m + lg2(e);
+                v[t] = (t < M) ? lnu - lse : lnuM - (alpha + lse);
+            }
+            __syncthreads();
+        }
+
+        // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units ----
+        float* Zp = a.Z + (size_t)pair * (N + 1) * (M + 1);
+        const float poison = (G > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                                 ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
+        const float vM = v[M] + poison;
+        float vr[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) vr[c] = (col0 + c < M) ? v[col0 + c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < CL_RPW; ++r) {
+            const int i = row0 + r;
+            if (i < N) {
+                float* zr = Zp + (size_t)i * (M + 1);
+#pragma unroll
+                for (int c = 0; c < 8; ++c)
+                    if (col0 + c < M) zr[col0 + c] = (s[r][c] + u[r] + vr[c]) * MDGAT_LN2 - norm;
+                if (lane == 0) zr[M] = (alpha + u[r] + vM) * MDGAT_LN2 - norm;
+            }
+        }
+        if (j == G - 1) {
+            // dustbin row: u_N from the final column potentials is NOT recomputed by the reference (it is the
+            // value of the last row update), which is what misc[0] still holds
+            const float uN = misc[0];
+            float* zl = Zp + (size_t)N * (M + 1);
+            for (int t = tid; t <= M; t += CL_THREADS) zl[t] = (alpha + uN + v[t]) * MDGAT_LN2 - norm;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // match extraction: one workgroup per pair
 struct ExArgs {
@@ -294,10 +567,56 @@ int launch_sk(const SkArgs& a, int B, hipStream_t s) {
 
 }  // namespace
 
+size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
+    if (N > 512 || M > 512) return 0;
+    return 256 + (size_t)64 * 2 * 4 * SLOT_STRIDE * sizeof(unsigned long long);
+}
+
+template <int G>
+static int launch_cluster(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
+                          float* Z, void* ws, int num_cu, hipStream_t s) {
+    int ngroups = num_cu / G;
+    if (ngroups > 64) ngroups = 64;
+    if (ngroups > B) ngroups = B;
+    if (ngroups >= 8) ngroups &= ~7;
+    if (ngroups < 1) return MDGAT_ERR_UNSUPPORTED;
+    const size_t ws_bytes = 256 + (size_t)ngroups * 2 * G * SLOT_STRIDE * sizeof(unsigned long long);
+    if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, ws_bytes, s), "memset(sinkhorn slots)")) return rc;
+    SkcArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
+              static_cast<unsigned*>(ws), B, N, M, iters, ngroups};
+    const size_t lds = CLUSTER_LDS_FLOATS * sizeof(float);
+    static bool attr_set[3] = {false, false, false};
+    const int gi = G == 1 ? 0 : (G == 2 ? 1 : 2);
+    if (!attr_set[gi]) {
+        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_cluster_kernel<G>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+                                     "sinkhorn cluster LDS attribute"))
+            return rc;
+        attr_set[gi] = true;
+    }
+    void* args[] = {&a};
+    // cooperative launch: the runtime checks that all ngroups * G workgroups can be co-resident
+    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(sinkhorn_cluster_kernel<G>), dim3(ngroups * G),
+                                              dim3(CL_THREADS), args, (unsigned)lds, s);
+    return mdgat_check_hip(e, "sinkhorn cluster launch");
+}
+
+size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_cluster_workspace_bytes(B, N, M); }
+
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, hipStream_t s) {
+                    int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
     if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("sinkhorn: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
+    const size_t need = sinkhorn_cluster_workspace_bytes(B, N, M);
+    if (need && ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 255) == 0) {
+        int dev = 0, num_cu = 0;
+        if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
+        if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
+        if (N <= 128) return launch_cluster<1>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
+        if (N <= 256) return launch_cluster<2>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
+        return launch_cluster<4>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
+    }
+    // streaming kernel: any shape up to M = 2048, no workspace
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters};
     if (M <= 64) return launch_sk<1, 16>(a, B, s);
     if (M <= 128) return launch_sk<2, 16>(a, B, s);

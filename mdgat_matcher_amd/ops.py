@@ -21,15 +21,21 @@ def _need_cuda(*ts):
             raise RuntimeError('mdgat_matcher_amd ops run on MI355X only (no CPU fallback)')
 
 
-def sinkhorn(scores: torch.Tensor, bin_score: float, iters: int) -> torch.Tensor:
-    """log_optimal_transport (mdgat.py:288-308): scores [B, N, M] -> Z [B, N+1, M+1] (fp32)."""
+def sinkhorn(scores: torch.Tensor, bin_score: float, iters: int, streaming: bool = False) -> torch.Tensor:
+    """log_optimal_transport (mdgat.py:288-308): scores [B, N, M] -> Z [B, N+1, M+1] (fp32).
+
+    N, M <= 512 run on the register-resident cluster kernel (needs a small workspace, allocated here);
+    larger shapes, or ``streaming=True``, use the one-workgroup-per-pair streaming kernel."""
     _need_cuda(scores)
     s = scores.to(torch.float32).contiguous()
     B, N, M = s.shape
     Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=s.device)
+    lib = _lib.load()
     with torch.cuda.device(s.device):
-        _lib.check(_lib.load().mdgat_sinkhorn(B, N, M, s.data_ptr(), float(bin_score), int(iters), Z.data_ptr(),
-                                              None, 0, _stream(s)), 'mdgat_sinkhorn')
+        need = 0 if streaming else lib.mdgat_sinkhorn_workspace_bytes(B, N, M)
+        ws = torch.empty(need, dtype=torch.uint8, device=s.device) if need else None
+        _lib.check(lib.mdgat_sinkhorn(B, N, M, s.data_ptr(), float(bin_score), int(iters), Z.data_ptr(),
+                                      ws.data_ptr() if ws is not None else None, need, _stream(s)), 'mdgat_sinkhorn')
     return Z
 
 

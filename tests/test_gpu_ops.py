@@ -148,8 +148,20 @@ def test_sinkhorn_vs_oracle(N, M, iters):
     rs = np.random.RandomState(N * 3 + M)
     s = torch.from_numpy(rs.standard_normal((3, N, M)) * 4.0)
     ref = O.log_optimal_transport(s, 0.7, iters)
-    Z = ops.sinkhorn(s.to(DEV), 0.7, iters).cpu().double()
-    assert (Z - ref).abs().max() < 1e-4
+    for streaming in (False, True):     # cluster kernel (N, M <= 512) and streaming kernel
+        Z = ops.sinkhorn(s.to(DEV), 0.7, iters, streaming=streaming).cpu().double()
+        assert (Z - ref).abs().max() < 1e-4, streaming
+
+
+@pytest.mark.parametrize('B,N,M', [(1, 512, 512), (70, 512, 512), (5, 200, 300), (9, 500, 37), (3, 128, 512), (130, 129, 64)])
+def test_sinkhorn_cluster_matches_streaming(B, N, M):
+    """The two kernels implement the same iteration: they must agree to fp32 round-off for any batch size
+    (more pairs than resident groups: the persistent loop; ragged shapes: the masks)."""
+    s = torch.randn(B, N, M, device=DEV, generator=torch.Generator(DEV).manual_seed(B + N)) * 3
+    Zc = ops.sinkhorn(s, 1.0, 30)
+    Zs = ops.sinkhorn(s, 1.0, 30, streaming=True)
+    assert torch.isfinite(Zc).all()
+    assert (Zc - Zs).abs().max() < 2e-5
 
 
 def test_sinkhorn_marginals_full_size():
