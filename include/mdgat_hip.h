@@ -122,9 +122,12 @@ int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_thr
 
 /* attention / dynamic_attention (mdgat.py:190-210) on projected q/k/v in the library layout
  * [B][P][3][4][32]; `cross` selects the other frame as source (mdgat.py:263-266); topk 0 = full.
- * msg [B][P][128] with channel = head*32 + dim. */
+ * msg [B][P][128] with channel = head*32 + dim.  The kernel consumes q/k/v as split-f16 operands
+ * (DESIGN.md section 3); this entry point converts the fp32 input into `workspace` first (16-byte
+ * aligned, mdgat_attention_workspace_bytes), the forward writes that layout from its projection. */
 int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg,
-                    void* stream);
+                    void* workspace, size_t workspace_bytes, void* stream);
+size_t mdgat_attention_workspace_bytes(int B, int N, int M);
 
 /* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
  * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */

@@ -53,7 +53,9 @@ SIGNATURES = {
                                  C.c_size_t, C.c_void_p]),
     'mdgat_sinkhorn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_extract': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4 + [C.c_void_p]),
-    'mdgat_attention': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mdgat_attention': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_size_t, C.c_void_p]),
+    'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_pointwise': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'mdgat_knn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -117,6 +117,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
 namespace {
 struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
+    _Float16* qkv16;
     size_t sk_bytes;
     size_t total;   // floats
 };
@@ -133,6 +134,7 @@ Workspace carve(float* base, int B, int N, int M) {
     w.Z = take((size_t)B * (N + 1) * (M + 1));
     w.sk_bytes = mdgat_sinkhorn_ws_bytes_impl(B, N, M);
     w.sk = take((w.sk_bytes + 3) / 4);
+    w.qkv16 = reinterpret_cast<_Float16*>(take((mdgat_qkv16_halves(B, N, M) + 1) / 2));
     w.total = o;
     return w;
 }
@@ -205,12 +207,14 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
 
     // ---- 2L attentional propagation layers (mdgat.py:259-276) ----
+    const Qkv16 q16 = mdgat_qkv16_carve(ws.qkv16, B, N, M);
     for (int i = 0; i < L2; ++i) {
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
         // q, k, v of every point from its own descriptor (proj[0..2], mdgat.py:227-232)
         if ((rc = launch_gemm(pointwise(ws.x, 128, 128, lw + bl.qkv_w, lw + bl.qkv_b, 0, ws.qkv, 384, R, 384), s))) return rc;
-        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], ws.qkv, ws.msg, s))) return rc;
+        if ((rc = launch_qkv_split(B, N, M, ws.qkv, q16, s))) return rc;
+        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s))) return rc;
         // hidden = relu(BN(W1 [x ; merge(msg)])) with merge and BN folded into W1 (mdgat.py:237, 247-248)
         {
             GemmArgs g = pointwise(ws.x, 128, 256, lw + bl.mlp1_w, lw + bl.mlp1_b, 1, ws.hid, 256, R, 256);
@@ -265,10 +269,23 @@ extern "C" int mdgat_extract(int B, int N, int M, const float* Z, int mode, floa
     return launch_extract(B, N, M, Z, mode, match_threshold, matches0, matches1, mscores0, mscores1, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, void* stream) {
-    if (!qkv || !msg) { mdgat_set_error("mdgat_attention: null pointer"); return MDGAT_ERR_BAD_ARG; }
+extern "C" size_t mdgat_attention_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return mdgat_qkv16_halves(B, N, M) * sizeof(_Float16);
+}
+
+extern "C" int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+    if (!qkv || !msg || !workspace) { mdgat_set_error("mdgat_attention: null pointer"); return MDGAT_ERR_BAD_ARG; }
     if (topk < 0) { mdgat_set_error("mdgat_attention: topk < 0"); return MDGAT_ERR_BAD_ARG; }
-    return launch_attention(B, N, M, cross, topk, qkv, msg, static_cast<hipStream_t>(stream));
+    if (workspace_bytes < mdgat_attention_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        mdgat_set_error("mdgat_attention: workspace too small or not 16-byte aligned");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Qkv16 q16 = mdgat_qkv16_carve(static_cast<_Float16*>(workspace), B, N, M);
+    if (int rc = launch_qkv_split(B, N, M, qkv, q16, s)) return rc;
+    return launch_attention(B, N, M, cross, topk, q16, msg, s);
 }
 
 extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,

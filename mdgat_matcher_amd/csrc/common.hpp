@@ -7,9 +7,22 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 #define MDGAT_LOG2E 1.4426950408889634f
 #define MDGAT_LN2 0.6931471805599453f
+
+// Split-f16 operands: x = hi + lo / 2048 with hi = f16(x), lo = f16((x - hi) * 2048) - 22 mantissa bits, so
+// hi.hi + (hi.lo + lo.hi) / 2048 on the f16 matrix cores is an fp32-class product.
+#define MDGAT_SPLIT_SCALE 2048.0f
+#define MDGAT_SPLIT_INV 0.00048828125f
+#ifdef __HIPCC__
+__device__ __forceinline__ void mdgat_split(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)((x - (float)h) * MDGAT_SPLIT_SCALE);
+}
+#endif
 
 // row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
 // (cdna_hip_programming.md section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).
@@ -58,7 +71,17 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 int launch_encode_l0(int B, int N, int P, int off, const float* kpts, const float* sigma, const float* fpfh,
                      const float* w, const BlobLayout& bl, float* hk0, float* hd0, hipStream_t s);
 
-int launch_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, hipStream_t s);
+// q/k/v of every point in the split-f16 operand layouts of the attention kernel (attention.hip)
+struct Qkv16 {
+    _Float16* q16;    // [B][P][4 heads][2 planes][32 dims], pre-scaled by log2(e) / sqrt(32)
+    _Float16* k16;    // [B][P][4][2][32]
+    _Float16* vt16;   // [B][4][2][32][PP]: V transposed, keys contiguous; frame 1 starts at column Npad
+    int Npad, PP;     // Npad = N rounded up to 32, PP = Npad + (M rounded up to 32)
+};
+size_t mdgat_qkv16_halves(int B, int N, int M);
+Qkv16 mdgat_qkv16_carve(_Float16* base, int B, int N, int M);
+int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& out, hipStream_t s);
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s);
 
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
                     int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s);

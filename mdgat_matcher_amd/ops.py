@@ -61,9 +61,12 @@ def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0) -> 
     B, P = x.shape[0], x.shape[1]
     assert P == N + M and tuple(x.shape[2:]) == (3, 4, 32)
     msg = torch.empty((B, P, 128), dtype=torch.float32, device=x.device)
+    lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mdgat_attention(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
-                                               _stream(x)), 'mdgat_attention')
+        need = lib.mdgat_attention_workspace_bytes(B, N, M)
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+        _lib.check(lib.mdgat_attention(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
+                                       ws.data_ptr(), need, _stream(x)), 'mdgat_attention')
     return msg
 
 

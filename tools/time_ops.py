@@ -1,0 +1,42 @@
+"""Ad-hoc kernel timing on the GPU box (HIP events on torch's stream): python tools/time_ops.py [B] [N]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdgat_matcher_amd import ops  # noqa: E402
+
+
+def t_ms(fn, reps=10, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    dev = 'cuda:0'
+    g = torch.Generator(dev).manual_seed(0)
+    qkv = torch.randn(B, 2 * n, 3, 4, 32, device=dev, generator=g) * 1.3
+    fl = B * 1024.0 * n * n * 2
+    for name, fn in (('attention_full', lambda: ops.attention(qkv, n, n, False, 0)),
+                     ('attention_cross', lambda: ops.attention(qkv, n, n, True, 0)),
+                     ('attention_top128', lambda: ops.attention(qkv, n, n, False, 128)),
+                     ('attention_top64', lambda: ops.attention(qkv, n, n, False, 64))):
+        ms = t_ms(fn)
+        print(f'{name}: {ms:.4f} ms  ({fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, incl. the fp32->f16 split pre-pass)')
+    scores = torch.randn(B, n, n, device=dev, generator=g) * 3
+    print(f'sinkhorn100: {t_ms(lambda: ops.sinkhorn(scores, 1.0, 100)):.4f} ms')
+
+
+if __name__ == '__main__':
+    main()
