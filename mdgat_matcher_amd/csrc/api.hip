@@ -56,9 +56,14 @@ struct mdgat_handle {
     mdgat_config cfg;
     int device;
     BlobLayout bl;
-    float* weights;   // device
+    float* weights;      // device, fp32 blob (pack.py layout)
+    _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
 };
+
+// split-weight buffer: per layer [w1 256x2x256 | w2 128x2x256 | qkv 384x2x128], then final_proj 128x2x128
+static constexpr size_t WS_W1 = 0, WS_W2 = 256 * 512, WS_QKV = WS_W2 + 128 * 512, WS_LAYER = WS_QKV + 384 * 256;
+static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + 128 * 256; }
 
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
@@ -78,13 +83,15 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->device = device;
     h->bl = mdgat_blob_layout(cfg->L);
     h->weights = nullptr;
+    h->wsplit = nullptr;
     h->loaded = false;
     int prev = 0;
     (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
+    if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMalloc(split weights)");
     (void)hipSetDevice(prev);
-    if (rc) { delete h; return rc; }
+    if (rc) { if (h->weights) (void)hipFree(h->weights); delete h; return rc; }
     *out = h;
     return MDGAT_OK;
 }
@@ -101,6 +108,22 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
                                      "hipMemcpy(weights)"))
             return rc;
     }
+    // split-f16 copies of the matrices the MFMA kernels consume (synchronous, like the copy above)
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = mdgat_check_hip(hipSetDevice(h->device), "hipSetDevice");
+    const BlobLayout& bl = h->bl;
+    for (int i = 0; i < 2 * h->cfg.L && !rc; ++i) {
+        const float* lw = h->weights + bl.layer0 + (size_t)i * bl.layer_stride;
+        _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
+        rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, nullptr);
+    }
+    if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, nullptr);
+    if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "split weights");
+    (void)hipSetDevice(prev);
+    if (rc) return rc;
     h->loaded = true;
     return MDGAT_OK;
 }
@@ -110,6 +133,7 @@ extern "C" float* mdgat_weights_device_ptr(mdgat_handle* h) { return h ? h->weig
 extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (!h) return;
     if (h->weights) (void)hipFree(h->weights);
+    if (h->wsplit) (void)hipFree(h->wsplit);
     delete h;
 }
 
@@ -207,33 +231,35 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
 
     // ---- 2L attentional propagation layers (mdgat.py:259-276) ----
+    // launch i: [attention of layer i] -> [mlp + residual of layer i | q/k/v of layer i + 1 (or final_proj)]
     const Qkv16 q16 = mdgat_qkv16_carve(ws.qkv16, B, N, M);
+    if ((N & 31) || (M & 31))   // the attention kernel reads V^T in whole 32-key blocks: pad columns must be zero
+        if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
+    float* mdesc = ws.hid;
+    const _Float16* wfinal = h->wsplit + WS_LAYER * (size_t)L2;
+    {
+        LayerLaunch p{};
+        p.x = ws.x; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 0;
+        if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
+        else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
+        if ((rc = launch_layer(p, s))) return rc;
+    }
     for (int i = 0; i < L2; ++i) {
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
+        const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
-        // q, k, v of every point from its own descriptor (proj[0..2], mdgat.py:227-232)
-        if ((rc = launch_gemm(pointwise(ws.x, 128, 128, lw + bl.qkv_w, lw + bl.qkv_b, 0, ws.qkv, 384, R, 384), s))) return rc;
-        if ((rc = launch_qkv_split(B, N, M, ws.qkv, q16, s))) return rc;
         if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s))) return rc;
-        // hidden = relu(BN(W1 [x ; merge(msg)])) with merge and BN folded into W1 (mdgat.py:237, 247-248)
-        {
-            GemmArgs g = pointwise(ws.x, 128, 256, lw + bl.mlp1_w, lw + bl.mlp1_b, 1, ws.hid, 256, R, 256);
-            g.K0 = 128; g.A1 = ws.msg; g.lda1 = 128;
-            if ((rc = launch_gemm(g, s))) return rc;
-        }
-        // x += W2 hidden + b2 (mdgat.py:248, 274)
-        {
-            GemmArgs g = pointwise(ws.hid, 256, 256, lw + bl.mlp2_w, lw + bl.mlp2_b, 0, ws.x, 128, R, 128);
-            g.R = ws.x; g.ldr = 128;
-            if ((rc = launch_gemm(g, s))) return rc;
-        }
+        LayerLaunch p{};
+        p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1;
+        p.w1s = ls + WS_W1; p.b1 = lw + bl.mlp1_b; p.w2s = ls + WS_W2; p.b2 = lw + bl.mlp2_b;
+        if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
+        else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
+        if ((rc = launch_layer(p, s))) return rc;
         if (taps && taps->x_layers)
             if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_layers + (size_t)i * R * 128, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_layers"))) return rc;
     }
 
-    // ---- final projection (mdgat.py:397) and score matrix (430-431) ----
-    float* mdesc = ws.msg;
-    if ((rc = launch_gemm(pointwise(ws.x, 128, 128, w + bl.final_w, w + bl.final_b, 0, mdesc, 128, R, 128), s))) return rc;
+    // ---- final projection (mdgat.py:397, computed by the last launch above) and score matrix (430-431) ----
     if (taps && taps->mdesc)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
     {

@@ -37,6 +37,7 @@ struct AttnArgs {
     const _Float16* vt16;  // [B][4][2][32][PP]  keys of frame 0 at columns [0, N), frame 1 at [Npad, Npad + M); pads zero
     float* msg;            // [B][P][128]
     int N, M, Npad, PP, cross, topk;
+    float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
 };
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
@@ -51,18 +52,35 @@ __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) 
     for (int j = 0; j < 8; ++j) l[j] = (_Float16)(p[j] - (float)h[j]);
 }
 
-template <int NBLK>
-__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk) {
+// Exact k-th largest logit of every row (rows = lane pairs (l, l ^ 32), 16 NBLK registers each).
+// Probe thresholds t, count(s >= t) per row, keep a bracket lo < thr <= hv with counts clo > k > chi.
+// The first probe is the normal quantile of the row (mean + zq * sd); later probes step by
+// (count - k) / density with the normal density at the probe, falling back to interpolation inside the
+// bracket and to its midpoint.  A row stops probing when count == k, when no float lies strictly inside
+// the bracket (exact ties at the k-th value: all kept), or when it is one element away from k on either
+// side; those rows are finished by direct order-statistic passes after the loop (max below hv / second
+// smallest at or above lo).  All rows of a wave run in lockstep, so the loop ends with its slowest row.
+template <int NBLK, bool EXACT>
+__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq) {
     const float INF = __builtin_inff();
-    float smin = INF;
+    float smin = INF, sum = 0.f, sq = 0.f;
 #pragma unroll
     for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float s = S[jb][r];
-            smin = fminf(smin, s == -INF ? INF : s);
+            float s = S[jb][r];
+            if (!EXACT) { smin = fminf(smin, s == -INF ? INF : s); s = (s == -INF) ? 0.f : s; }
+            else smin = fminf(smin, s);
+            sum += s;
+            sq = fmaf(s, s, sq);
         }
     smin = fminf(smin, xor32(smin));
+    sum += xor32(sum);
+    sq += xor32(sq);
+    const float inv_n = 1.0f / (float)nk;
+    const float mu = sum * inv_n;
+    const float sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
+    const float inv_sd = 1.0f / sd;
     auto count_ge = [&](float t) {
         int c = 0;
 #pragma unroll
@@ -74,34 +92,74 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     float thr = -INF;
     float lo = smin, hv = m;
     int clo = nk, chi = count_ge(m);
-    bool done = false;
-    if (chi >= k) { thr = m; done = true; }          // ties at the maximum (or k == 1)
-    if (nk <= k) { thr = smin; done = true; }        // this frame has exactly k keys: keep all
-    for (int it = 0; it < 96; ++it) {
-        if (__all(done)) break;
-        const float mid = 0.5f * lo + 0.5f * hv;
-        float t = mid;
-        if (!(it & 1)) {
-            const float frac = (float)(clo - k) / (float)(clo - chi);
-            const float ti = lo + (hv - lo) * frac;
-            if (ti > lo && ti < hv) t = ti;
+    // state: 0 probing, 1 done, 2 finish from above (k - chi == 1), 3 finish from below (clo - k == 1)
+    int state = 0;
+    if (chi >= k) { thr = m; state = 1; }            // ties at the maximum (or k == 1)
+    if (nk <= k) { thr = smin; state = 1; }          // this frame has exactly k keys: keep all
+    if (state == 0 && k - chi == 1) state = 2;
+    if (state == 0 && clo - k == 1) state = 3;
+    float t = mu + zq * sd;
+    for (int it = 0; it < 64; ++it) {
+        if (__all(state != 0)) break;
+        if (!(t > lo && t < hv)) {
+            t = lo + (hv - lo) * (((float)(clo - k) + 0.5f) / (float)(clo - chi));
+            if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
         }
         const bool collapsed = !(t > lo && t < hv);   // no float strictly inside the bracket
         const int c = count_ge(t);
-        if (!done) {
-            if (collapsed) { thr = lo; done = true; }          // ties at the k-th value: keep them all
-            else if (c == k) { thr = t; done = true; }
-            else if (c > k) { lo = t; clo = c; }
-            else { hv = t; chi = c; }
+        if (state == 0) {
+            if (collapsed) { thr = lo; state = 1; }            // ties at the k-th value: keep them all
+            else if (c == k) { thr = t; state = 1; }
+            else {
+                if (c > k) { lo = t; clo = c; } else { hv = t; chi = c; }
+                if (k - chi == 1) state = 2;
+                else if (clo - k == 1) state = 3;
+                else {
+                    const float z = (t - mu) * inv_sd;
+                    const float dens = (float)nk * 0.3989422804f * inv_sd * __builtin_amdgcn_exp2f(-0.7213475204f * z * z);
+                    const float tn = t + (float)(c - k) / fmaxf(dens, 1e-3f * (float)nk * inv_sd);
+                    t = ((it & 3) == 3) ? lo : tn;             // every 4th probe: interpolate inside the bracket
+                }
+            }
         }
     }
-    if (!done) thr = lo;
+    if (state == 0) { thr = lo; state = 1; }
+    if (__any(state == 2)) {      // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
+        float mx = -INF;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; mx = fmaxf(mx, s < hv ? s : -INF); }
+        mx = fmaxf(mx, xor32(mx));
+        if (state == 2) thr = mx;
+    }
+    if (__any(state == 3)) {      // k + 1 logits are >= lo: drop the smallest of them
+        float e1 = INF;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e1 = fminf(e1, s >= lo ? s : INF); }
+        e1 = fminf(e1, xor32(e1));
+        float e2 = INF;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e2 = fminf(e2, s > e1 ? s : INF); }
+        e2 = fminf(e2, xor32(e2));
+        // (if the smallest is tied, dropping "it" is ambiguous: keep the ties, thr = e1)
+        if (state == 3) thr = (count_ge(e2) >= k) ? e2 : e1;
+    }
     return thr;
 }
 
-// NBLK = compile-time bound on the number of 32-key blocks (registers for the row: 16 NBLK)
-template <bool TOPK, int NBLK>
-__global__ __launch_bounds__(256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnArgs a) {
+// NBLK  = 32-key blocks per chunk (16 NBLK row registers); full attention walks the keys chunk by chunk
+//         with an online softmax (running max / sum, the output rescaled between chunks), dynamic
+//         attention needs the whole row at once and therefore a single chunk.
+// EXACT = the key count is a multiple of 32 NBLK: no per-block conditions, one basic block per chunk.
+// Threads: 512 (two waves per SIMD, <= 256 registers) for NBLK <= 8, else 256 (one wave per SIMD).
+template <bool TOPK, int NBLK, bool EXACT>
+__global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnArgs a) {
+    constexpr int NT = NBLK <= 8 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,21 +180,43 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnA
     _Float16* Ks = smem;                    // [nkp][KROWH]
     _Float16* Vs = smem + nkp * KROWH;      // [2 planes][32 dims][VSTR]
 
-    // ---- stage K (128 contiguous bytes per key) and V^T (nkp contiguous halves per (plane, dim)) ----
+    // ---- stage K (128 contiguous bytes per key) and V^T (nkp contiguous halves per (plane, dim)),
+    //      four 16-byte loads in flight per thread ----
     {
         const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
-        for (int idx = tid; idx < nkp * 8; idx += 256) {
-            const int row = idx >> 3, c = idx & 7;
-            f32x4 x = {0.f, 0.f, 0.f, 0.f};
-            if (row < nk) x = *reinterpret_cast<const f32x4*>(kg + (size_t)row * 256 + c * 8);
-            *reinterpret_cast<f32x4*>(Ks + row * KROWH + c * 8) = x;
+        const int nk8 = nkp * 8;
+        for (int base = tid; base < nk8; base += 4 * NT) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NT;
+                const int row = idx >> 3, c = idx & 7;
+                x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (idx < nk8 && row < nk) x[u] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * 256 + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NT;
+                if (idx < nk8) *reinterpret_cast<f32x4*>(Ks + (idx >> 3) * KROWH + (idx & 7) * 8) = x[u];
+            }
         }
         const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
         const int cpr = nblk * 4;           // 16-byte chunks per row
-        for (int idx = tid; idx < 64 * cpr; idx += 256) {
-            const int row = idx / cpr, c = idx - row * cpr;
-            *reinterpret_cast<f32x4*>(Vs + row * VSTR + c * 8) =
-                *reinterpret_cast<const f32x4*>(vg + (size_t)row * a.PP + c * 8);
+        const int nv = 64 * cpr;
+        for (int base = tid; base < nv; base += 4 * NT) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NT;
+                const int row = idx / cpr, c = idx - row * cpr;
+                if (idx < nv) x[u] = *reinterpret_cast<const f32x4*>(vg + (size_t)row * a.PP + c * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * NT;
+                const int row = idx / cpr, c = idx - row * cpr;
+                if (idx < nv) *reinterpret_cast<f32x4*>(Vs + row * VSTR + c * 8) = x[u];
+            }
         }
     }
     __syncthreads();
@@ -146,8 +226,9 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnA
     // only the last block can be partially valid: register r of half `hi` holds key 16 (r >> 3) + 8 hi + (r & 7)
     const int last_lim = nk - (nblk - 1) * 32 - 8 * hi;
     const bool last_partial = (nk & 31) != 0;
+    constexpr int QT = (NT / 64) * 32;     // queries per workgroup pass
 
-    for (int q0 = blockIdx.x * 128; q0 < nq; q0 += gridDim.x * 128) {
+    for (int q0 = blockIdx.x * QT; q0 < nq; q0 += gridDim.x * QT) {
         const int qw = q0 + wave * 32;
         if (qw >= nq) continue;             // wave-uniform; no barrier inside the loop
 
@@ -162,79 +243,99 @@ __global__ __launch_bounds__(256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnA
             ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
         }
 
-        // ---- S^T = K Q^T, whole row resident in registers ----
-        f32x16 S[NBLK];
-#pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb) {
-            if (jb < nblk) {
-                const _Float16* kp = Ks + (jb * 32 + krow) * KROWH + 8 * hi;
-                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
-                const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
-                const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
-                const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                f32x16 acc, acx;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
-                if (last_partial && jb == nblk - 1) {   // wave-uniform
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        if (16 * (r >> 3) + (r & 7) >= last_lim) acc[r] = NEG_INF;
-                }
-                S[jb] = acc;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
-            }
-        }
-
-        // ---- row max ----
-        float m = NEG_INF;
-#pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
-        m = fmaxf(m, xor32(m));
-
-        // ---- exact top-k threshold (dynamic layers only) ----
-        float thr = NEG_INF;
-        if (TOPK) thr = topk_threshold<NBLK>(S, m, a.topk, nk);
-
-        // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O = P' V ----
-        const float m11 = m - 11.0f;
-        float l = 0.f;
+        float m_run = NEG_INF, l = 0.f;
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+
+        for (int c0 = 0; c0 < nblk; c0 += NBLK) {
+            // ---- S^T = K Q^T for the NBLK blocks of this chunk, resident in registers ----
+            f32x16 S[NBLK];
 #pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb) {
-            if (jb < nblk) {
+            for (int jb = 0; jb < NBLK; ++jb) {
+                if (EXACT || c0 + jb < nblk) {
+                    const _Float16* kp = Ks + ((c0 + jb) * 32 + krow) * KROWH + 8 * hi;
+                    const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
+                    const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
+                    const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
+                    const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
+                    f32x16 acc, acx;
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float p[8];
+                    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float s = S[jb][8 * t + j];
-                        float e = __builtin_amdgcn_exp2f(s - m11);
-                        if (TOPK) e = (s >= thr) ? e : 0.f;
-                        p[j] = e;
-                        l += e;
+                    for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+                    if (!EXACT && last_partial && c0 + jb == nblk - 1) {   // wave-uniform
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (16 * (r >> 3) + (r & 7) >= last_lim) acc[r] = NEG_INF;
                     }
-                    f16x8 ph, pl;
-                    split8(p, ph, pl);
-                    const _Float16* vp = Vs + l31 * VSTR + jb * 32 + t * 16 + 8 * hi;
-                    const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
-                    const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
-                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
-                    Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
-                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                    S[jb] = acc;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
+                }
+            }
+
+            // ---- chunk max, running max ----
+            float m = NEG_INF;
+#pragma unroll
+            for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
+            m = fmaxf(m, xor32(m));
+
+            // ---- exact top-k threshold (dynamic layers: the chunk is the whole row) ----
+            float thr = NEG_INF;
+            if (TOPK) thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq);
+
+            if (!TOPK && c0 > 0) {
+                // online softmax: bring the running sum and output to the new maximum
+                const float m_new = fmaxf(m_run, m);
+                const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+                m = m_new;
+                if (!__all(sc == 1.0f)) {
+                    l *= sc;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
+                        Om[r] *= f;
+                        Ox[r] *= f;
+                    }
+                }
+            }
+            m_run = m;
+
+            // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
+            const float m11 = m - 11.0f;
+#pragma unroll
+            for (int jb = 0; jb < NBLK; ++jb) {
+                if (EXACT || c0 + jb < nblk) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float p[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) {
+                            const float s = S[jb][8 * t + j];
+                            float e = __builtin_amdgcn_exp2f(s - m11);
+                            if (TOPK) e = (s >= thr) ? e : 0.f;
+                            p[j] = e;
+                            l += e;
+                        }
+                        f16x8 ph, pl;
+                        split8(p, ph, pl);
+                        const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
+                        const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
+                        const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
+                        Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                        Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                        Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                    }
                 }
             }
         }
@@ -304,11 +405,34 @@ int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& o, hipS
     return mdgat_check_hip(hipGetLastError(), "qkv split launch");
 }
 
+// upper-tail standard normal quantile (Acklam's rational approximation, |error| < 1.2e-9 - only a search start)
+static float normal_quantile_upper(double p) {
+    if (p <= 0.0) return 8.f;
+    if (p >= 1.0) return -8.f;
+    const double q0 = 1.0 - p;   // lower-tail probability
+    static const double a[] = {-3.969683028665376e+01, 2.209460984245205e+02, -2.759285104469687e+02, 1.383577518672690e+02, -3.066479806614716e+01, 2.506628277459239e+00};
+    static const double b[] = {-5.447609879822406e+01, 1.615858368580409e+02, -1.556989798598866e+02, 6.680131188771972e+01, -1.328068155288572e+01};
+    static const double c[] = {-7.784894002430293e-03, -3.223964580411365e-01, -2.400758277161838e+00, -2.549732539343734e+00, 4.374664141464968e+00, 2.938163982698783e+00};
+    static const double d[] = {7.784695709041462e-03, 3.224671290700398e-01, 2.445134137142996e+00, 3.754408661907416e+00};
+    double x;
+    if (q0 < 0.02425) {
+        const double q = sqrt(-2 * log(q0));
+        x = (((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    } else if (q0 <= 1 - 0.02425) {
+        const double q = q0 - 0.5, r = q * q;
+        x = (((((a[0] * r + a[1]) * r + a[2]) * r + a[3]) * r + a[4]) * r + a[5]) * q / (((((b[0] * r + b[1]) * r + b[2]) * r + b[3]) * r + b[4]) * r + 1);
+    } else {
+        const double q = sqrt(-2 * log(1 - q0));
+        x = -(((((c[0] * q + c[1]) * q + c[2]) * q + c[3]) * q + c[4]) * q + c[5]) / ((((d[0] * q + d[1]) * q + d[2]) * q + d[3]) * q + 1);
+    }
+    return (float)x;
+}
+
 int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
     if (nk_max > MAXBLK * 32) {
-        mdgat_set_error("attention: %d keys > %d supported by the register-resident kernel", nk_max, MAXBLK * 32);
+        mdgat_set_error("attention: %d keys > %d supported by the LDS-resident kernel", nk_max, MAXBLK * 32);
         return MDGAT_ERR_UNSUPPORTED;
     }
     if (topk > 0) {
@@ -319,31 +443,35 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             return MDGAT_ERR_BAD_ARG;
         }
     }
-    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk};
+    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f};
+    if (topk > 0) a.zq = normal_quantile_upper(((double)topk - 0.5) / (double)nk_max);
     const int nkp = ((nk_max + 31) / 32) * 32;
     const size_t lds = ((size_t)nkp * KROWH + (size_t)64 * (nkp + 8)) * sizeof(_Float16);
-    // one workgroup per (pair, frame, head) loops over its query tiles; split the tiles over more
-    // workgroups only when there are too few (pair, frame, head) units to fill the chip twice
-    const int qtiles = (nk_max + 127) / 128;
-    int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
-    if (qsplit > qtiles) qsplit = qtiles;
-    if (qsplit < 1) qsplit = 1;
-    dim3 grid(qsplit, MDGAT_HEADS, B * 2);
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     const int nblk = nkp / 32;
-    auto go = [&](auto kern) {
+    // one workgroup per (pair, frame, head) loops over its query tiles; split the tiles over more
+    // workgroups only when there are too few (pair, frame, head) units to fill the chip twice
+    auto go = [&](auto kern, int threads) {
+        const int qt = (threads / 64) * 32;
+        const int qtiles = (nk_max + qt - 1) / qt;
+        int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
+        if (qsplit > qtiles) qsplit = qtiles;
+        if (qsplit < 1) qsplit = 1;
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        hipLaunchKernelGGL(kern, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(threads), lds, s, a);
     };
+    const bool mult32 = (N % 32 == 0) && (M % 32 == 0);
     if (dyn) {
-        if (nblk <= 4) go(attention_kernel<true, 4>);
-        else if (nblk <= 8) go(attention_kernel<true, 8>);
-        else go(attention_kernel<true, 16>);
+        // the whole row in one chunk
+        if (nblk <= 4) go(attention_kernel<true, 4, false>, 512);
+        else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true>, 512); else go(attention_kernel<true, 8, false>, 512); }
+        else { if (mult32 && N == 512 && M == 512) go(attention_kernel<true, 16, true>, 256); else go(attention_kernel<true, 16, false>, 256); }
     } else {
-        if (nblk <= 4) go(attention_kernel<false, 4>);
-        else if (nblk <= 8) go(attention_kernel<false, 8>);
-        else go(attention_kernel<false, 16>);
+        // chunks of 8 blocks (256 keys), two waves per SIMD
+        if (nblk <= 4) go(attention_kernel<false, 4, false>, 512);
+        else if (mult32 && N % 256 == 0 && M % 256 == 0) go(attention_kernel<false, 8, true>, 512);
+        else go(attention_kernel<false, 8, false>, 512);
     }
     return mdgat_check_hip(hipGetLastError(), "attention launch");
 }

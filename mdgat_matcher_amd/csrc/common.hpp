@@ -83,6 +83,20 @@ Qkv16 mdgat_qkv16_carve(_Float16* base, int B, int N, int M);
 int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& out, hipStream_t s);
 int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s);
 
+// fused layer tail (layer.hip): [mlp.0 -> mlp.3 -> residual] of one layer + q|k|v projection of the next
+struct LayerLaunch {
+    float* x; const float* msg;
+    const _Float16 *w1s, *w2s, *w3s;   // split weights [rows][2][K]
+    const float *b1, *b2, *b3;
+    Qkv16 out;                         // mode3 == 1
+    float* mdesc;                      // mode3 == 2
+    int R, N, M;
+    int do_mlp;                        // 0: projection only
+    int mode3;                         // 1: q|k|v, 2: final_proj
+};
+int launch_layer(const LayerLaunch& p, hipStream_t s);
+int launch_split_rows(const float* w, _Float16* out, int rows, int K, hipStream_t s);
+
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
                     int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s);
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);

@@ -24,6 +24,7 @@ def t_ms(fn, reps=10, warm=3):
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+    only = sys.argv[3] if len(sys.argv) > 3 else ''
     dev = 'cuda:0'
     g = torch.Generator(dev).manual_seed(0)
     qkv = torch.randn(B, 2 * n, 3, 4, 32, device=dev, generator=g) * 1.3
@@ -32,8 +33,12 @@ def main():
                      ('attention_cross', lambda: ops.attention(qkv, n, n, True, 0)),
                      ('attention_top128', lambda: ops.attention(qkv, n, n, False, 128)),
                      ('attention_top64', lambda: ops.attention(qkv, n, n, False, 64))):
+        if only and only not in name:
+            continue
         ms = t_ms(fn)
         print(f'{name}: {ms:.4f} ms  ({fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, incl. the fp32->f16 split pre-pass)')
+    if only and 'sinkhorn' not in only:
+        return
     scores = torch.randn(B, n, n, device=dev, generator=g) * 3
     print(f'sinkhorn100: {t_ms(lambda: ops.sinkhorn(scores, 1.0, 100)):.4f} ms')
 
