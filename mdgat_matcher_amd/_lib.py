@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmdgat_hip.so')
+LIB_PATH = os.environ.get('MDGAT_HIP_LIB') or os.path.join(_HERE, 'libmdgat_hip.so')   # override: kernel experiments only
 
 MAX_LAYERS = 64
 

@@ -24,6 +24,7 @@
 // the transposed V^T layout.  One wave per SIMD (about 370 registers), the MFMA pipe is the bound.
 #include "common.hpp"
 
+
 namespace {
 
 constexpr int ROWH256 = 520;                 // LDS row (halves) for K = 256: 256 hi | 256 lo | 8 pad
@@ -71,7 +72,9 @@ template <int K>
 __device__ __forceinline__ void stage_issue(const _Float16* g, f32x4 (&st)[8], int tid) {
     constexpr int NU = (32 * 2 * K * 2 / 16) / 256;   // 16-byte chunks per thread: 8 (K = 256) or 4 (K = 128)
 #pragma unroll
-    for (int u = 0; u < NU; ++u) st[u] = *reinterpret_cast<const f32x4*>(g + (size_t)(tid + 256 * u) * 8);
+    for (int u = 0; u < NU; ++u) {
+        st[u] = *reinterpret_cast<const f32x4*>(g + (size_t)(tid + 256 * u) * 8);
+    }
 }
 template <int K>
 __device__ __forceinline__ void stage_commit(_Float16* buf, const f32x4 (&st)[8], int tid) {
@@ -87,34 +90,46 @@ __device__ __forceinline__ void stage_commit(_Float16* buf, const f32x4 (&st)[8]
 
 // D^T block (32 channels x 32 keypoints) = W block (LDS) . X^T (register fragments), NK k-steps of 16.
 // SWAP: W is the A operand (row = channel perm), X the B operand; else X is A and W is B.
+// The W fragments are read two k-steps ahead of the MFMAs that consume them (one wave per SIMD: nothing
+// else hides the LDS latency); sched_barrier keeps the compiler from sinking the reads back to their use.
 template <int NK, bool SWAP>
 __device__ __forceinline__ void block_mma(const _Float16* buf, int wrow, int hi, const f16x8* xh, const f16x8* xl,
                                           f32x16& out) {
     constexpr int K = NK * 16, ROWH = 2 * K + 8;
     const _Float16* wp = buf + wrow * ROWH + 8 * hi;
+    auto kcol = [&](int ks) { return 16 * ks; };
     f32x16 acc, aca, acb;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc[r] = 0.f; aca[r] = 0.f; acb[r] = 0.f; }
+    f16x8 wh[NK], wl[NK];
+    wh[0] = *reinterpret_cast<const f16x8*>(wp + kcol(0));
+    wl[0] = *reinterpret_cast<const f16x8*>(wp + K + kcol(0));
+    wh[1] = *reinterpret_cast<const f16x8*>(wp + kcol(1));
+    wl[1] = *reinterpret_cast<const f16x8*>(wp + K + kcol(1));
 #pragma unroll
     for (int ks = 0; ks < NK; ++ks) {
-        const f16x8 wh = *reinterpret_cast<const f16x8*>(wp + 16 * ks);
-        const f16x8 wl = *reinterpret_cast<const f16x8*>(wp + K + 16 * ks);
-        if (SWAP) {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xh[ks], acc, 0, 0, 0);
-            aca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh, xl[ks], aca, 0, 0, 0);
-            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl, xh[ks], acb, 0, 0, 0);
-        } else {
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wh, acc, 0, 0, 0);
-            aca = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], wh, aca, 0, 0, 0);
-            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wl, acb, 0, 0, 0);
+        if (ks + 2 < NK) {
+            wh[ks + 2] = *reinterpret_cast<const f16x8*>(wp + kcol(ks + 2));
+            wl[ks + 2] = *reinterpret_cast<const f16x8*>(wp + K + kcol(ks + 2));
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of k-step ks + 2 ahead of the MFMAs of k-step ks
+        if (SWAP) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[ks], acc, 0, 0, 0);
+            aca = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[ks], aca, 0, 0, 0);
+            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[ks], acb, 0, 0, 0);
+        } else {
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wh[ks], acc, 0, 0, 0);
+            aca = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], wh[ks], aca, 0, 0, 0);
+            acb = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wl[ks], acb, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[r] = fmaf(aca[r] + acb[r], MDGAT_SPLIT_INV, acc[r]);
 }
 
 __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 2 x STAGE_HALVES
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 2 x STAGE_HALVES + 768 floats of biases
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -122,14 +137,87 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
     const int wrow = perm32(l31);
     const int pt_raw = blockIdx.x * 128 + wave * 32 + l31;
     const int pt = min(pt_raw, a.R - 1);               // clamped loads; stores are masked
-    const bool pt_ok = pt_raw < a.R;
     _Float16* buf0 = smem;
     _Float16* buf1 = smem + STAGE_HALVES;
+    float* bias1 = reinterpret_cast<float*>(smem + 2 * STAGE_HALVES);   // [256]
+    float* bias2 = bias1 + 256;                                         // [128]
+    float* bias3 = bias2 + 128;                                         // [384]
     f32x4 st[8];
+
+    const int n3 = a.mode3 == 1 ? 12 : 4;    // row blocks of phase 3
+    {
+        if (a.do_mlp) {
+            bias1[tid] = a.b1[tid];
+            if (tid < 128) bias2[tid] = a.b2[tid];
+        }
+        for (int i = tid; i < n3 * 32; i += 256) bias3[i] = a.b3[i];
+    }
 
     f16x8 xnh[8], xnl[8];     // the (new) descriptors of this lane's keypoint as 8 k-step fragments
 
-    const int n3 = a.mode3 == 1 ? 12 : 4;    // row blocks of phase 3
+    // phase-3 epilogue of row block qb
+    auto epilogue3 = [&](int qb, const f32x16& o) {
+        if (a.mode3 == 1 && qb < 8) {
+            // q or k of head qb & 3: [pt][head][plane][32 dims]; this lane's dims 16 t + 8 hi .. + 7
+            const float sc = qb < 4 ? MDGAT_LOG2E * 0.17677669529663687f : 1.0f;   // log2(e) / sqrt(32) on q
+            _Float16* dst = (qb < 4 ? a.q16 : a.k16) + ((size_t)pt * 4 + (qb & 3)) * 64 + 8 * hi;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bias[8], v[8];
+                load8(bias3 + qb * 32 + 16 * t + 8 * hi, bias);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (o[8 * t + j] + bias[j]) * sc;
+                f16x8 h, l;
+                split8s(v, h, l);
+                // lanes past the end hold a copy of the last keypoint (clamped loads): they rewrite the same values
+                *reinterpret_cast<f16x8*>(dst + 16 * t) = h;
+                *reinterpret_cast<f16x8*>(dst + 32 + 16 * t) = l;
+            }
+        } else if (a.mode3 == 1) {
+            // v of head qb & 3 (non-swapped product): lane = dim l31, registers = keypoints mfma32_row(r, hi) of this wave
+            const int head = qb & 3;
+            const float bias = bias3[qb * 32 + l31];
+            const int P = a.N + a.M;
+            const int wave_pt0 = blockIdx.x * 128 + wave * 32;
+            const bool fast = ((a.N | a.M) & 3) == 0;          // 4 consecutive keypoints share frame and pair, 8-byte aligned
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int p0 = wave_pt0 + 8 * g + 4 * hi;
+                if (p0 >= a.R) continue;
+                _Float16 h[4], l[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
+                if (fast) {
+                    const int bb = p0 / P, pp = p0 - bb * P;
+                    _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + l31) * a.PP;
+                    const int col = pp < a.N ? pp : a.Npad + pp - a.N;
+                    *reinterpret_cast<f16x4*>(row_h + col) = f16x4{h[0], h[1], h[2], h[3]};
+                    *reinterpret_cast<f16x4*>(row_h + (size_t)32 * a.PP + col) = f16x4{l[0], l[1], l[2], l[3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int pj = p0 + j;
+                        if (pj >= a.R) break;
+                        const int bj = pj / P, qj = pj - bj * P;
+                        const int col = qj < a.N ? qj : a.Npad + qj - a.N;
+                        _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + l31) * a.PP;
+                        rh[col] = h[j];
+                        rh[(size_t)32 * a.PP + col] = l[j];
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bias[8], v[8];
+                const int ch = qb * 32 + 16 * t + 8 * hi;
+                load8(bias3 + ch, bias);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = o[8 * t + j] + bias[j];
+                store8(a.mdesc + (size_t)pt * 128 + ch, v);
+            }
+        }
+    };
 
     if (a.do_mlp) {
         // ---- fragments of [x ; msg]: k-step ks covers channels 16 ks .. 16 ks + 15, this lane 8 hi .. 8 hi + 7 ----
@@ -147,6 +235,16 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
 
         // ---- phase 1: 8 row blocks of W1 -> hidden fragments (k-steps 2 rb, 2 rb + 1 of phase 2) ----
         f16x8 hh[16], hl[16];
+        auto epilogue1 = [&](int rb, const f32x16& o) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bias[8], v[8];
+                load8(bias1 + rb * 32 + 16 * t + 8 * hi, bias);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = fmaxf(o[8 * t + j] + bias[j], 0.f);
+                split8s(v, hh[2 * rb + t], hl[2 * rb + t]);
+            }
+        };
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb) {
             _Float16* cur = (rb & 1) ? buf1 : buf0;
@@ -155,42 +253,47 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
             else stage_issue<256>(a.w2s, st, tid);
             f32x16 o;
             block_mma<16, true>(cur, wrow, hi, ah, al, o);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float bias[8], v[8];
-                load8(a.b1 + rb * 32 + 16 * t + 8 * hi, bias);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = fmaxf(o[8 * t + j] + bias[j], 0.f);
-                split8s(v, hh[2 * rb + t], hl[2 * rb + t]);
-            }
-            stage_commit<256>(nxt, st, tid);
+            stage_commit<256>(nxt, st, tid);   // before the epilogue: its vmcnt wait must not cover this stage's stores
+            epilogue1(rb, o);
             __syncthreads();
         }
 
         // ---- phase 2: 4 row blocks of W2, residual, new x (fp32 to memory, split fragments kept) ----
+        auto epilogue2 = [&](int ob, const f32x16& o, const float (&res)[16]) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float bias[8], v[8];
+                const int ch = ob * 32 + 16 * t + 8 * hi;
+                load8(bias2 + ch, bias);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = res[8 * t + j] + (o[8 * t + j] + bias[j]);
+                store8(a.x + (size_t)pt * 128 + ch, v);
+                split8s(v, xnh[2 * ob + t], xnl[2 * ob + t]);
+            }
+        };
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
             _Float16* cur = (ob & 1) ? buf1 : buf0;
             _Float16* nxt = (ob & 1) ? buf0 : buf1;
             if (ob < 3) stage_issue<256>(a.w2s + (size_t)(ob + 1) * 32 * 512, st, tid);
             else stage_issue<128>(a.w3s, st, tid);
+            float res[16];   // residual x of this block, loaded ahead of the MFMAs
+            {
+                float ra[8], rb8[8];
+                const int ch = ob * 32;
+                load8(a.x + (size_t)pt * 128 + ch + 8 * hi, ra);
+                load8(a.x + (size_t)pt * 128 + ch + 16 + 8 * hi, rb8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { res[j] = ra[j]; res[8 + j] = rb8[j]; }
+            }
             f32x16 o;
             block_mma<16, true>(cur, wrow, hi, hh, hl, o);
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float bias[8], res[8], v[8];
-                const int ch = ob * 32 + 16 * t + 8 * hi;
-                load8(a.b2 + ch, bias);
-                load8(a.x + (size_t)pt * 128 + ch, res);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = res[j] + (o[8 * t + j] + bias[j]);
-                if (pt_ok) store8(a.x + (size_t)pt * 128 + ch, v);
-                split8s(v, xnh[2 * ob + t], xnl[2 * ob + t]);
-            }
             if (ob < 3) stage_commit<256>(nxt, st, tid);
             else stage_commit<128>(nxt, st, tid);
+            epilogue2(ob, o, res);
             __syncthreads();
         }
+
     } else {
         stage_issue<128>(a.w3s, st, tid);
 #pragma unroll
@@ -203,10 +306,8 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
         __syncthreads();
     }
 
-    // ---- phase 3: q | k | v of the next layer (12 row blocks) or the final projection (4) ----
-    // (after an even number of stages the first block of W3 is in buf0 in both branches)
-    const int b_of_pt = pt / (a.N + a.M);
-    const int p_of_pt = pt - b_of_pt * (a.N + a.M);
+    // ---- phase 3: q | k | v of the next layer (12 row blocks) or the final projection (4); after an even
+    //      number of stages the first block of W3 is in buf0 in both branches ----
 #pragma unroll
     for (int qb = 0; qb < 12; ++qb) {
         if (qb < n3) {
@@ -215,78 +316,13 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
             const bool more = qb + 1 < n3;
             if (more) stage_issue<128>(a.w3s + (size_t)(qb + 1) * 32 * 256, st, tid);
             f32x16 o;
-            const bool is_v = a.mode3 == 1 && qb >= 8;
-            if (!is_v) {
-                block_mma<8, true>(cur, wrow, hi, xnh, xnl, o);
-                if (a.mode3 == 1) {
-                    // q or k of head qb & 3: [pt][head][plane][32 dims]; this lane's dims 16 t + 8 hi .. + 7
-                    const float sc = qb < 4 ? MDGAT_LOG2E * 0.17677669529663687f : 1.0f;   // log2(e) / sqrt(32) on q
-                    _Float16* dst = (qb < 4 ? a.q16 : a.k16) + ((size_t)pt * 4 + (qb & 3)) * 64 + 8 * hi;
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        float bias[8], v[8];
-                        load8(a.b3 + qb * 32 + 16 * t + 8 * hi, bias);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = (o[8 * t + j] + bias[j]) * sc;
-                        f16x8 h, l;
-                        split8s(v, h, l);
-                        if (pt_ok) {
-                            *reinterpret_cast<f16x8*>(dst + 16 * t) = h;
-                            *reinterpret_cast<f16x8*>(dst + 32 + 16 * t) = l;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        float bias[8], v[8];
-                        const int ch = qb * 32 + 16 * t + 8 * hi;
-                        load8(a.b3 + ch, bias);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = o[8 * t + j] + bias[j];
-                        if (pt_ok) store8(a.mdesc + (size_t)pt * 128 + ch, v);
-                    }
-                }
-            } else {
-                // v of head qb & 3, non-swapped: lane = dim l31, registers = keypoints mfma32_row(r, hi) of this wave
-                block_mma<8, false>(cur, l31, hi, xnh, xnl, o);
-                const int head = qb & 3;
-                const float bias = a.b3[qb * 32 + l31];
-                const int P = a.N + a.M;
-                const int wave_pt0 = blockIdx.x * 128 + wave * 32;
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int p0 = wave_pt0 + 8 * g + 4 * hi;          // 4 consecutive keypoints
-                    if (p0 >= a.R) continue;
-                    const int bb = p0 / P, pp = p0 - bb * P;
-                    _Float16 h[4], l[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
-                    _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + l31) * a.PP;
-                    _Float16* row_l = row_h + (size_t)32 * a.PP;
-                    const bool fast = ((a.N | a.M) & 3) == 0;          // the 4 keypoints share frame and pair, 8-byte aligned
-                    if (fast) {
-                        const int col = pp < a.N ? pp : a.Npad + pp - a.N;
-                        *reinterpret_cast<f16x4*>(row_h + col) = f16x4{h[0], h[1], h[2], h[3]};
-                        *reinterpret_cast<f16x4*>(row_l + col) = f16x4{l[0], l[1], l[2], l[3]};
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int pj = p0 + j;
-                            if (pj >= a.R) break;
-                            const int bj = pj / P, qj = pj - bj * P;
-                            const int col = qj < a.N ? qj : a.Npad + qj - a.N;
-                            _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + l31) * a.PP;
-                            rh[col] = h[j];
-                            rh[(size_t)32 * a.PP + col] = l[j];
-                        }
-                    }
-                }
-            }
+            if (a.mode3 == 1 && qb >= 8) block_mma<8, false>(cur, l31, hi, xnh, xnl, o);
+            else block_mma<8, true>(cur, wrow, hi, xnh, xnl, o);
             if (more) stage_commit<128>(nxt, st, tid);
+            epilogue3(qb, o);
             __syncthreads();
         }
     }
-    (void)b_of_pt; (void)p_of_pt;
 }
 
 // fp32 [rows][K] -> split [rows][2][K] (hi plane | lo plane), once per weight load
@@ -318,7 +354,7 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
     a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP;
     a.do_mlp = p.do_mlp; a.mode3 = p.mode3;
-    const size_t lds = (size_t)2 * STAGE_HALVES * sizeof(_Float16);
+    const size_t lds = (size_t)2 * STAGE_HALVES * sizeof(_Float16) + 768 * sizeof(float);
     static bool attr = false;
     if (!attr) {
         if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel),
