@@ -108,6 +108,24 @@ int mdgat_forward(mdgat_handle* h, int B, int N, int M,
                   float* Z, const mdgat_taps* taps,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* Per-kernel-class timing of mdgat_forward, measured with HIP events on the launch stream (bench.py's
+ * roofline leg).  mdgat_profile(h, enable, ms, launches) returns the time (ms) and launch count
+ * accumulated per class since the previous call in ms[MDGAT_PROF_CLASSES] / launches[...] (either may
+ * be NULL), clears them, and switches the instrumentation on or off.  While it is on, mdgat_forward
+ * ends with a stream synchronisation; an interval covers the launch(es) of the class and the gap
+ * before them. */
+enum {
+    MDGAT_PROF_ENCODER = 0,        /* both encoders up to the summed descriptor */
+    MDGAT_PROF_LAYER = 1,          /* fused mlp + residual + next q/k/v projection (or final_proj) */
+    MDGAT_PROF_ATTENTION_FULL = 2,
+    MDGAT_PROF_ATTENTION_TOPK = 3,
+    MDGAT_PROF_SCORES = 4,         /* score matrix */
+    MDGAT_PROF_SINKHORN = 5,
+    MDGAT_PROF_EXTRACT = 6,
+    MDGAT_PROF_CLASSES = 7
+};
+int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
+
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
 
 /* log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308): scores [B][N][M] -> Z. */

@@ -17,6 +17,8 @@ EXTRACT_DUSTBIN_MUTUAL = 1
 EXTRACT_THRESHOLD = 2
 EXTRACT_THRESHOLD_MUTUAL = 3
 
+PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores', 'sinkhorn', 'extract')
+
 OK = 0
 ERR_BAD_ARG = -1
 ERR_HIP = -2
@@ -49,6 +51,7 @@ SIGNATURES = {
     'mdgat_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'mdgat_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p] * 4 +
                       [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     'mdgat_sinkhorn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     'mdgat_sinkhorn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

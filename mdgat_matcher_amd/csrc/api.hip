@@ -3,6 +3,7 @@
 #include <cstdio>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "common.hpp"
 
@@ -59,6 +60,11 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
+    // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream
+    bool prof_on;
+    std::vector<hipEvent_t> prof_ev;
+    double prof_ms[MDGAT_PROF_CLASSES];
+    long long prof_launches[MDGAT_PROF_CLASSES];
 };
 
 // split-weight buffer: per layer [w1 256x2x256 | w2 128x2x256 | qkv 384x2x128], then final_proj 128x2x128
@@ -85,6 +91,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights = nullptr;
     h->wsplit = nullptr;
     h->loaded = false;
+    h->prof_on = false;
+    for (int c = 0; c < MDGAT_PROF_CLASSES; ++c) { h->prof_ms[c] = 0.0; h->prof_launches[c] = 0; }
     int prev = 0;
     (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
@@ -134,6 +142,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (!h) return;
     if (h->weights) (void)hipFree(h->weights);
     if (h->wsplit) (void)hipFree(h->wsplit);
+    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -210,6 +219,22 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
     const int R = B * P;
     int rc;
 
+    // profiling (off by default): an event after every launch; intervals are attributed to kernel classes after
+    // the forward, which then ends with a stream synchronisation
+    std::vector<int> prof_cls;
+    size_t prof_n = 0;
+    auto mark = [&](int cls) {
+        if (!h->prof_on) return;
+        if (prof_n == h->prof_ev.size()) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) return;
+            h->prof_ev.push_back(e);
+        }
+        (void)hipEventRecord(h->prof_ev[prof_n++], s);
+        prof_cls.push_back(cls);
+    };
+    mark(-1);
+
     // ---- encoders (mdgat.py:392-393) ----
     float* scr = ws.qkv;                 // R*640 floats of scratch (qkv + hid)
     float* hk0 = scr;                    // [R][32]
@@ -227,6 +252,7 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         g.K0 = 128; g.A1 = hk2; g.lda1 = 128;
         if ((rc = launch_gemm(g, s))) return rc;
     }
+    mark(MDGAT_PROF_ENCODER);
     if (taps && taps->x_enc)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
 
@@ -243,18 +269,21 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
+        mark(MDGAT_PROF_LAYER);
     }
     for (int i = 0; i < L2; ++i) {
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
         const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
         if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s))) return rc;
+        mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1;
         p.w1s = ls + WS_W1; p.b1 = lw + bl.mlp1_b; p.w2s = ls + WS_W2; p.b2 = lw + bl.mlp2_b;
         if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
+        mark(MDGAT_PROF_LAYER);
         if (taps && taps->x_layers)
             if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_layers + (size_t)i * R * 128, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_layers"))) return rc;
     }
@@ -270,13 +299,39 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         g.batch = B; g.sA = (long long)P * 128; g.sW = (long long)P * 128; g.sC = (long long)N * M;
         if ((rc = launch_gemm(g, s))) return rc;
     }
+    mark(MDGAT_PROF_SCORES);
     if (taps && taps->scores)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;
 
     // ---- optimal transport (mdgat.py:434-436) and match extraction (441-483) ----
     float* Zout = Z ? Z : ws.Z;
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, s))) return rc;
-    return launch_extract(B, N, M, Zout, h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, s);
+    mark(MDGAT_PROF_SINKHORN);
+    if ((rc = launch_extract(B, N, M, Zout, h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, s))) return rc;
+    mark(MDGAT_PROF_EXTRACT);
+    if (h->prof_on && prof_n > 1) {
+        if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;
+        for (size_t i = 1; i < prof_n; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, h->prof_ev[i - 1], h->prof_ev[i]) == hipSuccess && prof_cls[i] >= 0) {
+                h->prof_ms[prof_cls[i]] += ms;
+                h->prof_launches[prof_cls[i]] += 1;
+            }
+        }
+    }
+    return MDGAT_OK;
+}
+
+extern "C" int mdgat_profile(mdgat_handle* h, int enable, double* ms_out, long long* launches_out) {
+    if (!h) { mdgat_set_error("mdgat_profile: null handle"); return MDGAT_ERR_BAD_ARG; }
+    for (int c = 0; c < MDGAT_PROF_CLASSES; ++c) {
+        if (ms_out) ms_out[c] = h->prof_ms[c];
+        if (launches_out) launches_out[c] = h->prof_launches[c];
+        h->prof_ms[c] = 0.0;
+        h->prof_launches[c] = 0;
+    }
+    h->prof_on = enable != 0;
+    return MDGAT_OK;
 }
 
 // ---------------------------------------------------------------------------------- per-op entry points

@@ -298,6 +298,16 @@ class MDGAT(nn.Module):
             _lib.check(rc, 'mdgat_forward')
         return m0, m1, s0, s1, Z
 
+    def profile(self, device, enable: bool):
+        """Switch the library's per-kernel-class HIP-event timing of the forward on/off for ``device`` and
+        return what was accumulated since the previous call: ``{class: (total_ms, launches)}``."""
+        st = self._state_for(torch.device(device))
+        ms = (C.c_double * len(_lib.PROF_CLASSES))()
+        n = (C.c_longlong * len(_lib.PROF_CLASSES))()
+        with st.lock:
+            _lib.check(_lib.load().mdgat_profile(st.handle, int(bool(enable)), ms, n), 'mdgat_profile')
+        return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
+
     # ------------------------------------------------------------------ match() API
     @torch.no_grad()
     def match(self, kpts0, desc0, kpts1, desc1, scores0=None, scores1=None, return_scores=False):
