@@ -161,34 +161,8 @@ __global__ __launch_bounds__(NW * 64) void sinkhorn_kernel(SkArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
-// Register-resident cluster kernel (N, M <= 512): the pair's score block never leaves the register file.
-//
-// G workgroups (1024 threads = 16 waves each, one per CU, co-resident: cooperative launch) share one pair:
-// workgroup j owns rows [128 j, 128 j + 128), wave w of it 8 of those rows, lane l the 8 contiguous columns
-// 8 l .. 8 l + 7 of each - a lane holds an 8 x 8 block of S (64 VGPRs) for all iterations.
-//   row update   : per row, 8 in-lane terms + a 6-step DPP wave reduction for max and for sum-of-exp2;
-//   column update: per column, in-lane over the wave's 8 rows -> (max, sum) pairs merged across the 16
-//                  waves through LDS -> ONE float per column and workgroup (its local log-sum-exp) is
-//                  exchanged with the G-1 partner workgroups through L2 as 8-byte {epoch, value} granules
-//                  (single relaxed agent-scope 8-byte stores/loads: the data is the flag, no fence; two
-//                  slot sets alternate by epoch parity) and merged with the closed-form dustbin terms.
-// The blockIdx -> (pair group, j) map keeps the G partners on one XCD (blockIdx % 8), a pure speed choice:
-// the protocol is placement independent.  Spins are bounded; a timeout poisons the error word.
-struct SkcArgs {
-    const float* scores;
-    const float* alpha_dev;
-    float alpha_host;
-    float* Z;
-    unsigned long long* slots;   // [ngroups][2][G][SLOT_STRIDE] granules, zeroed before every launch
-    unsigned* error_word;
-    int B, N, M, iters, ngroups;
-};
-
+// helpers of the cluster kernel
 constexpr int SLOT_STRIDE = 520;
-constexpr int CL_WAVES = 8;                 // waves per workgroup (2 per SIMD: 256-VGPR budget)
-constexpr int CL_THREADS = CL_WAVES * 64;
-constexpr int CL_RPW = 128 / CL_WAVES;      // rows per wave
-constexpr int CLUSTER_LDS_FLOATS = 516 + 2 * CL_WAVES * 512 + CL_WAVES + 4;
 
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float dpp_move(float identity, float v) {
@@ -217,16 +191,53 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
-template <int G>
-__global__ __launch_bounds__(CL_THREADS) void sinkhorn_cluster_kernel(SkcArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // CLUSTER_LDS_FLOATS
-    float* v = lds;                       // [M+1] (<= 513), padded to 516
-    float* pm = lds + 516;                // [CL_WAVES][512] per-wave column maxima
-    float* ps = pm + CL_WAVES * 512;      // [CL_WAVES][512] per-wave column sums
-    float* pu = ps + CL_WAVES * 512;      // [CL_WAVES] per-wave LSE of the row potentials
-    float* misc = pu + CL_WAVES;          // [0] = u_N
+// ------------------------------------------------------------------------------------------------
+// Scaling-form cluster kernel (N, M <= 512), the production path.
+//
+// The log-domain iteration of mdgat.py:283-284 is the classical Sinkhorn matrix scaling written for
+// numerical range.  Here the range is handled once: with K_ij = exp2(s_ij + u0_i + v0_j) for absorbed
+// potentials (u0_i = - max(row max, dustbin) at start, v0 = 0) the SAME iteration is
+//      a_i = mu_i / (sum_j K_ij b_j),   b_j = nu_j / (sum_i K_ij a_i),      u = u0 + log2 a,  v = v0 + log2 b
+// i.e. two FMAs per matrix element and iteration instead of two exp2 and eight adds / maxes, and no
+// transcendental in the loop.  Every row of K has its largest entry equal to 1 and the dustbin row /
+// column entries are positive, so no sum can vanish; entries that underflow are < 2^-126 of their
+// row's largest and cannot matter.  When a scaling factor leaves [2^-40, 2^40] it is folded back into
+// K and the absorbed potentials (b: decided on b alone, which is bit-identical in all workgroups of a
+// pair; a: per row, purely local), so any dynamic range the log-domain form handles is handled here.
+//
+// G workgroups (8 waves each, two workgroups per CU) share one pair: workgroup j owns rows [64 j, 64 j + 64),
+// wave w of it 8 of those rows, lane l the columns 8 l .. 8 l + 7: a lane keeps an 8 x 8 block of K (64
+// VGPRs) for all iterations.  Row sums: 8 in-lane FMAs + a DPP wave reduction per row.  Column sums:
+// in-lane over the wave's 8 rows, the 8 waves merged through LDS, the G workgroups through L2 as 8-byte
+// {epoch, value} granules (relaxed agent-scope atomics, the data is the flag, two slot sets alternate by
+// epoch parity; partners sit on one XCD for speed only; bounded spins, a timeout poisons Z with NaN).
+struct SksArgs {
+    const float* scores;
+    const float* alpha_dev;
+    float alpha_host;
+    float* Z;
+    unsigned long long* slots;   // [ngroups][2][G][SLOT_STRIDE] granules, zeroed before every launch
+    unsigned* error_word;
+    int B, N, M, iters, ngroups, G;
+};
 
-    const int N = a.N, M = a.M;
+constexpr int SKS_THREADS = 512;
+constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8;
+
+// RPW = rows per wave: 16 -> 128 rows per workgroup, up to 4 workgroups per pair, one workgroup per CU.
+// Per-row quantities (absorbed potential, dustbin-column entry, scaling a) live in lane r of the wave for
+// row r; the scaling is broadcast for the column pass with v_readlane.  Per-column quantities of the
+// lane's 8 columns live in registers; the thread that finalises column t keeps its own copies.
+template <int RPW>
+__global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArgs a) {
+    constexpr int MAXG = 512 / (8 * RPW);
+    __shared__ __attribute__((aligned(16))) float lds[SKS_LDS_FLOATS];
+    float* bvec = lds;                    // [M+1] column scalings (padded to 520)
+    float* colp = lds + 520;              // [8 waves][512] per-wave column sums
+    float* pdust = colp + 8 * 512;        // [8] per-wave sums of the dustbin column
+    int* flags = reinterpret_cast<int*>(pdust + 8);   // [0]: a column scaling left the safe range
+
+    const int N = a.N, M = a.M, G = a.G;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int group, j;
@@ -240,23 +251,25 @@ __global__ __launch_bounds__(CL_THREADS) void sinkhorn_cluster_kernel(SkcArgs a)
     }
     const float alpha = (a.alpha_dev ? *a.alpha_dev : a.alpha_host) * MDGAT_LOG2E;
     const float norm = -logf((float)(N + M));
-    const float lmu = norm * MDGAT_LOG2E;
-    const float lmuN = (logf((float)M) + norm) * MDGAT_LOG2E;
-    const float lnu = lmu;
-    const float lnuM = (logf((float)N) + norm) * MDGAT_LOG2E;
-    const int row0 = j * 128 + wave * CL_RPW;   // first row of this wave
+    const float mu = 1.0f / (float)(N + M);                    // exp(log_mu) of mdgat.py:302 (rows 0..N-1)
+    const float muN = (float)M / (float)(N + M);               // dustbin row
+    const float nu = mu;                                       // columns 0..M-1 (mdgat.py:303)
+    const float nuM = (float)N / (float)(N + M);               // dustbin column
+    const int row0 = (j * 8 + wave) * RPW;    // first row of this wave
     const int col0 = lane * 8;                // first column of this lane
+    const bool my_row_valid = lane < RPW && row0 + lane < N;   // lane r carries the per-row state of row r
     gu64* slots = (gu64*)(a.slots) + (size_t)group * 2 * G * SLOT_STRIDE;
     unsigned epoch = 0;
     bool failed = false;
+    const float RANGE_HI = 1.099511627776e12f, RANGE_LO = 9.094947017729282e-13f;   // 2^40, 2^-40
 
     for (int pair = group; pair < a.B; pair += a.ngroups) {
         const float* S = a.scores + (size_t)pair * N * M;
-        // ---- the CL_RPW x 8 block of this lane, base-2 log domain (clamped addresses + selects: no branches) ----
-        float s[CL_RPW][8];
+        // ---- this lane's RPW x 8 block of scores (base-2 log units); invalid entries -> exp2 gives 0 ----
+        float K[RPW][8];
         const bool vec_ok = (M & 3) == 0 && col0 + 8 <= M;
 #pragma unroll
-        for (int r = 0; r < CL_RPW; ++r) {
+        for (int r = 0; r < RPW; ++r) {
             const int i = row0 + r;
             const float* row = S + (size_t)min(i, N - 1) * M;
             if (vec_ok) {
@@ -264,170 +277,216 @@ __global__ __launch_bounds__(CL_THREADS) void sinkhorn_cluster_kernel(SkcArgs a)
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + col0 + 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    s[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
-                    s[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
+                    K[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
+                    K[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
                 }
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float x = row[min(col0 + c, M - 1)];
-                    s[r][c] = (i < N && col0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
+                    K[r][c] = (i < N && col0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
                 }
             }
         }
-        __syncthreads();                       // previous pair's readers of v are done
-        for (int t = tid; t <= M; t += CL_THREADS) v[t] = 0.f;
-        if (tid == 0) misc[0] = 0.f;
-        float u[CL_RPW];
+        // ---- absorb the row maximum (dustbin column included): every row of K then has largest entry 1 ----
+        float u0r = 0.f, kbr = 0.f, ar = 0.f;     // lane r: absorbed potential, dustbin-column entry, scaling of row r
 #pragma unroll
-        for (int r = 0; r < CL_RPW; ++r) u[r] = 0.f;
-        __syncthreads();
+        for (int r = 0; r < RPW; ++r) {
+            float m = K[r][0];
+#pragma unroll
+            for (int c = 1; c < 8; ++c) m = fmaxf(m, K[r][c]);
+            m = fmaxf(wave_max_dpp(m), alpha);     // wave-uniform
+            if (lane == r) u0r = -m;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) K[r][c] = ex2(K[r][c] - m);
+        }
+        if (my_row_valid) { kbr = ex2(alpha + u0r); ar = 1.f; } else { u0r = 0.f; }
+        // absorbed dustbin row: u0_N = -alpha, so its entries are exp2(v0_j) = 1
+        float u0N = -alpha, aN = 1.f;
+        float v0[8], kr[8], b[8];         // per lane column: absorbed potential, dustbin-row entry, column scaling
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { v0[c] = 0.f; kr[c] = (col0 + c < M) ? 1.f : 0.f; b[c] = (col0 + c < M) ? 1.f : 0.f; }
+        float v0M = 0.f, kc = 1.f, bM = 1.f;
+        // state of the columns this thread finalises: t = tid (rep 0) and t = tid + 512 (rep 1: only t == M == 512)
+        float krt = 1.f, v0t0 = 0.f, bt0 = 1.f, v0t1 = 0.f, bt1 = 1.f;
+        __syncthreads();                  // previous pair's readers of the LDS vectors are done
+        if (tid == 0) flags[0] = 0;
 
         for (int it = 0; it < a.iters; ++it) {
             ++epoch;
-            // ---- row update (mdgat.py:283) ----
-            float vr[8];
+            // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
+            float psum = 0.f;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) vr[c] = (col0 + c < M) ? v[col0 + c] : 0.f;
-            const float bM = alpha + v[M];
-            if (wave == CL_WAVES - 1) {
-                const float lse = alpha + wave_lse2(v, M, v[M], lane);
-                if (lane == 0) misc[0] = lmuN - lse;
-            }
-            float mx[CL_RPW];
+            for (int r = 0; r < RPW; ++r) {
+                float acc = K[r][0] * b[0];
 #pragma unroll
-            for (int r = 0; r < CL_RPW; ++r) {
-                float m = s[r][0] + vr[0];
-#pragma unroll
-                for (int c = 1; c < 8; ++c) m = fmaxf(m, s[r][c] + vr[c]);
-                mx[r] = m;
-            }
-#pragma unroll
-            for (int r = 0; r < CL_RPW; ++r) mx[r] = fmaxf(wave_max_dpp(mx[r]), bM);
-#pragma unroll
-            for (int c = 0; c < 8; ++c) asm volatile("" : "+v"(vr[c]));   // recompute s + v below: do not keep 128 sums live
-            float ex[CL_RPW];
-#pragma unroll
-            for (int r = 0; r < CL_RPW; ++r) {
-                float e = 0.f;
-#pragma unroll
-                for (int c = 0; c < 8; ++c) e += ex2(s[r][c] + vr[c] - mx[r]);
-                ex[r] = e;
-            }
-#pragma unroll
-            for (int r = 0; r < CL_RPW; ++r) {
-                const float e = wave_sum_dpp(ex[r]) + ex2(bM - mx[r]);
-                u[r] = lmu - (mx[r] + lg2(e));
-            }
-            // ---- column update, wave-local part (mdgat.py:284) ----
-            float cmx[8], csm[8];
-#pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                float m = s[0][c] + u[0];
-#pragma unroll
-                for (int r = 1; r < CL_RPW; ++r) m = fmaxf(m, s[r][c] + u[r]);
-                asm volatile("" : "+v"(m));
-                float e = 0.f;
-#pragma unroll
-                for (int r = 0; r < CL_RPW; ++r) e += ex2(s[r][c] + u[r] - m);
-                cmx[c] = m; csm[c] = e;
+                for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
+                const float tot = wave_sum_dpp(acc);          // wave-uniform
+                psum = (lane == r) ? tot : psum;
             }
             {
-                f32x4* pmw = reinterpret_cast<f32x4*>(pm + wave * 512 + col0);
-                f32x4* psw = reinterpret_cast<f32x4*>(ps + wave * 512 + col0);
-                pmw[0] = f32x4{cmx[0], cmx[1], cmx[2], cmx[3]}; pmw[1] = f32x4{cmx[4], cmx[5], cmx[6], cmx[7]};
-                psw[0] = f32x4{csm[0], csm[1], csm[2], csm[3]}; psw[1] = f32x4{csm[4], csm[5], csm[6], csm[7]};
+                float pd = kr[0] * b[0];
+#pragma unroll
+                for (int c = 1; c < 8; ++c) pd = fmaf(kr[c], b[c], pd);
+                pd = wave_sum_dpp(pd);
+                aN = muN * __builtin_amdgcn_rcpf(fmaf(kc, bM, pd));
             }
-            {   // LSE of this wave's valid row potentials (for the dustbin column)
-                float m = NEG_BIG;
+            ar = my_row_valid ? mu * __builtin_amdgcn_rcpf(fmaf(kbr, bM, psum)) : 0.f;
+            const float dsum = wave_sum_dpp(kbr * ar);
+            // ---- column update, wave-local part (mdgat.py:284): sum_i K_ij a_i over this wave's rows ----
+            float q[8];
 #pragma unroll
-                for (int r = 0; r < CL_RPW; ++r) if (row0 + r < N) m = fmaxf(m, u[r]);
-                float e = 0.f;
+            for (int c = 0; c < 8; ++c) q[c] = 0.f;
 #pragma unroll
-                for (int r = 0; r < CL_RPW; ++r) if (row0 + r < N) e += ex2(u[r] - m);
-                if (lane == 0) pu[wave] = (e > 0.f) ? m + lg2(e) : NEG_BIG;
+            for (int r = 0; r < RPW; ++r) {
+                const float arr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ar), r));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) q[c] = fmaf(K[r][c], arr, q[c]);
+            }
+            {
+                f32x4* qw = reinterpret_cast<f32x4*>(colp + wave * 512 + col0);
+                qw[0] = f32x4{q[0], q[1], q[2], q[3]};
+                qw[1] = f32x4{q[4], q[5], q[6], q[7]};
+                if (lane == 0) pdust[wave] = dsum;
             }
             __syncthreads();
-            // ---- merge the 16 waves, exchange with the partner workgroups, new column potentials ----
-            for (int t = tid; t <= M; t += CL_THREADS) {
-                float loc;
-                if (t < M) {
-                    float m = pm[t];
+            // ---- merge the 8 waves, exchange with the partner workgroups, new column scalings ----
 #pragma unroll
-                    for (int w = 1; w < CL_WAVES; ++w) m = fmaxf(m, pm[w * 512 + t]);
-                    float e = 0.f;
+            for (int rep = 0; rep < 2; ++rep) {
+                const int t = tid + rep * SKS_THREADS;
+                if (t <= M) {
+                    float loc;
+                    if (t < M) {
+                        loc = colp[t];
 #pragma unroll
-                    for (int w = 0; w < CL_WAVES; ++w) e += ps[w * 512 + t] * ex2(pm[w * 512 + t] - m);
-                    loc = m + lg2(e);
-                } else {
-                    float m = pu[0];
+                        for (int w = 1; w < 8; ++w) loc += colp[w * 512 + t];
+                    } else {
+                        loc = pdust[0];
 #pragma unroll
-                    for (int w = 1; w < CL_WAVES; ++w) m = fmaxf(m, pu[w]);
-                    float e = 0.f;
+                        for (int w = 1; w < 8; ++w) loc += pdust[w];
+                    }
+                    float vals[MAXG];
 #pragma unroll
-                    for (int w = 0; w < CL_WAVES; ++w) e += ex2(pu[w] - m);
-                    loc = m + lg2(e);
-                }
-                float vals[G];
-                vals[0] = loc;
-                if (G > 1) {
-                    gu64* mine = slots + ((size_t)(epoch & 1) * G + j) * SLOT_STRIDE + t;
-                    __hip_atomic_store(mine, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, loc),
-                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-                    for (int p = 0; p < G; ++p) {
-                        if (p == j) { vals[p] = loc; continue; }
-                        gu64* theirs = slots + ((size_t)(epoch & 1) * G + p) * SLOT_STRIDE + t;
-                        unsigned long long x = 0;
+                    for (int pp = 0; pp < MAXG; ++pp) vals[pp] = 0.f;
+                    if (G > 1) {
+                        gu64* base = slots + (size_t)(epoch & 1) * G * SLOT_STRIDE + t;
+                        __hip_atomic_store(base + (size_t)j * SLOT_STRIDE, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, loc),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        unsigned pending = ((1u << G) - 1u) & ~(1u << j);
                         unsigned spins = 0;
-                        while (true) {
-                            x = __hip_atomic_load(theirs, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if ((unsigned)(x >> 32) == epoch || failed) break;
-                            if (++spins > (1u << 22)) { failed = true; atomicOr(a.error_word, 1u); break; }
-                            __builtin_amdgcn_s_sleep(2);
+                        while (pending) {
+                            unsigned long long x[MAXG];
+#pragma unroll
+                            for (int pp = 0; pp < MAXG; ++pp)      // all outstanding partners polled concurrently
+                                if (pending & (1u << pp))
+                                    x[pp] = __hip_atomic_load(base + (size_t)pp * SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                            for (int pp = 0; pp < MAXG; ++pp)
+                                if ((pending & (1u << pp)) && (unsigned)(x[pp] >> 32) == epoch) {
+                                    vals[pp] = __builtin_bit_cast(float, (unsigned)x[pp]);
+                                    pending &= ~(1u << pp);
+                                }
+                            if (pending) {
+                                if (failed || ++spins > (1u << 22)) { failed = true; atomicOr(a.error_word, 1u); break; }
+                                __builtin_amdgcn_s_sleep(1);
+                            }
                         }
-                        vals[p] = __builtin_bit_cast(float, (unsigned)x);
+                    }
+                    float total = 0.f;
+#pragma unroll
+                    for (int pp = 0; pp < MAXG; ++pp) total += (pp == j) ? loc : vals[pp];   // fixed order: bit-identical in every partner
+                    float bt;
+                    if (t < M) bt = nu * __builtin_amdgcn_rcpf(fmaf(krt, aN, total));
+                    else bt = nuM * __builtin_amdgcn_rcpf(fmaf(kc, aN, total));
+                    if (rep == 0) bt0 = bt; else bt1 = bt;
+                    bvec[t] = bt;
+                    if (!(bt > RANGE_LO && bt < RANGE_HI)) flags[0] = 1;
+                }
+            }
+            __syncthreads();
+            {
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(bvec + col0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(bvec + col0 + 4);
+                b[0] = x0[0]; b[1] = x0[1]; b[2] = x0[2]; b[3] = x0[3]; b[4] = x1[0]; b[5] = x1[1]; b[6] = x1[2]; b[7] = x1[3];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) if (col0 + c >= M) b[c] = 0.f;
+                bM = bvec[M];
+            }
+            // ---- fold scalings that left [2^-40, 2^40] back into K and the absorbed potentials (rare) ----
+            if (flags[0] != 0) {                   // identical in all partner workgroups (same b everywhere)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    if (col0 + c < M) {
+#pragma unroll
+                        for (int r = 0; r < RPW; ++r) K[r][c] *= b[c];
+                        v0[c] += lg2(b[c]);
+                        kr[c] *= b[c];
+                        b[c] = 1.f;
                     }
                 }
-                const float uN = misc[0];
-                const float extra = (t < M) ? alpha + uN : uN;     // dustbin-row term
-                float m = extra;
-#pragma unroll
-                for (int p = 0; p < G; ++p) m = fmaxf(m, vals[p]);
-                float e = ex2(extra - m);
-#pragma unroll
-                for (int p = 0; p < G; ++p) e += ex2(vals[p] - m);
-                const float lse = m + lg2(e);
-                v[t] = (t < M) ? lnu - lse : lnuM - (alpha + lse);
+                kbr *= bM;
+                kc *= bM;
+                v0M += lg2(bM);
+                bM = 1.f;
+                if (tid < M) { krt *= bt0; v0t0 += lg2(bt0); bt0 = 1.f; }
+                if (tid == M) { v0t0 += lg2(bt0); bt0 = 1.f; }
+                if (tid + SKS_THREADS == M) { v0t1 += lg2(bt1); bt1 = 1.f; }
+                __syncthreads();                   // everyone has read the flag and bvec
+                if (tid == 0) flags[0] = 0;
             }
-            __syncthreads();
+            if (!(aN > RANGE_LO && aN < RANGE_HI)) {      // uniform everywhere: aN is replicated bit-identically
+#pragma unroll
+                for (int c = 0; c < 8; ++c) kr[c] *= aN;
+                krt *= aN;
+                kc *= aN;
+                u0N += lg2(aN);
+                aN = 1.f;
+            }
+            {
+                const bool fold = my_row_valid && !(ar > RANGE_LO && ar < RANGE_HI);
+                const unsigned long long fm = __ballot(fold);        // rows of this wave to fold (purely local)
+                if (fm) {
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        if (fm & (1ull << r)) {
+                            const float arr = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, ar), r));
+#pragma unroll
+                            for (int c = 0; c < 8; ++c) K[r][c] *= arr;
+                        }
+                    }
+                    if (fold) { kbr *= ar; u0r += lg2(ar); ar = 1.f; }
+                }
+            }
         }
 
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units ----
         float* Zp = a.Z + (size_t)pair * (N + 1) * (M + 1);
         const float poison = (G > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                  ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
-        const float vM = v[M] + poison;
-        float vr[8];
+        const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
+        const float VM = ran ? v0M + lg2(bM) + poison : 0.f;
+        const float Ur = (ran && my_row_valid) ? u0r + lg2(ar) : 0.f;    // lane r: potential of row r
+        float V[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) vr[c] = (col0 + c < M) ? v[col0 + c] : 0.f;
+        for (int c = 0; c < 8; ++c) V[c] = (ran && col0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
 #pragma unroll
-        for (int r = 0; r < CL_RPW; ++r) {
+        for (int r = 0; r < RPW; ++r) {
             const int i = row0 + r;
             if (i < N) {
+                const float U = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ur), r));
+                const float* row = S + (size_t)i * M;
                 float* zr = Zp + (size_t)i * (M + 1);
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if (col0 + c < M) zr[col0 + c] = (s[r][c] + u[r] + vr[c]) * MDGAT_LN2 - norm;
-                if (lane == 0) zr[M] = (alpha + u[r] + vM) * MDGAT_LN2 - norm;
+                    if (col0 + c < M) zr[col0 + c] = (row[col0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
+                if (lane == 0) zr[M] = (alpha + U + VM) * MDGAT_LN2 - norm;
             }
         }
         if (j == G - 1) {
-            // dustbin row: u_N from the final column potentials is NOT recomputed by the reference (it is the
-            // value of the last row update), which is what misc[0] still holds
-            const float uN = misc[0];
+            const float UN = ran ? u0N + lg2(aN) : 0.f;
             float* zl = Zp + (size_t)N * (M + 1);
-            for (int t = tid; t <= M; t += CL_THREADS) zl[t] = (alpha + uN + v[t]) * MDGAT_LN2 - norm;
+            if (tid <= M) zl[tid] = (alpha + UN + (ran ? v0t0 + lg2(bt0) + poison : 0.f)) * MDGAT_LN2 - norm;
+            if (tid + SKS_THREADS <= M) zl[tid + SKS_THREADS] = (alpha + UN + (ran ? v0t1 + lg2(bt1) + poison : 0.f)) * MDGAT_LN2 - norm;
         }
     }
 }
@@ -569,36 +628,28 @@ int launch_sk(const SkArgs& a, int B, hipStream_t s) {
 
 size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
     if (N > 512 || M > 512) return 0;
-    return 256 + (size_t)64 * 2 * 4 * SLOT_STRIDE * sizeof(unsigned long long);
+    return 256 + (size_t)64 * 2 * 8 * SLOT_STRIDE * sizeof(unsigned long long);
 }
 
-template <int G>
-static int launch_cluster(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
+static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
                           float* Z, void* ws, int num_cu, hipStream_t s) {
-    int ngroups = num_cu / G;
+    constexpr int RPW = 16;
+    const int G = (N + 8 * RPW - 1) / (8 * RPW);   // workgroups per pair
+    const int occ = RPW == 8 ? 2 : 1;              // resident workgroups per CU by registers
+    int ngroups = (num_cu * occ) / G;
     if (ngroups > 64) ngroups = 64;
     if (ngroups > B) ngroups = B;
     if (ngroups >= 8) ngroups &= ~7;
     if (ngroups < 1) return MDGAT_ERR_UNSUPPORTED;
     const size_t ws_bytes = 256 + (size_t)ngroups * 2 * G * SLOT_STRIDE * sizeof(unsigned long long);
     if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, ws_bytes, s), "memset(sinkhorn slots)")) return rc;
-    SkcArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), B, N, M, iters, ngroups};
-    const size_t lds = CLUSTER_LDS_FLOATS * sizeof(float);
-    static bool attr_set[3] = {false, false, false};
-    const int gi = G == 1 ? 0 : (G == 2 ? 1 : 2);
-    if (!attr_set[gi]) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(sinkhorn_cluster_kernel<G>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
-                                     "sinkhorn cluster LDS attribute"))
-            return rc;
-        attr_set[gi] = true;
-    }
+    SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
+              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, G};
     void* args[] = {&a};
     // cooperative launch: the runtime checks that all ngroups * G workgroups can be co-resident
-    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(sinkhorn_cluster_kernel<G>), dim3(ngroups * G),
-                                              dim3(CL_THREADS), args, (unsigned)lds, s);
-    return mdgat_check_hip(e, "sinkhorn cluster launch");
+    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW>), dim3(ngroups * G),
+                                              dim3(SKS_THREADS), args, 0, s);
+    return mdgat_check_hip(e, "sinkhorn scaling launch");
 }
 
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_cluster_workspace_bytes(B, N, M); }
@@ -612,9 +663,7 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        if (N <= 128) return launch_cluster<1>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
-        if (N <= 256) return launch_cluster<2>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
-        return launch_cluster<4>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
+        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
     }
     // streaming kernel: any shape up to M = 2048, no workspace
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters};
