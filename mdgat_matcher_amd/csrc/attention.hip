@@ -52,16 +52,81 @@ __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) 
     for (int j = 0; j < 8; ++j) l[j] = (_Float16)(p[j] - (float)h[j]);
 }
 
-// Exact k-th largest logit of every row (rows = lane pairs (l, l ^ 32), 16 NBLK registers each).
-// Probe thresholds t, count(s >= t) per row, keep a bracket lo < thr <= hv with counts clo > k > chi.
-// The first probe is the normal quantile of the row (mean + zq * sd); later probes step by
+// How the two lanes of a row (and, in the split-key kernel, the two waves of a row) combine per-row
+// partial results.  WaveComm: the row lives in one wave (lanes l, l ^ 32).
+struct WaveComm {
+    __device__ __forceinline__ float rsum(float v) { return v + xor32(v); }
+    __device__ __forceinline__ int rsum(int v) { return v + xor32i(v); }
+    __device__ __forceinline__ float rmin(float v) { return fminf(v, xor32(v)); }
+    __device__ __forceinline__ float rmax(float v) { return fmaxf(v, xor32(v)); }
+    __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) {
+        mn = fminf(mn, xor32(mn)); sum += xor32(sum); sq += xor32(sq);
+    }
+    // row count + "is any row of the voting domain still probing" in one step
+    __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
+        any_probing = __any(probing);
+        return c + xor32i(c);
+    }
+};
+// SplitComm: the keys of a row are split over waves w and w ^ 4 of an 8-wave workgroup (same lane = same
+// query).  Partials cross through a double-buffered LDS slot with ONE barrier per exchange; every wave of the
+// workgroup makes the same sequence of calls (the search below is lockstep by construction).
+struct SplitComm {
+    float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
+    int wave, lane, par;
+    __device__ __forceinline__ float exch(float v) {
+        float* b = buf + par * 512;
+        b[wave * 64 + lane] = v;
+        __syncthreads();
+        const float o = b[(wave ^ 4) * 64 + lane];
+        par ^= 1;
+        return o;
+    }
+    __device__ __forceinline__ float rsum(float v) { v += xor32(v); return v + exch(v); }
+    __device__ __forceinline__ int rsum(int v) { v += xor32i(v); return v + __builtin_bit_cast(int, exch(__builtin_bit_cast(float, v))); }
+    __device__ __forceinline__ float rmin(float v) { v = fminf(v, xor32(v)); return fminf(v, exch(v)); }
+    __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, xor32(v)); return fmaxf(v, exch(v)); }
+    __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p) != 0; }
+    __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) {
+        mn = fminf(mn, xor32(mn)); sum += xor32(sum); sq += xor32(sq);
+        float* b0 = buf + par * 512;          // three values per lane pair: lanes < 32 carry (mn, sum), lanes >= 32 carry sq
+        float* b1 = buf + (par ^ 1) * 512;    // (both slots: once per row, followed by a second barrier)
+        b0[wave * 64 + lane] = lane < 32 ? mn : sq;
+        b1[wave * 64 + lane] = sum;
+        __syncthreads();
+        const int o = (wave ^ 4) * 64;
+        mn = fminf(mn, b0[o + (lane & 31)]);
+        sq += b0[o + 32 + (lane & 31)];
+        sum += b1[o + lane];
+        __syncthreads();
+    }
+    __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
+        c += xor32i(c);
+        float* b = buf + par * 512;
+        b[wave * 64 + lane] = __builtin_bit_cast(float, c);
+        if (lane == 0) reinterpret_cast<int*>(buf)[1024 + par * 8 + wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (probing) reinterpret_cast<int*>(buf)[1024 + par * 8 + wave] = 1;
+        __syncthreads();
+        const int* f = reinterpret_cast<const int*>(buf) + 1024 + par * 8;
+        any_probing = (f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7]) != 0;
+        const int o = __builtin_bit_cast(int, b[(wave ^ 4) * 64 + lane]);
+        par ^= 1;
+        return c + o;
+    }
+};
+
+// Exact k-th largest logit of every row (this wave holds 16 NBLK logits of the row per lane; Comm combines
+// the partials of a row).  Probe thresholds t, count(s >= t) per row, keep a bracket lo < thr <= hv with counts
+// clo > k > chi.  The first probe is the normal quantile of the row (mean + zq * sd); later probes step by
 // (count - k) / density with the normal density at the probe, falling back to interpolation inside the
 // bracket and to its midpoint.  A row stops probing when count == k, when no float lies strictly inside
 // the bracket (exact ties at the k-th value: all kept), or when it is one element away from k on either
 // side; those rows are finished by direct order-statistic passes after the loop (max below hv / second
-// smallest at or above lo).  All rows of a wave run in lockstep, so the loop ends with its slowest row.
-template <int NBLK, bool EXACT>
-__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq) {
+// smallest at or above lo).  All rows run in lockstep, so the loop ends with its slowest row.
+template <int NBLK, bool EXACT, typename Comm>
+__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
     const float INF = __builtin_inff();
     float smin = INF, sum = 0.f, sq = 0.f;
 #pragma unroll
@@ -74,21 +139,33 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
             sum += s;
             sq = fmaf(s, s, sq);
         }
-    smin = fminf(smin, xor32(smin));
-    sum += xor32(sum);
-    sq += xor32(sq);
+    comm.stats(smin, sum, sq);
     const float inv_n = 1.0f / (float)nk;
     const float mu = sum * inv_n;
     const float sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
     const float inv_sd = 1.0f / sd;
-    auto count_ge = [&](float t) {
-        int c = 0;
+    // count(s >= t) without the VCC-serialised compare/add-carry chain: the sign bits of s - t are shifted into
+    // four independent accumulators (v_alignbit) and counted 32 at a time (v_bcnt)
+    auto count_local = [&](float t) {
+        int below = 0;
+        unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
 #pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb)
+        for (int jb = 0; jb < NBLK; ++jb) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) c += (S[jb][r] >= t) ? 1 : 0;
-        return c + xor32i(c);
+            for (int r = 0; r < 16; r += 4) {
+                acc0 = __builtin_amdgcn_alignbit(acc0, __builtin_bit_cast(unsigned, S[jb][r + 0] - t), 31);
+                acc1 = __builtin_amdgcn_alignbit(acc1, __builtin_bit_cast(unsigned, S[jb][r + 1] - t), 31);
+                acc2 = __builtin_amdgcn_alignbit(acc2, __builtin_bit_cast(unsigned, S[jb][r + 2] - t), 31);
+                acc3 = __builtin_amdgcn_alignbit(acc3, __builtin_bit_cast(unsigned, S[jb][r + 3] - t), 31);
+            }
+            if ((jb & 7) == 7 || jb == NBLK - 1) {     // 4 x 32 sign bits collected
+                below += __builtin_popcount(acc0) + __builtin_popcount(acc1) + __builtin_popcount(acc2) + __builtin_popcount(acc3);
+                acc0 = acc1 = acc2 = acc3 = 0;
+            }
+        }
+        return 16 * NBLK - below;                     // s - t < 0 (sign set) <=> s < t; -inf pads count as below
     };
+    auto count_ge = [&](float t) { return comm.rsum(count_local(t)); };
     float thr = -INF;
     float lo = smin, hv = m;
     int clo = nk, chi = count_ge(m);
@@ -100,13 +177,14 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     if (state == 0 && clo - k == 1) state = 3;
     float t = mu + zq * sd;
     for (int it = 0; it < 64; ++it) {
-        if (__all(state != 0)) break;
         if (!(t > lo && t < hv)) {
             t = lo + (hv - lo) * (((float)(clo - k) + 0.5f) / (float)(clo - chi));
             if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
         }
         const bool collapsed = !(t > lo && t < hv);   // no float strictly inside the bracket
-        const int c = count_ge(t);
+        bool any_probing;
+        const int c = comm.count_vote(count_local(t), state == 0, any_probing);   // one exchange per probe
+        if (!any_probing) break;                       // every row had finished before this probe
         if (state == 0) {
             if (collapsed) { thr = lo; state = 1; }            // ties at the k-th value: keep them all
             else if (c == k) { thr = t; state = 1; }
@@ -124,30 +202,31 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         }
     }
     if (state == 0) { thr = lo; state = 1; }
-    if (__any(state == 2)) {      // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
+    if (comm.any(state == 2)) {   // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
         float mx = -INF;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; mx = fmaxf(mx, s < hv ? s : -INF); }
-        mx = fmaxf(mx, xor32(mx));
+        mx = comm.rmax(mx);
         if (state == 2) thr = mx;
     }
-    if (__any(state == 3)) {      // k + 1 logits are >= lo: drop the smallest of them
+    if (comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
         float e1 = INF;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e1 = fminf(e1, s >= lo ? s : INF); }
-        e1 = fminf(e1, xor32(e1));
+        e1 = comm.rmin(e1);
         float e2 = INF;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e2 = fminf(e2, s > e1 ? s : INF); }
-        e2 = fminf(e2, xor32(e2));
+        e2 = comm.rmin(e2);
         // (if the smallest is tied, dropping "it" is ambiguous: keep the ties, thr = e1)
-        if (state == 3) thr = (count_ge(e2) >= k) ? e2 : e1;
+        const int c2 = count_ge(e2);
+        if (state == 3) thr = (c2 >= k) ? e2 : e1;
     }
     return thr;
 }
@@ -292,7 +371,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
             // ---- exact top-k threshold (dynamic layers: the chunk is the whole row) ----
             float thr = NEG_INF;
-            if (TOPK) thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq);
+            if (TOPK) { WaveComm comm; thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm); }
 
             if (!TOPK && c0 > 0) {
                 // online softmax: bring the running sum and output to the new maximum
@@ -351,6 +430,163 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
             const int q = qw + row;
             if (q < nq) out[(size_t)q * 128] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]) * inv;
         }
+    }
+}
+
+// Dynamic attention for exactly 512 keys per frame with TWO waves per query tile: waves w and w + 4 of an
+// 8-wave workgroup serve the same 32 queries, wave w keys [0, 256), wave w + 4 keys [256, 512).  Each keeps
+// its half row in 128 registers (two waves per SIMD instead of one wave with 256 registers spread over the
+// VGPR / AGPR halves); row maximum, top-k counts (SplitComm), the row sum and the output partials cross
+// through LDS.
+__global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a) {
+    constexpr int NBLK = 8;
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qgroup = wave & 3, khalf = wave >> 2;
+    const int head = blockIdx.y;
+    const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int P = a.N + a.M;
+    const int nq = side ? a.M : a.N;
+    const int q_off = side ? a.N : 0;
+    const int src = a.cross ? (1 - side) : side;
+    const int nk = 512;
+    const int k_off = src ? a.N : 0;
+    constexpr int VSTR = 512 + 8;
+
+    _Float16* Ks = smem;                          // [512][KROWH]
+    _Float16* Vs = smem + 512 * KROWH;            // [2 planes][32 dims][VSTR]
+    float* xbuf = reinterpret_cast<float*>(Vs + 64 * VSTR);   // SplitComm: 1040 floats
+    float* obuf = xbuf + 1040;                    // [4 query groups][17][64]: output partials and row sums of the upper key half
+
+    {
+        const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
+        for (int base = tid; base < 512 * 8; base += 4 * 512) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 512;
+                x[u] = *reinterpret_cast<const f32x4*>(kg + (size_t)(idx >> 3) * 256 + (idx & 7) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 512;
+                *reinterpret_cast<f32x4*>(Ks + (idx >> 3) * KROWH + (idx & 7) * 8) = x[u];
+            }
+        }
+        const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
+        for (int base = tid; base < 64 * 64; base += 4 * 512) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 512;
+                x[u] = *reinterpret_cast<const f32x4*>(vg + (size_t)(idx >> 6) * a.PP + (idx & 63) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int idx = base + u * 512;
+                *reinterpret_cast<f32x4*>(Vs + (idx >> 6) * VSTR + (idx & 63) * 8) = x[u];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2 <-> 3
+    SplitComm comm{xbuf, wave, lane, 0};
+    const int npass = (nq + 127) / 128;       // every wave runs every pass (barriers inside)
+
+    for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        const int qw = pass * 128 + qgroup * 32;
+        f16x8 qh[2], ql[2];
+        {
+            const int qrow = min(qw + l31, nq - 1);
+            const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * hi;
+            qh[0] = *reinterpret_cast<const f16x8*>(p);
+            qh[1] = *reinterpret_cast<const f16x8*>(p + 16);
+            ql[0] = *reinterpret_cast<const f16x8*>(p + 32);
+            ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
+        }
+        f32x16 S[NBLK];
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+            const _Float16* kp = Ks + ((khalf * NBLK + jb) * 32 + krow) * KROWH + 8 * hi;
+            const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
+            const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
+            const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
+            const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
+            f32x16 acc, acx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+            S[jb] = acc;
+        }
+        float m = -__builtin_inff();
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
+        m = comm.rmax(m);
+        const float thr = topk_threshold<NBLK, true>(S, m, a.topk, nk, a.zq, comm);
+
+        const float m11 = m - 11.0f;
+        float l = 0.f;
+        f32x16 Om, Ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float s = S[jb][8 * t + j];
+                    float e = __builtin_amdgcn_exp2f(s - m11);
+                    e = (s >= thr) ? e : 0.f;
+                    p[j] = e;
+                    l += e;
+                }
+                f16x8 ph, pl;
+                split8(p, ph, pl);
+                const _Float16* vp = Vs + l31 * VSTR + (khalf * NBLK + jb) * 32 + t * 16 + 8 * hi;
+                const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
+                const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
+                Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+            }
+        }
+        l += xor32(l);
+        // ---- the upper key half hands its partial output and row sum to the lower half ----
+        float* ob = obuf + qgroup * 17 * 64;
+        if (khalf == 1) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]);
+            ob[16 * 64 + lane] = l;
+        }
+        __syncthreads();
+        if (khalf == 0 && qw < nq) {
+            const float inv_l = 1.0f / (l + ob[16 * 64 + lane]);
+            float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, hi);
+                const float inv = __shfl(inv_l, row, 64);
+                const int q = qw + row;
+                const float o = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]) + ob[r * 64 + lane];
+                if (q < nq) out[(size_t)q * 128] = o * inv;
+            }
+        }
+        __syncthreads();     // obuf is reused by the next pass
     }
 }
 
@@ -466,7 +702,15 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
         // the whole row in one chunk
         if (nblk <= 4) go(attention_kernel<true, 4, false>, 512);
         else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true>, 512); else go(attention_kernel<true, 8, false>, 512); }
-        else { if (mult32 && N == 512 && M == 512) go(attention_kernel<true, 16, true>, 256); else go(attention_kernel<true, 16, false>, 256); }
+        else if (N == 512 && M == 512) {
+            // 512 keys in both frames: the split-key kernel (two waves per query tile)
+            const size_t lds2 = ((size_t)512 * KROWH + (size_t)64 * 520) * sizeof(_Float16) + (1040 + 4 * 17 * 64) * sizeof(float);
+            int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
+            if (qsplit > 4) qsplit = 4;
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk_split_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
+            hipLaunchKernelGGL(attention_topk_split_kernel, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds2, s, a);
+        } else go(attention_kernel<true, 16, false>, 256);
     } else {
         // chunks of 8 blocks (256 keys), two waves per SIMD
         if (nblk <= 4) go(attention_kernel<false, 4, false>, 512);
