@@ -29,7 +29,6 @@
 namespace {
 
 constexpr int KROWH = 72;   // K row in LDS, halves: 32 hi | 32 lo | 8 pad (144 B = 9 x 16 B: conflict free)
-constexpr int MAXBLK = 16;  // 16 x 32 = 512 keys
 
 struct AttnArgs {
     const _Float16* q16;   // [B][P][4][2][32]   pre-scaled by log2(e)/sqrt(32)
@@ -235,9 +234,12 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
 //         with an online softmax (running max / sum, the output rescaled between chunks), dynamic
 //         attention needs the whole row at once and therefore a single chunk.
 // EXACT = the key count is a multiple of 32 NBLK: no per-block conditions, one basic block per chunk.
+// LARGE = more than 512 keys (full attention only): LDS holds a window of 512 keys that is re-staged for
+//         every query pass; the online softmax carries across windows.
 // Threads: 512 (two waves per SIMD, <= 256 registers) for NBLK <= 8, else 256 (one wave per SIMD).
-template <bool TOPK, int NBLK, bool EXACT>
+template <bool TOPK, int NBLK, bool EXACT, bool LARGE>
 __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnArgs a) {
+    static_assert(!(TOPK && LARGE), "dynamic attention needs the whole row in one chunk");
     constexpr int NT = NBLK <= 8 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
@@ -252,18 +254,19 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
     const int src = a.cross ? (1 - side) : side;
     const int nk = src ? a.M : a.N;
     const int k_off = src ? a.N : 0;
-    const int nblk = (nk + 31) >> 5;
-    const int nkp = nblk * 32;
-    const int VSTR = nkp + 8;               // V^T row stride in halves: (nkp + 8) / 8 is odd -> conflict free
+    const int nblk = (nk + 31) >> 5;                    // all blocks of the row
+    const int wcap = LARGE ? 16 : nblk;                 // blocks the LDS window holds
+    const int VSTR = wcap * 32 + 8;         // V^T row stride in halves: (32 wcap + 8) / 8 is odd -> conflict free
 
-    _Float16* Ks = smem;                    // [nkp][KROWH]
-    _Float16* Vs = smem + nkp * KROWH;      // [2 planes][32 dims][VSTR]
+    _Float16* Ks = smem;                    // [32 wcap][KROWH]
+    _Float16* Vs = smem + wcap * 32 * KROWH;   // [2 planes][32 dims][VSTR]
 
-    // ---- stage K (128 contiguous bytes per key) and V^T (nkp contiguous halves per (plane, dim)),
-    //      four 16-byte loads in flight per thread ----
-    {
-        const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
-        const int nk8 = nkp * 8;
+    // ---- stage K (128 contiguous bytes per key) and V^T (contiguous halves per (plane, dim)) of the blocks
+    //      [wb0, wb0 + wnb), four 16-byte loads in flight per thread ----
+    auto stage = [&](int wb0, int wnb) {
+        const _Float16* kg = a.k16 + (((size_t)b * P + k_off + wb0 * 32) * 4 + head) * 64;
+        const int nk8 = wnb * 32 * 8;
+        const int krem = nk - wb0 * 32;     // valid keys from the window start
         for (int base = tid; base < nk8; base += 4 * NT) {
             f32x4 x[4];
 #pragma unroll
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 const int idx = base + u * NT;
                 const int row = idx >> 3, c = idx & 7;
                 x[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (idx < nk8 && row < nk) x[u] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * 256 + c * 8);
+                if (idx < nk8 && row < krem) x[u] = *reinterpret_cast<const f32x4*>(kg + (size_t)row * 256 + c * 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -279,8 +282,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 if (idx < nk8) *reinterpret_cast<f32x4*>(Ks + (idx >> 3) * KROWH + (idx & 7) * 8) = x[u];
             }
         }
-        const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
-        const int cpr = nblk * 4;           // 16-byte chunks per row
+        const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0) + wb0 * 32;
+        const int cpr = wnb * 4;            // 16-byte chunks per row
         const int nv = 64 * cpr;
         for (int base = tid; base < nv; base += 4 * NT) {
             f32x4 x[4];
@@ -297,8 +300,11 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 if (idx < nv) *reinterpret_cast<f32x4*>(Vs + row * VSTR + c * 8) = x[u];
             }
         }
+    };
+    if (!LARGE) {
+        stage(0, nblk);
+        __syncthreads();
     }
-    __syncthreads();
 
     const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2 <-> 3
     const float NEG_INF = -__builtin_inff();
@@ -309,7 +315,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
     for (int q0 = blockIdx.x * QT; q0 < nq; q0 += gridDim.x * QT) {
         const int qw = q0 + wave * 32;
-        if (qw >= nq) continue;             // wave-uniform; no barrier inside the loop
+        if (!LARGE && qw >= nq) continue;   // wave-uniform; no barrier inside the loop (LARGE: barriers, every wave stays)
 
         // ---- this lane's query fragments: dims 16 t + 8 hi + j of query l31, planes hi / lo ----
         f16x8 qh[2], ql[2];
@@ -327,93 +333,101 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
 
-        for (int c0 = 0; c0 < nblk; c0 += NBLK) {
-            // ---- S^T = K Q^T for the NBLK blocks of this chunk, resident in registers ----
-            f32x16 S[NBLK];
-#pragma unroll
-            for (int jb = 0; jb < NBLK; ++jb) {
-                if (EXACT || c0 + jb < nblk) {
-                    const _Float16* kp = Ks + ((c0 + jb) * 32 + krow) * KROWH + 8 * hi;
-                    const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
-                    const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
-                    const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
-                    const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                    f32x16 acc, acx;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
-                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
-                    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
-                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
-                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
-                    acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
-                    if (!EXACT && last_partial && c0 + jb == nblk - 1) {   // wave-uniform
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            if (16 * (r >> 3) + (r & 7) >= last_lim) acc[r] = NEG_INF;
-                    }
-                    S[jb] = acc;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
-                }
+        for (int wb0 = 0; wb0 < nblk; wb0 += wcap) {            // LDS windows (one unless LARGE)
+            const int wnb = min(wcap, nblk - wb0);
+            if (LARGE) {
+                __syncthreads();            // the previous window has been consumed by every wave
+                stage(wb0, wnb);
+                __syncthreads();
             }
-
-            // ---- chunk max, running max ----
-            float m = NEG_INF;
+            for (int c0 = 0; c0 < wnb; c0 += NBLK) {
+                // ---- S^T = K Q^T for the NBLK blocks of this chunk, resident in registers ----
+                f32x16 S[NBLK];
 #pragma unroll
-            for (int jb = 0; jb < NBLK; ++jb)
+                for (int jb = 0; jb < NBLK; ++jb) {
+                    if (EXACT || c0 + jb < wnb) {
+                        const _Float16* kp = Ks + ((c0 + jb) * 32 + krow) * KROWH + 8 * hi;
+                        const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
+                        const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
+                        const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
+                        const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
+                        f32x16 acc, acx;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
-            m = fmaxf(m, xor32(m));
-
-            // ---- exact top-k threshold (dynamic layers: the chunk is the whole row) ----
-            float thr = NEG_INF;
-            if (TOPK) { WaveComm comm; thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm); }
-
-            if (!TOPK && c0 > 0) {
-                // online softmax: bring the running sum and output to the new maximum
-                const float m_new = fmaxf(m_run, m);
-                const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
-                m = m_new;
-                if (!__all(sc == 1.0f)) {
-                    l *= sc;
+                        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
-                        Om[r] *= f;
-                        Ox[r] *= f;
-                    }
-                }
-            }
-            m_run = m;
-
-            // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
-            const float m11 = m - 11.0f;
+                        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+                        if (!EXACT && last_partial && wb0 + c0 + jb == nblk - 1) {   // wave-uniform
 #pragma unroll
-            for (int jb = 0; jb < NBLK; ++jb) {
-                if (EXACT || c0 + jb < nblk) {
-#pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        float p[8];
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float s = S[jb][8 * t + j];
-                            float e = __builtin_amdgcn_exp2f(s - m11);
-                            if (TOPK) e = (s >= thr) ? e : 0.f;
-                            p[j] = e;
-                            l += e;
+                            for (int r = 0; r < 16; ++r)
+                                if (16 * (r >> 3) + (r & 7) >= last_lim) acc[r] = NEG_INF;
                         }
-                        f16x8 ph, pl;
-                        split8(p, ph, pl);
-                        const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
-                        const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
-                        const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
-                        Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
-                        Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
-                        Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                        S[jb] = acc;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
+                    }
+                }
+
+                // ---- chunk max, running max ----
+                float m = NEG_INF;
+#pragma unroll
+                for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
+                m = fmaxf(m, xor32(m));
+
+                // ---- exact top-k threshold (dynamic layers: the chunk is the whole row) ----
+                float thr = NEG_INF;
+                if (TOPK) { WaveComm comm; thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm); }
+
+                if (!TOPK && (wb0 + c0) > 0) {
+                    // online softmax: bring the running sum and output to the new maximum
+                    const float m_new = fmaxf(m_run, m);
+                    const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+                    m = m_new;
+                    if (!__all(sc == 1.0f)) {
+                        l *= sc;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
+                            Om[r] *= f;
+                            Ox[r] *= f;
+                        }
+                    }
+                }
+                m_run = m;
+
+                // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
+                const float m11 = m - 11.0f;
+#pragma unroll
+                for (int jb = 0; jb < NBLK; ++jb) {
+                    if (EXACT || c0 + jb < wnb) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            float p[8];
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float s = S[jb][8 * t + j];
+                                float e = __builtin_amdgcn_exp2f(s - m11);
+                                if (TOPK) e = (s >= thr) ? e : 0.f;
+                                p[j] = e;
+                                l += e;
+                            }
+                            f16x8 ph, pl;
+                            split8(p, ph, pl);
+                            const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
+                            const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
+                            const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
+                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                            Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -590,6 +604,205 @@ __global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a
     }
 }
 
+// WideComm: the keys of a row are spread over NW consecutive waves of an 8-wave workgroup (same lane = same
+// query).  Same protocol as SplitComm: one barrier per exchange, every wave makes the same calls.
+template <int NW>
+struct WideComm {
+    float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
+    int wave, lane, par;
+    template <typename Op>
+    __device__ __forceinline__ float exch(float v, Op op) {
+        float* b = buf + par * 512;
+        b[wave * 64 + lane] = v;
+        __syncthreads();
+        const int g0 = (wave / NW) * NW;
+        float r = b[g0 * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) r = op(r, b[(g0 + w) * 64 + lane]);
+        par ^= 1;
+        return r;
+    }
+    __device__ __forceinline__ float rsum(float v) { v += xor32(v); return exch(v, [](float x, float y) { return x + y; }); }
+    __device__ __forceinline__ int rsum(int v) {
+        v += xor32i(v);
+        return __builtin_bit_cast(int, exch(__builtin_bit_cast(float, v), [](float x, float y) {
+            return __builtin_bit_cast(float, __builtin_bit_cast(int, x) + __builtin_bit_cast(int, y)); }));
+    }
+    __device__ __forceinline__ float rmin(float v) { v = fminf(v, xor32(v)); return exch(v, [](float x, float y) { return fminf(x, y); }); }
+    __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, xor32(v)); return exch(v, [](float x, float y) { return fmaxf(x, y); }); }
+    __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p) != 0; }
+    __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) { mn = rmin(mn); sum = rsum(sum); sq = rsum(sq); }
+    __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
+        int* flags = reinterpret_cast<int*>(buf) + 1024 + par * 8;
+        if (lane == 0) flags[wave] = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (probing) flags[wave] = 1;
+        const int r = rsum(c);                      // contains the barrier; `par` has flipped afterwards
+        any_probing = (flags[0] | flags[1] | flags[2] | flags[3] | flags[4] | flags[5] | flags[6] | flags[7]) != 0;
+        return r;
+    }
+};
+
+// Dynamic attention for more than 512 keys per frame (up to 256 NW): NW waves share a 32-query tile, wave
+// kw of the tile keeps the logits of keys [256 kw, 256 kw + 256) in 128 registers.  Nothing is shared between
+// the waves except per-row scalars, so K and V^T fragments come straight from global memory (L2) instead of LDS.
+template <int NW>
+__global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a) {
+    constexpr int NBLK = 8;
+    constexpr int NG = 8 / NW;                // query tiles per workgroup pass
+    extern __shared__ __attribute__((aligned(16))) float fsm[];
+    float* xbuf = fsm;                        // WideComm: 1040 floats
+    float* obuf = fsm + 1040;                 // [8 waves][17][64] output partials and row sums
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int qgroup = wave / NW, kw = wave % NW;
+    const int head = blockIdx.y;
+    const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int P = a.N + a.M;
+    const int nq = side ? a.M : a.N;
+    const int q_off = side ? a.N : 0;
+    const int src = a.cross ? (1 - side) : side;
+    const int nk = src ? a.M : a.N;
+    const int k_off = src ? a.N : 0;
+    const int nblk = (nk + 31) >> 5;
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2 <-> 3
+    const float NEG_INF = -__builtin_inff();
+    const int last_lim = nk - (nblk - 1) * 32 - 8 * hi;
+    const bool last_partial = (nk & 31) != 0;
+    const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64 + 8 * hi;
+    const _Float16* vg = a.vt16 + (((size_t)b * 4 + head) * 64 + l31) * a.PP + (src ? a.Npad : 0) + 8 * hi;
+    WideComm<NW> comm{xbuf, wave, lane, 0};
+    const int npass = (nq + 32 * NG - 1) / (32 * NG);
+
+    for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+        const int qw = (pass * NG + qgroup) * 32;
+        f16x8 qh[2], ql[2];
+        {
+            const int qrow = min(qw + l31, nq - 1);
+            const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * hi;
+            qh[0] = *reinterpret_cast<const f16x8*>(p);
+            qh[1] = *reinterpret_cast<const f16x8*>(p + 16);
+            ql[0] = *reinterpret_cast<const f16x8*>(p + 32);
+            ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
+        }
+        f32x16 S[NBLK];
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+            const int gb = kw * NBLK + jb;
+            if (gb < nblk) {
+                const int key = min(gb * 32 + krow, nk - 1);      // rows past the end: any finite data, masked below
+                const _Float16* kp = kg + (size_t)key * 256;
+                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
+                const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
+                const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
+                const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
+                f32x16 acc, acx;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+                if (last_partial && gb == nblk - 1) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (16 * (r >> 3) + (r & 7) >= last_lim) acc[r] = NEG_INF;
+                }
+                S[jb] = acc;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
+            }
+        }
+        float m = NEG_INF;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
+        m = comm.rmax(m);
+        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
+
+        const float m11 = m - 11.0f;
+        float l = 0.f;
+        f32x16 Om, Ox;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+            const int gb = kw * NBLK + jb;
+            if (gb < nblk) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    float p[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float s = S[jb][8 * t + j];
+                        float e = __builtin_amdgcn_exp2f(s - m11);
+                        e = (s >= thr) ? e : 0.f;
+                        p[j] = e;
+                        l += e;
+                    }
+                    f16x8 ph, pl;
+                    split8(p, ph, pl);
+                    const _Float16* vp = vg + gb * 32 + t * 16;
+                    const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
+                    const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
+                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                    Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                }
+            }
+        }
+        l += xor32(l);
+        float* ob = obuf + wave * 17 * 64;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]);
+        ob[16 * 64 + lane] = l;
+        __syncthreads();
+        if (kw == 0 && qw < nq) {
+            float lt = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) lt += obuf[(qgroup * NW + w) * 17 * 64 + 16 * 64 + lane];
+            const float inv_l = 1.0f / lt;
+            float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = mfma32_row(r, hi);
+                const float inv = __shfl(inv_l, row, 64);
+                const int q = qw + row;
+                float o = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) o += obuf[(qgroup * NW + w) * 17 * 64 + r * 64 + lane];
+                if (q < nq) out[(size_t)q * 128] = o * inv;
+            }
+        }
+        __syncthreads();     // obuf is reused by the next pass
+    }
+}
+
+static int launch_attention_topk_wide(const AttnArgs& a, int B, int nk_max, hipStream_t s) {
+    const int nblk = (nk_max + 31) / 32;
+    if (nblk > 64) {
+        mdgat_set_error("dynamic attention: %d keys per frame > 2048 supported", nk_max);
+        return MDGAT_ERR_UNSUPPORTED;
+    }
+    const size_t lds = (size_t)(1040 + 8 * 17 * 64) * sizeof(float);
+    if (nblk <= 32) {
+        const int npass = (nk_max + 63) / 64;
+        hipLaunchKernelGGL(attention_topk_wide_kernel<4>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+    } else {
+        const int npass = (nk_max + 31) / 32;
+        hipLaunchKernelGGL(attention_topk_wide_kernel<8>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+    }
+    return mdgat_check_hip(hipGetLastError(), "wide dynamic attention launch");
+}
+
 // fp32 q/k/v [B][P][3][4][32] -> the split-f16 operand layouts above (per-op entry point and tests; the
 // forward's q/k/v projection writes these layouts directly from its epilogue)
 __global__ __launch_bounds__(256) void qkv_split_kernel(const float* qkv, _Float16* q16, _Float16* k16, _Float16* vt16,
@@ -667,10 +880,6 @@ static float normal_quantile_upper(double p) {
 int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
-    if (nk_max > MAXBLK * 32) {
-        mdgat_set_error("attention: %d keys > %d supported by the LDS-resident kernel", nk_max, MAXBLK * 32);
-        return MDGAT_ERR_UNSUPPORTED;
-    }
     if (topk > 0) {
         // torch.topk raises when k exceeds the number of keys of either direction (mdgat.py:202)
         const int nk_min = N < M ? N : M;
@@ -682,7 +891,8 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f};
     if (topk > 0) a.zq = normal_quantile_upper(((double)topk - 0.5) / (double)nk_max);
     const int nkp = ((nk_max + 31) / 32) * 32;
-    const size_t lds = ((size_t)nkp * KROWH + (size_t)64 * (nkp + 8)) * sizeof(_Float16);
+    const int wkeys = nkp > 512 ? 512 : nkp;      // keys the LDS window holds
+    const size_t lds = ((size_t)wkeys * KROWH + (size_t)64 * (wkeys + 8)) * sizeof(_Float16);
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     const int nblk = nkp / 32;
@@ -694,14 +904,15 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
         int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
         if (qsplit > qtiles) qsplit = qtiles;
         if (qsplit < 1) qsplit = 1;
+        if (nk_max > 512) qsplit = qtiles;     // windowed kernel: every pass re-stages its keys anyway
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(threads), lds, s, a);
     };
     const bool mult32 = (N % 32 == 0) && (M % 32 == 0);
     if (dyn) {
         // the whole row in one chunk
-        if (nblk <= 4) go(attention_kernel<true, 4, false>, 512);
-        else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true>, 512); else go(attention_kernel<true, 8, false>, 512); }
+        if (nblk <= 4) go(attention_kernel<true, 4, false, false>, 512);
+        else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false>, 512); else go(attention_kernel<true, 8, false, false>, 512); }
         else if (N == 512 && M == 512) {
             // 512 keys in both frames: the split-key kernel (two waves per query tile)
             const size_t lds2 = ((size_t)512 * KROWH + (size_t)64 * 520) * sizeof(_Float16) + (1040 + 4 * 17 * 64) * sizeof(float);
@@ -710,12 +921,16 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk_split_kernel),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
             hipLaunchKernelGGL(attention_topk_split_kernel, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds2, s, a);
-        } else go(attention_kernel<true, 16, false>, 256);
+        } else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
+        else return launch_attention_topk_wide(a, B, nk_max, s);
     } else {
         // chunks of 8 blocks (256 keys), two waves per SIMD
-        if (nblk <= 4) go(attention_kernel<false, 4, false>, 512);
-        else if (mult32 && N % 256 == 0 && M % 256 == 0) go(attention_kernel<false, 8, true>, 512);
-        else go(attention_kernel<false, 8, false>, 512);
+        if (nblk <= 4) go(attention_kernel<false, 4, false, false>, 512);
+        else if (nblk > 16) {
+            if (mult32 && N % 256 == 0 && M % 256 == 0) go(attention_kernel<false, 8, true, true>, 512);
+            else go(attention_kernel<false, 8, false, true>, 512);
+        } else if (mult32 && N % 256 == 0 && M % 256 == 0) go(attention_kernel<false, 8, true, false>, 512);
+        else go(attention_kernel<false, 8, false, false>, 512);
     }
     return mdgat_check_hip(hipGetLastError(), "attention launch");
 }
