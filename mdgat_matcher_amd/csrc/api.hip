@@ -304,11 +304,12 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;
 
     // ---- optimal transport (mdgat.py:434-436) and match extraction (441-483) ----
-    float* Zout = Z ? Z : ws.Z;
-    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, s))) return rc;
+    // (Z is only materialised when the caller asks for it or the streaming Sinkhorn needs it for the extraction)
+    const bool fused = ws.sk_bytes != 0;   // N, M <= 512: the cluster kernel, arg-maxes fused
+    float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
+    const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1};
+    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s))) return rc;
     mark(MDGAT_PROF_SINKHORN);
-    if ((rc = launch_extract(B, N, M, Zout, h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, s))) return rc;
-    mark(MDGAT_PROF_EXTRACT);
     if (h->prof_on && prof_n > 1) {
         if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;
         for (size_t i = 1; i < prof_n; ++i) {
@@ -341,7 +342,7 @@ extern "C" int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bi
                               size_t workspace_bytes, void* stream) {
     if (!scores || !Z) { mdgat_set_error("mdgat_sinkhorn: null pointer"); return MDGAT_ERR_BAD_ARG; }
     // without (enough, 256-byte aligned) workspace the streaming kernel is used instead of the cluster kernel
-    return launch_sinkhorn(B, N, M, scores, nullptr, bin_score, iters, Z, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
+    return launch_sinkhorn(B, N, M, scores, nullptr, bin_score, iters, Z, workspace, workspace_bytes, nullptr, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_threshold, int64_t* matches0,

@@ -97,8 +97,13 @@ struct LayerLaunch {
 int launch_layer(const LayerLaunch& p, hipStream_t s);
 int launch_split_rows(const float* w, _Float16* out, int rows, int K, hipStream_t s);
 
+struct SkExtract {   // match extraction to run after (or fused into) the Sinkhorn kernel
+    int mode; float thr;
+    int64_t *m0, *m1;
+    float *s0, *s1;
+};
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s);
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s);
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,

@@ -219,10 +219,17 @@ struct SksArgs {
     unsigned long long* slots;   // [ngroups][2][G][SLOT_STRIDE] granules, zeroed before every launch
     unsigned* error_word;
     int B, N, M, iters, ngroups, G;
+    // fused arg-max of the match extraction (mdgat.py:441-483): per row over the columns, per column over this
+    // workgroup's rows (merged later); ext_mode < 0: off.  Z may be NULL when only the matches are wanted.
+    int ext_mode;
+    int* rbest_idx;      // [B][N]
+    float* rbest_val;    // [B][N]
+    int* cbest_idx;      // [B][4][M]
+    float* cbest_val;    // [B][4][M]
 };
 
 constexpr int SKS_THREADS = 512;
-constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8;
+constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8 + 8 * 512;
 
 // RPW = rows per wave: 16 -> 128 rows per workgroup, up to 4 workgroups per pair, one workgroup per CU.
 // Per-row quantities (absorbed potential, dustbin-column entry, scaling a) live in lane r of the wave for
@@ -236,6 +243,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
     float* colp = lds + 520;              // [8 waves][512] per-wave column sums
     float* pdust = colp + 8 * 512;        // [8] per-wave sums of the dustbin column
     int* flags = reinterpret_cast<int*>(pdust + 8);   // [0]: a column scaling left the safe range
+    int* colpi = flags + 8;               // [8 waves][512] row indices of the per-wave column maxima (fused extraction)
 
     const int N = a.N, M = a.M, G = a.G;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -459,8 +467,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
         }
 
-        // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units ----
-        float* Zp = a.Z + (size_t)pair * (N + 1) * (M + 1);
+        // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
+        float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
         const float poison = (G > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                  ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
@@ -469,24 +477,83 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         float V[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) V[c] = (ran && col0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
+        const bool ext = a.ext_mode >= 0;
+        const bool inner = a.ext_mode >= MDGAT_EXTRACT_THRESHOLD;   // arg-max over the inner N x M block only
+        float cbv[8];
+        int cbi[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) { cbv[c] = -__builtin_inff(); cbi[c] = 0; }
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int i = row0 + r;
             if (i < N) {
                 const float U = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ur), r));
                 const float* row = S + (size_t)i * M;
-                float* zr = Zp + (size_t)i * (M + 1);
+                float z[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    if (col0 + c < M) zr[col0 + c] = (row[col0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
-                if (lane == 0) zr[M] = (alpha + U + VM) * MDGAT_LN2 - norm;
+                    z[c] = (col0 + c < M) ? (row[min(col0 + c, M - 1)] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm : -__builtin_inff();
+                const float zM = (alpha + U + VM) * MDGAT_LN2 - norm;
+                if (Zp) {
+                    float* zr = Zp + (size_t)i * (M + 1);
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (col0 + c < M) zr[col0 + c] = z[c];
+                    if (lane == 0) zr[M] = zM;
+                }
+                if (ext) {
+                    // row: first maximal column (torch.max), the dustbin column included unless `inner`
+                    float bv = z[0];
+                    int bi = col0;
+#pragma unroll
+                    for (int c = 1; c < 8; ++c)
+                        if (z[c] > bv) { bv = z[c]; bi = col0 + c; }
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) {
+                        const float ov = __shfl_xor(bv, o, 64);
+                        const int oi = __shfl_xor(bi, o, 64);
+                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+                    }
+                    if (!inner && zM > bv) { bv = zM; bi = M; }
+                    if (lane == 0) { a.rbest_idx[(size_t)pair * N + i] = bi; a.rbest_val[(size_t)pair * N + i] = bv; }
+                    // columns: first maximal row among this wave's rows (ascending, strict compare)
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if (z[c] > cbv[c]) { cbv[c] = z[c]; cbi[c] = i; }
+                }
             }
         }
-        if (j == G - 1) {
-            const float UN = ran ? u0N + lg2(aN) : 0.f;
+        const float UN = ran ? u0N + lg2(aN) : 0.f;
+        const float zN0 = (alpha + UN + (ran ? v0t0 + lg2(bt0) + poison : 0.f)) * MDGAT_LN2 - norm;   // Z[N][tid]
+        if (j == G - 1 && Zp) {
             float* zl = Zp + (size_t)N * (M + 1);
-            if (tid <= M) zl[tid] = (alpha + UN + (ran ? v0t0 + lg2(bt0) + poison : 0.f)) * MDGAT_LN2 - norm;
+            if (tid <= M) zl[tid] = zN0;
             if (tid + SKS_THREADS <= M) zl[tid + SKS_THREADS] = (alpha + UN + (ran ? v0t1 + lg2(bt1) + poison : 0.f)) * MDGAT_LN2 - norm;
+        }
+        if (ext) {
+            // merge the 8 waves (ascending rows), add the dustbin row (last row, only in the last workgroup, not `inner`)
+            __syncthreads();             // colp's readers of the last iteration are done
+            {
+                f32x4* qw = reinterpret_cast<f32x4*>(colp + wave * 512 + col0);
+                qw[0] = f32x4{cbv[0], cbv[1], cbv[2], cbv[3]};
+                qw[1] = f32x4{cbv[4], cbv[5], cbv[6], cbv[7]};
+                int* qi = colpi + wave * 512 + col0;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) qi[c] = cbi[c];
+            }
+            __syncthreads();
+            if (tid < M) {
+                float bv = colp[tid];
+                int bi = colpi[tid];
+#pragma unroll
+                for (int w = 1; w < 8; ++w) {
+                    const float v = colp[w * 512 + tid];
+                    if (v > bv) { bv = v; bi = colpi[w * 512 + tid]; }
+                }
+                if (!inner && j == G - 1 && zN0 > bv) { bv = zN0; bi = N; }
+                a.cbest_val[((size_t)pair * 4 + j) * M + tid] = bv;
+                a.cbest_idx[((size_t)pair * 4 + j) * M + tid] = bi;
+            }
         }
     }
 }
@@ -500,6 +567,8 @@ struct ExArgs {
     int64_t* m0; int64_t* m1;
     float* s0; float* s1;
     int* valid_count;   // global count of valid frame-0 rows (dustbin modes; mdgat.py:465 quirk)
+    // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests; column bests per row slab, G slabs)
+    const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int G;
 };
 
 __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
@@ -517,6 +586,22 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     const int nrow = inner ? N : N + 1;   // rows scanned per column
     if (tid == 0) *nvalid = 0;
 
+    if (!a.Z) {
+        for (int i = tid; i < N; i += 1024) {
+            idx0[i] = a.rbest_idx[(size_t)blockIdx.x * N + i];
+            val0[i] = a.rbest_val[(size_t)blockIdx.x * N + i];
+        }
+        for (int j = tid; j < M; j += 1024) {
+            const size_t base = (size_t)blockIdx.x * 4 * M + j;
+            float bv = a.cbest_val[base];
+            int bi = a.cbest_idx[base];
+            for (int g = 1; g < a.G; ++g) {          // ascending row slabs, strict compare: first maximal row
+                const float v = a.cbest_val[base + (size_t)g * M];
+                if (v > bv) { bv = v; bi = a.cbest_idx[base + (size_t)g * M]; }
+            }
+            idx1[j] = bi; val1[j] = bv;
+        }
+    } else {
     // rows: first maximal index (torch.max semantics)
     for (int i = wave; i < N; i += 16) {
         const float* zr = Z + (size_t)i * (M + 1);
@@ -543,6 +628,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             if (z > bv) { bv = z; bi = i; }
         }
         idx1[j] = bi; val1[j] = bv;
+    }
     }
     __syncthreads();
 
@@ -626,13 +712,17 @@ int launch_sk(const SkArgs& a, int B, hipStream_t s) {
 
 }  // namespace
 
+static size_t slots_bytes() { return 256 + (size_t)64 * 2 * 4 * SLOT_STRIDE * sizeof(unsigned long long); }
 size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
     if (N > 512 || M > 512) return 0;
-    return 256 + (size_t)64 * 2 * 8 * SLOT_STRIDE * sizeof(unsigned long long);
+    // exchange slots + fused arg-max scratch: row bests [B][N] (int + float), column bests [B][4][M] (int + float)
+    return slots_bytes() + ((size_t)B * N * 2 + (size_t)B * 4 * M * 2) * sizeof(float);
 }
 
+static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s);
+
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
-                          float* Z, void* ws, int num_cu, hipStream_t s) {
+                          float* Z, void* ws, int num_cu, const SkExtract* ex, hipStream_t s) {
     constexpr int RPW = 16;
     const int G = (N + 8 * RPW - 1) / (8 * RPW);   // workgroups per pair
     const int occ = RPW == 8 ? 2 : 1;              // resident workgroups per CU by registers
@@ -644,43 +734,64 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     const size_t ws_bytes = 256 + (size_t)ngroups * 2 * G * SLOT_STRIDE * sizeof(unsigned long long);
     if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, ws_bytes, s), "memset(sinkhorn slots)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, G};
+              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, G, -1, nullptr, nullptr, nullptr, nullptr};
+    if (ex) {
+        char* p = static_cast<char*>(ws) + slots_bytes();
+        a.ext_mode = ex->mode;
+        a.rbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * N * sizeof(int);
+        a.rbest_val = reinterpret_cast<float*>(p);                    p += (size_t)B * N * sizeof(float);
+        a.cbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * 4 * M * sizeof(int);
+        a.cbest_val = reinterpret_cast<float*>(p);
+    }
     void* args[] = {&a};
     // cooperative launch: the runtime checks that all ngroups * G workgroups can be co-resident
     hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW>), dim3(ngroups * G),
                                               dim3(SKS_THREADS), args, 0, s);
-    return mdgat_check_hip(e, "sinkhorn scaling launch");
+    if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
+    if (ex) {
+        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr,
+                 a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, G};
+        return launch_extract_impl(B, N, M, x, s);
+    }
+    return MDGAT_OK;
 }
 
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_cluster_workspace_bytes(B, N, M); }
 
+// ex != NULL: also extract the matches.  With the cluster kernel the arg-maxes are fused into its epilogue and Z may
+// be NULL; otherwise Z must be given and is scanned by the extraction kernel.
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, hipStream_t s) {
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
+    if (!Z && !ex) { mdgat_set_error("sinkhorn: nothing to compute (no Z, no extraction)"); return MDGAT_ERR_BAD_ARG; }
     if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("sinkhorn: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
     const size_t need = sinkhorn_cluster_workspace_bytes(B, N, M);
     if (need && ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 255) == 0) {
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, s);
+        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, s);
     }
+    if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
     // streaming kernel: any shape up to M = 2048, no workspace
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters};
-    if (M <= 64) return launch_sk<1, 16>(a, B, s);
-    if (M <= 128) return launch_sk<2, 16>(a, B, s);
-    if (M <= 256) return launch_sk<4, 16>(a, B, s);
-    if (M <= 512) return launch_sk<8, 16>(a, B, s);
-    if (M <= 1024 && N <= 4096) return launch_sk<16, 8>(a, B, s);
-    if (M <= 2048 && N <= 4096) return launch_sk<32, 8>(a, B, s);
-    mdgat_set_error("sinkhorn: M=%d > 2048 unsupported", M);
-    return MDGAT_ERR_UNSUPPORTED;
+    int rc;
+    if (M <= 64) rc = launch_sk<1, 16>(a, B, s);
+    else if (M <= 128) rc = launch_sk<2, 16>(a, B, s);
+    else if (M <= 256) rc = launch_sk<4, 16>(a, B, s);
+    else if (M <= 512) rc = launch_sk<8, 16>(a, B, s);
+    else if (M <= 1024 && N <= 4096) rc = launch_sk<16, 8>(a, B, s);
+    else if (M <= 2048 && N <= 4096) rc = launch_sk<32, 8>(a, B, s);
+    else {
+        mdgat_set_error("sinkhorn: M=%d > 2048 unsupported", M);
+        return MDGAT_ERR_UNSUPPORTED;
+    }
+    if (rc || !ex) return rc;
+    return launch_extract(B, N, M, Z, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, s);
 }
 
-int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
-                   float* s1, hipStream_t s) {
-    if (B <= 0) return MDGAT_OK;
-    if (mode < 0 || mode > 3) { mdgat_set_error("extract: bad mode %d", mode); return MDGAT_ERR_BAD_ARG; }
+static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s) {
+    if (a.mode < 0 || a.mode > 3) { mdgat_set_error("extract: bad mode %d", a.mode); return MDGAT_ERR_BAD_ARG; }
     int dev = 0;
     if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
     if (dev >= 16) { mdgat_set_error("extract: device index %d >= 16", dev); return MDGAT_ERR_UNSUPPORTED; }
@@ -688,15 +799,22 @@ int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int
         if (int rc = mdgat_check_hip(hipMalloc(&g_valid_count[dev], sizeof(int)), "hipMalloc(valid_count)")) return rc;
     }
     if (int rc = mdgat_check_hip(hipMemsetAsync(g_valid_count[dev], 0, sizeof(int), s), "memset(valid_count)")) return rc;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, g_valid_count[dev]};
+    a.valid_count = g_valid_count[dev];
     const size_t lds = (size_t)(2 * (N + M) + 4) * sizeof(float);
     hipLaunchKernelGGL(extract_kernel, dim3(B), dim3(1024), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "extract launch")) return rc;
-    if (mode == MDGAT_EXTRACT_DUSTBIN || mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
+    if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
         const size_t n = (size_t)B * M;
         hipLaunchKernelGGL(extract_alldust_fixup, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s,
-                           g_valid_count[dev], s1, n);
+                           g_valid_count[dev], a.s1, n);
         return mdgat_check_hip(hipGetLastError(), "extract fixup launch");
     }
     return MDGAT_OK;
+}
+
+int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
+                   float* s1, hipStream_t s) {
+    if (B <= 0) return MDGAT_OK;
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    return launch_extract_impl(B, N, M, a, s);
 }
