@@ -108,6 +108,16 @@ int mdgat_forward(mdgat_handle* h, int B, int N, int M,
                   float* Z, const mdgat_taps* taps,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward fed with the loader's raw frame records instead of separate arrays: frames [B][N][37] fp32,
+ * one record per keypoint = xyz(3) | saliency(1) | FPFH(33), the layout of the KITTI keypoint files that
+ * SparseDataset.__getitem__ reads (load_data.py:146-165).  normalize_fpfh != 0 applies the loader's L2
+ * normalisation of the FPFH part (load_data.py:290-292) inside the encoder kernel. */
+int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* frames0, const float* frames1,
+                         int normalize_fpfh,
+                         int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
+                         float* Z, const mdgat_taps* taps,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
 /* Per-kernel-class timing of mdgat_forward, measured with HIP events on the launch stream (bench.py's
  * roofline leg).  mdgat_profile(h, enable, ms, launches) returns the time (ms) and launch count
  * accumulated per class since the previous call in ms[MDGAT_PROF_CLASSES] / launches[...] (either may

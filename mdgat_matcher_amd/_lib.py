@@ -51,6 +51,8 @@ SIGNATURES = {
     'mdgat_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'mdgat_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p] * 4 +
                       [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_forward_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
+                             [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     'mdgat_sinkhorn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),

@@ -69,7 +69,7 @@ struct mdgat_handle {
 
 // split-weight buffer: per layer [w1 256x2x256 | w2 128x2x256 | qkv 384x2x128], then final_proj 128x2x128
 static constexpr size_t WS_W1 = 0, WS_W2 = 256 * 512, WS_QKV = WS_W2 + 128 * 512, WS_LAYER = WS_QKV + 384 * 256;
-static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + 128 * 256; }
+static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + 128 * 256 + MDGAT_ENC_SPLIT_HALVES; }
 
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
@@ -129,6 +129,14 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
         if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, nullptr);
     }
     if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, nullptr);
+    {
+        _Float16* es = h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L) + 128 * 256;
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc2_w, es + 64 * 64, 128, 64, nullptr);
+        if (!rc) rc = launch_split_rows_pad(h->weights + bl.denc0_w, es + 64 * 64 + 128 * 128, 64, 33, 48, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.denc1_w, es + 64 * 64 + 128 * 128 + 64 * 96, 128, 64, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.encl_w, es + 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128, 128, 256, nullptr);
+    }
     if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "split weights");
     (void)hipSetDevice(prev);
     if (rc) return rc;
@@ -189,14 +197,16 @@ static GemmArgs pointwise(const float* A, int lda, int K, const float* W, const 
     return g;
 }
 
-extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
-                             const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
-                             int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
-                             const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
+                        const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
+                        const float* rec0, const float* rec1, int normalize_fpfh,
+                        int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
     if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
-    if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1 || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
+    const bool arrays = kpts0 && sigma0 && fpfh0 && kpts1 && sigma1 && fpfh1;
+    if ((!arrays && !(rec0 && rec1)) || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
         mdgat_set_error("mdgat_forward: null pointer argument");
         return MDGAT_ERR_BAD_ARG;
     }
@@ -235,22 +245,14 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
     };
     mark(-1);
 
-    // ---- encoders (mdgat.py:392-393) ----
-    float* scr = ws.qkv;                 // R*640 floats of scratch (qkv + hid)
-    float* hk0 = scr;                    // [R][32]
-    float* hd0 = hk0 + (size_t)R * 32;   // [R][64]
-    float* hk1 = hd0 + (size_t)R * 64;   // [R][64]
-    float* hk2 = hk1 + (size_t)R * 64;   // [R][128]
-    float* hd1 = hk2 + (size_t)R * 128;  // [R][128]
-    if ((rc = launch_encode_l0(B, N, P, 0, kpts0, sigma0, fpfh0, w, bl, hk0, hd0, s))) return rc;
-    if ((rc = launch_encode_l0(B, M, P, N, kpts1, sigma1, fpfh1, w, bl, hk0, hd0, s))) return rc;
-    if ((rc = launch_gemm(pointwise(hk0, 32, 32, w + bl.kenc1_w, w + bl.kenc1_b, 1, hk1, 64, R, 64), s))) return rc;
-    if ((rc = launch_gemm(pointwise(hk1, 64, 64, w + bl.kenc2_w, w + bl.kenc2_b, 1, hk2, 128, R, 128), s))) return rc;
-    if ((rc = launch_gemm(pointwise(hd0, 64, 64, w + bl.denc1_w, w + bl.denc1_b, 1, hd1, 128, R, 128), s))) return rc;
+    // ---- encoders (mdgat.py:392-393), one fused launch ----
     {
-        GemmArgs g = pointwise(hd1, 128, 256, w + bl.encl_w, w + bl.encl_b, 0, ws.x, 128, R, 128);
-        g.K0 = 128; g.A1 = hk2; g.lda1 = 128;
-        if ((rc = launch_gemm(g, s))) return rc;
+        EncoderLaunch e{};
+        e.kpts0 = kpts0; e.sigma0 = sigma0; e.fpfh0 = fpfh0; e.kpts1 = kpts1; e.sigma1 = sigma1; e.fpfh1 = fpfh1;
+        e.rec0 = rec0; e.rec1 = rec1; e.normalize = normalize_fpfh;
+        e.w = w; e.bl = &bl; e.es = h->wsplit + WS_LAYER * (size_t)L2 + 128 * 256;
+        e.x = ws.x; e.B = B; e.N = N; e.M = M;
+        if ((rc = launch_encoder(e, s))) return rc;
     }
     mark(MDGAT_PROF_ENCODER);
     if (taps && taps->x_enc)
@@ -321,6 +323,24 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
         }
     }
     return MDGAT_OK;
+}
+
+extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
+                             const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
+                             int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                             const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1) { mdgat_set_error("mdgat_forward: null input pointer"); return MDGAT_ERR_BAD_ARG; }
+    return forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
+                        mscores1, Z, taps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* frames0, const float* frames1,
+                                    int normalize_fpfh, int64_t* matches0, int64_t* matches1, float* mscores0,
+                                    float* mscores1, float* Z, const mdgat_taps* taps, void* workspace,
+                                    size_t workspace_bytes, void* stream) {
+    if (!frames0 || !frames1) { mdgat_set_error("mdgat_forward_frames: null frame pointer"); return MDGAT_ERR_BAD_ARG; }
+    return forward_impl(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
+                        matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdgat_profile(mdgat_handle* h, int enable, double* ms_out, long long* launches_out) {

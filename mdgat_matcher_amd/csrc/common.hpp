@@ -68,8 +68,20 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 
-int launch_encode_l0(int B, int N, int P, int off, const float* kpts, const float* sigma, const float* fpfh,
-                     const float* w, const BlobLayout& bl, float* hk0, float* hd0, hipStream_t s);
+// fused encoders (encoder.hip).  es = split weights [kenc.3 64x2x32 | kenc.6 128x2x64 | denc.0 64x2x48 | denc.3 128x2x64 |
+// last convs 128x2x256]; inputs either as separate arrays or as raw 37-float frame records
+struct EncoderLaunch {
+    const float *kpts0, *sigma0, *fpfh0, *kpts1, *sigma1, *fpfh1;
+    const float *rec0, *rec1;
+    int normalize;
+    const float* w; const BlobLayout* bl;
+    const _Float16* es;
+    float* x;
+    int B, N, M;
+};
+constexpr size_t MDGAT_ENC_SPLIT_HALVES = 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128 + 128 * 512;
+int launch_encoder(const EncoderLaunch& p, hipStream_t s);
+int launch_split_rows_pad(const float* w, _Float16* out, int rows, int Kin, int Kpad, hipStream_t s);
 
 // q/k/v of every point in the split-f16 operand layouts of the attention kernel (attention.hip)
 struct Qkv16 {

@@ -1,42 +1,7 @@
-// Small per-point kernels: first encoder layers (VALU) and the kNN graph helper.
+// The kNN graph helper.
 #include "common.hpp"
 
 namespace {
-
-// First layer of both encoders (BN folded, ReLU): KeypointEncoder conv 4->32 on [x, y, z, saliency]
-// (mdgat.py:181, 186-188) and DescriptorEncoder conv 33->64 on the FPFH row (mdgat.py:148, 154-155).
-// K = 4 and K = 33 are not MFMA shapes and the layer is 0.1 % of the FLOPs: plain VALU, one thread per
-// output channel; the 37 input floats of a point are broadcast through L1 to its 96 threads.
-__global__ __launch_bounds__(256) void encode_l0_kernel(int B, int N, int P, int off, const float* __restrict__ kpts,
-                                                        const float* __restrict__ sigma, const float* __restrict__ fpfh,
-                                                        const float* __restrict__ wk, const float* __restrict__ bk,
-                                                        const float* __restrict__ wd, const float* __restrict__ bd,
-                                                        float* __restrict__ hk0, float* __restrict__ hd0) {
-    const size_t total = (size_t)B * N * 96;
-    for (size_t idx = blockIdx.x * (size_t)blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int ch = (int)(idx % 96);
-        const size_t pt = idx / 96;                 // b * N + n
-        const size_t b = pt / N, n = pt % N;
-        const size_t row = b * P + off + n;
-        if (ch < 32) {
-            const float* k = kpts + pt * 3;
-            float acc = bk[ch];
-            acc = fmaf(wk[ch * 4 + 0], k[0], acc);
-            acc = fmaf(wk[ch * 4 + 1], k[1], acc);
-            acc = fmaf(wk[ch * 4 + 2], k[2], acc);
-            acc = fmaf(wk[ch * 4 + 3], sigma[pt], acc);
-            hk0[row * 32 + ch] = fmaxf(acc, 0.f);
-        } else {
-            const int c = ch - 32;
-            const float* f = fpfh + pt * MDGAT_FPFH;
-            const float* w = wd + c * MDGAT_FPFH;
-            float acc = bd[c];
-#pragma unroll
-            for (int i = 0; i < MDGAT_FPFH; ++i) acc = fmaf(w[i], f[i], acc);
-            hd0[row * 64 + c] = fmaxf(acc, 0.f);
-        }
-    }
-}
 
 // knn() of mdgat.py:8-15 (+ get_graph_feature's adjacency, 17-32).  One wave per query point: the
 // M negative squared distances -|x|^2 + 2 x.s - |s|^2 go to LDS, then k rounds of wave arg-max pick
@@ -83,16 +48,6 @@ __global__ __launch_bounds__(256) void knn_kernel(int C, int N, int M, int k, co
 }
 
 }  // namespace
-
-int launch_encode_l0(int B, int N, int P, int off, const float* kpts, const float* sigma, const float* fpfh,
-                     const float* w, const BlobLayout& bl, float* hk0, float* hd0, hipStream_t s) {
-    if (B <= 0 || N <= 0) return MDGAT_OK;
-    const size_t total = (size_t)B * N * 96;
-    const unsigned grid = (unsigned)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(encode_l0_kernel, dim3(grid), dim3(256), 0, s, B, N, P, off, kpts, sigma, fpfh, w + bl.kenc0_w,
-                       w + bl.kenc0_b, w + bl.denc0_w, w + bl.denc0_b, hk0, hd0);
-    return mdgat_check_hip(hipGetLastError(), "encode_l0 launch");
-}
 
 int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
                hipStream_t s) {

@@ -258,7 +258,9 @@ class MDGAT(nn.Module):
     def _f32(t, device):
         return t.to(device=device, dtype=torch.float32).contiguous()
 
-    def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None):
+    def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True):
+        if frames is not None:
+            return self._run_frames(frames[0], frames[1], normalize, want_Z, taps)
         if not kpts0.is_cuda:
             raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
                                'device; there is no CPU fallback')
@@ -307,6 +309,57 @@ class MDGAT(nn.Module):
         with st.lock:
             _lib.check(_lib.load().mdgat_profile(st.handle, int(bool(enable)), ms, n), 'mdgat_profile')
         return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
+
+    def _run_frames(self, frames0, frames1, normalize, want_Z=False, taps=None):
+        if not frames0.is_cuda:
+            raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
+                               'device; there is no CPU fallback')
+        if frames0.shape[-1] != 37 or frames1.shape[-1] != 37 or frames0.dim() != 3:
+            raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
+        dev = frames0.device
+        B, N, M = frames0.shape[0], frames0.shape[1], frames1.shape[1]
+        r0, r1 = self._f32(frames0, dev), self._f32(frames1, dev)
+        st = self._state_for(dev)
+        lib = _lib.load()
+        with torch.cuda.device(dev), st.lock:
+            need = lib.mdgat_workspace_bytes(st.handle, B, N, M)
+            if st.workspace is None or st.workspace.numel() < need:
+                st.workspace = None
+                st.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            m0 = torch.empty((B, N), dtype=torch.int64, device=dev)
+            m1 = torch.empty((B, M), dtype=torch.int64, device=dev)
+            s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
+            s1 = torch.empty((B, M), dtype=torch.float32, device=dev)
+            Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=dev) if want_Z else None
+            tap_struct = None
+            if taps is not None:
+                tap_struct = _lib.MdgatTaps()
+                for name in ('x_enc', 'x_layers', 'mdesc', 'scores'):
+                    t = taps.get(name)
+                    setattr(tap_struct, name, t.data_ptr() if t is not None else None)
+            rc = lib.mdgat_forward_frames(
+                st.handle, B, N, M, r0.data_ptr(), r1.data_ptr(), int(bool(normalize)),
+                m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(),
+                Z.data_ptr() if Z is not None else None,
+                C.byref(tap_struct) if tap_struct is not None else None,
+                st.workspace.data_ptr(), st.workspace.numel(), torch.cuda.current_stream(dev).cuda_stream)
+            _lib.check(rc, 'mdgat_forward_frames')
+        return m0, m1, s0, s1, Z
+
+    @torch.no_grad()
+    def match_frames(self, frames0, frames1, normalize=True, return_scores=False):
+        """Match straight from the loader's raw keypoint records (``load_data.py:146-165``): ``frames`` are
+        ``[B, N, 37]`` (or ``[N, 37]``) float32 rows ``xyz | saliency | FPFH``, exactly the content of the KITTI
+        keypoint ``.bin`` files.  The record split and the FPFH L2 normalisation (``load_data.py:290-292``) happen
+        inside the encoder kernel.  Returns ``(matches0, matches1, mscores0, mscores1[, Z])``."""
+        single = frames0.dim() == 2
+        if single:
+            frames0, frames1 = frames0[None], frames1[None]
+        m0, m1, s0, s1, Z = self._run_frames(frames0, frames1, normalize, want_Z=return_scores)
+        outs = [m0, m1, s0, s1] + ([Z] if return_scores else [])
+        if single:
+            outs = [o[0] for o in outs]
+        return tuple(outs)
 
     # ------------------------------------------------------------------ match() API
     @torch.no_grad()

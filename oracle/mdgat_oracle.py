@@ -250,6 +250,23 @@ def knn_adjacency(x, src, k: int, idx=None):
     return adj
 
 
+# ----------------------------------------------------------------------------- frame decode (loader)
+def decode_frames(records):
+    """SparseDataset.__getitem__'s record handling (load_data.py:152-165, 290-295) for a batch of raw keypoint
+    frames ``[B, N, 37]`` float32: xyz = [:, :3], saliency = [:, 3], FPFH = [:, 4:] scaled by 1 / ||FPFH||_2
+    (computed in float32 like numpy does there), everything then cast to float64.
+    Returns (keypoints [B, N, 3], scores [B, N], descriptors [B, N, 33])."""
+    import numpy as np
+    rec = np.asarray(records, dtype=np.float32)
+    kp = rec[..., :3]
+    score = rec[..., 3]
+    desc = rec[..., 4:]
+    norm = np.linalg.norm(desc, axis=-1)[..., None]
+    desc = np.multiply(desc, 1 / norm)
+    return (torch.tensor(kp, dtype=torch.double), torch.tensor(score, dtype=torch.double),
+            torch.tensor(desc, dtype=torch.double))
+
+
 # ----------------------------------------------------------------------------- whole forward
 def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture: Optional[dict] = None):
     """MDGAT.forward for ``descriptor == 'FPFH'`` (mdgat.py:369-483, 596-603), loss excluded.

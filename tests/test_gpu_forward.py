@@ -256,3 +256,33 @@ def test_large_frames(n, m, L, S, k):
     else:
         assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC and err.max() < FLIP_MAX
         assert (m0.cpu() != ref['matches0']).double().mean() < FLIP_FRAC
+
+
+def test_match_frames_raw_records():
+    """Raw 37-float keypoint records (load_data.py:152-165) straight into the encoder kernel, FPFH normalisation
+    (load_data.py:290-292) fused: same result as decoding with the oracle's restatement of the loader."""
+    L, S, B, n, m = 2, 20, 2, 200, 168
+    cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=S)
+    sd = synth.make_state_dict(L=L, seed=2)
+    net = MDGAT(cfg)
+    net.load_state_dict(sd)
+    net = net.double().eval().to(DEV)
+    rs = np.random.RandomState(11)
+    def frames(count):
+        rec = np.zeros((B, count, 37), dtype=np.float32)
+        rec[..., :3] = 20.0 * rs.standard_normal((B, count, 3))
+        rec[..., 3] = rs.uniform(0, 1, (B, count))
+        rec[..., 4:] = rs.uniform(0, 200, (B, count, 33))        # un-normalised histogram-like FPFH
+        return rec
+    r0, r1 = frames(n), frames(m)
+    k0, s0, d0 = O.decode_frames(r0)
+    k1, s1, d1 = O.decode_frames(r1)
+    data = {'keypoints0': k0, 'scores0': s0, 'descriptors0': d0, 'keypoints1': k1, 'scores1': s1, 'descriptors1': d1}
+    cap = {}
+    ref = O.mdgat_forward(sd, cfg, data, cap)
+    m0, m1, c0, c1, Z = net.match_frames(torch.from_numpy(r0).to(DEV), torch.from_numpy(r1).to(DEV), return_scores=True)
+    assert (Z.cpu().double() - cap['Z']).abs().max() < Z_TOL
+    assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
+    # and the array entry point agrees with the record entry point on pre-decoded inputs
+    m0b = net.match(k0.to(DEV), d0.to(DEV), k1.to(DEV), d1.to(DEV), s0.to(DEV), s1.to(DEV))[0]
+    assert torch.equal(m0b, m0)
