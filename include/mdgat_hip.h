@@ -169,6 +169,23 @@ int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W
 int mdgat_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx,
               int64_t* adj, void* stream);
 
+/* ---- the steps either side of the matcher, fp64 like the reference's numpy ---------- */
+
+/* Pose from matches, per pair: solve_icp (utils/utils_test.py:73-110: centroids, cross covariance, SVD,
+ * R = U V^T without reflection fix) on {kpts0[i], kpts1[matches0[i]] : matches0[i] >= 0}, as test.py:213-216
+ * selects them; T [B][4][4] maps frame-1 points onto frame 0.  stats [B][5] = number of matches, inliers
+ * (|T p1 - p0| < inlier_dist, utils_test.py:55-63), inlier ratio, and - when T_gt [B][4][4] is given -
+ * translation / rotation error of inv(T) T_gt (utils_test.py:65-70; the arccos is not clamped there either). */
+int mdgat_pose(int B, int N, int M, const float* kpts0, const float* kpts1, const int64_t* matches0,
+               const double* T_gt, double inlier_dist, double* T, double* stats, void* stream);
+
+/* Ground-truth matches of SparseDataset.__getitem__ (load_data.py:238-285): nearest neighbours of the
+ * world-frame keypoints (T0/T1 [B][4][4] = pose . T_cam0_velo per frame, NULL = identity) in both
+ * directions under `threshold`, optional mutual check; -1 = no match; rep [B] = number of frame-0
+ * keypoints with a frame-1 keypoint within the threshold (load_data.py:264). */
+int mdgat_gt_matches(int B, int N, int M, const float* kpts0, const float* kpts1, const double* T0, const double* T1,
+                     double threshold, int mutual, int64_t* gt0, int64_t* gt1, int64_t* rep, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

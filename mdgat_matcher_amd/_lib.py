@@ -63,6 +63,10 @@ SIGNATURES = {
     'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_pointwise': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'mdgat_pose': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                             C.c_void_p, C.c_void_p]),
+    'mdgat_gt_matches': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mdgat_knn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                             C.c_void_p]),
 }

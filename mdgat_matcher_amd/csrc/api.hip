@@ -403,3 +403,17 @@ extern "C" int mdgat_knn(int B, int C, int N, int M, int k, const float* x, cons
     if (!x || !src || !idx) { mdgat_set_error("mdgat_knn: null pointer"); return MDGAT_ERR_BAD_ARG; }
     return launch_knn(B, C, N, M, k, x, src, idx, adj, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int mdgat_pose(int B, int N, int M, const float* kpts0, const float* kpts1, const int64_t* matches0,
+                          const double* T_gt, double inlier_dist, double* T, double* stats, void* stream) {
+    if (!kpts0 || !kpts1 || !matches0 || !T || !stats) { mdgat_set_error("mdgat_pose: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (N <= 0 || M <= 0) { mdgat_set_error("mdgat_pose: empty frame"); return MDGAT_ERR_BAD_ARG; }
+    return launch_pose(B, N, M, kpts0, kpts1, matches0, T_gt, inlier_dist, T, stats, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_gt_matches(int B, int N, int M, const float* kpts0, const float* kpts1, const double* T0, const double* T1,
+                                double threshold, int mutual, int64_t* gt0, int64_t* gt1, int64_t* rep, void* stream) {
+    if (!kpts0 || !kpts1 || !gt0 || !gt1 || !rep) { mdgat_set_error("mdgat_gt_matches: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (N <= 0 || M <= 0) { mdgat_set_error("mdgat_gt_matches: empty frame"); return MDGAT_ERR_BAD_ARG; }
+    return launch_gt_match(B, N, M, kpts0, kpts1, T0, T1, threshold, mutual, gt0, gt1, rep, static_cast<hipStream_t>(stream));
+}

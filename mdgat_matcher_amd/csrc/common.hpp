@@ -121,5 +121,10 @@ size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,
                    float* s0, float* s1, hipStream_t s);
 
+int launch_pose(int B, int N, int M, const float* kpts0, const float* kpts1, const int64_t* matches0, const double* T_gt,
+                double inlier_dist, double* T, double* stats, hipStream_t s);
+int launch_gt_match(int B, int N, int M, const float* kpts0, const float* kpts1, const double* T0, const double* T1,
+                    double threshold, int mutual, int64_t* gt0, int64_t* gt1, int64_t* rep, hipStream_t s);
+
 int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
                hipStream_t s);

@@ -102,3 +102,43 @@ def knn(x: torch.Tensor, src: torch.Tensor, k: int, adjacency: bool = False):
         _lib.check(_lib.load().mdgat_knn(B, Cc, N, M, int(k), xp.data_ptr(), sp.data_ptr(), idx.data_ptr(),
                                          adj.data_ptr() if adj is not None else None, _stream(x)), 'mdgat_knn')
     return (idx, adj) if adjacency else idx
+
+
+def pose_from_matches(kpts0: torch.Tensor, kpts1: torch.Tensor, matches0: torch.Tensor, T_gt=None, inlier_dist: float = 1.0):
+    """solve_icp + calculate_error (utils/utils_test.py:41-110) for a batch: kpts [B, N, 3] / [B, M, 3], matches0
+    [B, N] int64 (-1 = unmatched).  Returns (T [B, 4, 4] float64 mapping frame 1 onto frame 0, stats [B, 5] float64 =
+    matches, inliers, inlier ratio, translation error, rotation error; the errors are NaN without ``T_gt``)."""
+    _need_cuda(kpts0, kpts1, matches0)
+    k0 = kpts0.to(torch.float32).contiguous()
+    k1 = kpts1.to(torch.float32).contiguous()
+    m0 = matches0.to(torch.int64).contiguous()
+    B, N, M = k0.shape[0], k0.shape[1], k1.shape[1]
+    T = torch.empty((B, 4, 4), dtype=torch.float64, device=k0.device)
+    stats = torch.empty((B, 5), dtype=torch.float64, device=k0.device)
+    g = T_gt.to(device=k0.device, dtype=torch.float64).contiguous() if T_gt is not None else None
+    with torch.cuda.device(k0.device):
+        _lib.check(_lib.load().mdgat_pose(B, N, M, k0.data_ptr(), k1.data_ptr(), m0.data_ptr(),
+                                          g.data_ptr() if g is not None else None, float(inlier_dist), T.data_ptr(),
+                                          stats.data_ptr(), _stream(k0)), 'mdgat_pose')
+    return T, stats
+
+
+def gt_matches(kpts0: torch.Tensor, kpts1: torch.Tensor, T0=None, T1=None, threshold: float = 0.5, mutual: bool = False):
+    """Ground-truth matches of the loader (load_data.py:238-285): kpts [B, N, 3] / [B, M, 3] in the sensor frame,
+    T0 / T1 [B, 4, 4] float64 sensor -> world (None = identity).  Returns (gt_matches0 [B, N], gt_matches1 [B, M],
+    rep [B]) as int64, -1 = no match."""
+    _need_cuda(kpts0, kpts1)
+    k0 = kpts0.to(torch.float32).contiguous()
+    k1 = kpts1.to(torch.float32).contiguous()
+    B, N, M = k0.shape[0], k0.shape[1], k1.shape[1]
+    g0 = torch.empty((B, N), dtype=torch.int64, device=k0.device)
+    g1 = torch.empty((B, M), dtype=torch.int64, device=k0.device)
+    rep = torch.empty((B,), dtype=torch.int64, device=k0.device)
+    t0 = T0.to(device=k0.device, dtype=torch.float64).contiguous() if T0 is not None else None
+    t1 = T1.to(device=k0.device, dtype=torch.float64).contiguous() if T1 is not None else None
+    with torch.cuda.device(k0.device):
+        _lib.check(_lib.load().mdgat_gt_matches(B, N, M, k0.data_ptr(), k1.data_ptr(),
+                                                t0.data_ptr() if t0 is not None else None,
+                                                t1.data_ptr() if t1 is not None else None, float(threshold), int(bool(mutual)),
+                                                g0.data_ptr(), g1.data_ptr(), rep.data_ptr(), _stream(k0)), 'mdgat_gt_matches')
+    return g0, g1, rep

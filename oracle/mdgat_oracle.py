@@ -267,6 +267,75 @@ def decode_frames(records):
             torch.tensor(desc, dtype=torch.double))
 
 
+# ----------------------------------------------------------------------------- pose from matches (evaluation)
+def solve_icp(P, Q):
+    """utils/utils_test.py:73-110 (numpy, float64): rigid transform taking P onto Q from one SVD, R = U Vh, no
+    reflection fix."""
+    import numpy as np
+    P = np.asarray(P, dtype=np.float64)
+    Q = np.asarray(Q, dtype=np.float64)
+    up, uq = P.mean(axis=0), Q.mean(axis=0)
+    U, _, Vh = np.linalg.svd(np.dot((Q - uq).T, P - up), full_matrices=True, compute_uv=True)
+    R = np.dot(U, Vh)
+    T = np.zeros((4, 4))
+    T[:3, :3] = R
+    T[:3, 3] = uq - np.dot(R, up)
+    T[3, 3] = 1.0
+    return T
+
+
+def pose_from_matches(kpts0, kpts1, matches0, T_gt=None, inlier_dist=1.0):
+    """test.py:213-216 (selection of the matched keypoints) + calculate_error (utils_test.py:41-71) for one pair.
+    Returns (T, matches, inliers, inlier_ratio, trans_error, rot_error)."""
+    import numpy as np
+    kpts0 = np.asarray(kpts0, dtype=np.float64)
+    kpts1 = np.asarray(kpts1, dtype=np.float64)
+    matches0 = np.asarray(matches0)
+    valid = matches0 > -1
+    mk0, mk1 = kpts0[valid], kpts1[matches0[valid]]
+    T = solve_icp(mk1, mk0)
+    w = (T[:3, :3] @ mk1.T).T + T[:3, 3]
+    inl = int((np.linalg.norm(w - mk0, axis=1) < inlier_dist).sum())
+    te = re = float('nan')
+    if T_gt is not None:
+        E = np.linalg.inv(T) @ np.asarray(T_gt, dtype=np.float64)
+        te = float(np.linalg.norm(E[:3, 3]))
+        with np.errstate(invalid='ignore'):
+            re = float(np.arccos((E[0, 0] + E[1, 1] + E[2, 2] - 1) * 0.5))
+    return T, int(valid.sum()), inl, inl / max(int(valid.sum()), 1), te, re
+
+
+def gt_matches(kp0, kp1, T0=None, T1=None, threshold=0.5, mutual=False):
+    """load_data.py:238-285 for one pair: world-frame keypoints, cdist, arg-mins both ways, threshold, optional
+    mutual check.  Returns (match0 [N], match1 [M], rep)."""
+    import numpy as np
+    from scipy.spatial.distance import cdist
+    def world(kp, T):
+        kp = np.asarray(kp, dtype=np.float64)
+        if T is None:
+            return kp
+        T = np.asarray(T, dtype=np.float64)
+        return (T[:3, :3] @ kp.T).T + T[:3, 3]
+    a, b = world(kp0, T0), world(kp1, T1)
+    dists = cdist(a, b)
+    min1 = np.argmin(dists, axis=0)
+    min2 = np.argmin(dists, axis=1)
+    min1v = np.min(dists, axis=1)
+    min1f = min2[min1v < threshold]
+    rep = len(min1f)
+    match1, match2 = -1 * np.ones(len(a), dtype=np.int64), -1 * np.ones(len(b), dtype=np.int64)
+    if mutual:
+        xx = np.where(min2[min1] == np.arange(min1.shape[0]))[0]
+        matches = np.intersect1d(min1f, xx)
+        match1[min1[matches]] = matches
+        match2[matches] = min1[matches]
+    else:
+        match1[min1v < threshold] = min1f
+        min2v = np.min(dists, axis=0)
+        match2[min2v < threshold] = min1[min2v < threshold]
+    return match1, match2, rep
+
+
 # ----------------------------------------------------------------------------- whole forward
 def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture: Optional[dict] = None):
     """MDGAT.forward for ``descriptor == 'FPFH'`` (mdgat.py:369-483, 596-603), loss excluded.

@@ -149,3 +149,24 @@ def test_double_eval_does_not_repack():
     assert net._sig_holder[0] == sig and 99 in net._states
     net.float()
     assert 99 not in net._states          # a real cast drops the packed weights
+
+
+def test_oracle_postproc_restatements():
+    """The oracle's restatements of utils_test.solve_icp and the loader's ground-truth matcher on a known case:
+    exact correspondences under a known rigid motion."""
+    from oracle import mdgat_oracle as O
+    rs = np.random.RandomState(3)
+    th = 0.3
+    R = np.array([[np.cos(th), -np.sin(th), 0], [np.sin(th), np.cos(th), 0], [0, 0, 1.0]])
+    t = np.array([1.0, -2.0, 0.5])
+    P = rs.standard_normal((40, 3)) * 10
+    Q = P @ R.T + t
+    T = O.solve_icp(P, Q)
+    assert np.abs(T[:3, :3] - R).max() < 1e-12 and np.abs(T[:3, 3] - t).max() < 1e-11
+    Tp, n, inl, ratio, te, re = O.pose_from_matches(Q, P, np.arange(40), T_gt=T)
+    assert n == 40 and inl == 40 and te < 1e-10 and (re < 1e-6 or np.isnan(re))
+    # ground-truth matcher: frame 1 = permuted frame 0 -> the permutation comes back, mutual or not
+    perm = rs.permutation(40)
+    for mutual in (False, True):
+        m0, m1, rep = O.gt_matches(P, P[perm], threshold=0.5, mutual=mutual)
+        assert rep == 40 and (P[perm][m0] == P).all() and (m1 == perm).all()
