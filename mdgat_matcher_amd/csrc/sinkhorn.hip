@@ -216,73 +216,131 @@ struct SksArgs {
     const float* alpha_dev;
     float alpha_host;
     float* Z;
-    unsigned long long* slots;   // [ngroups][2][G][SLOT_STRIDE] granules, zeroed before every launch
+    unsigned long long* slots;   // per group: column slots [2][GC][GR][SLOT_STRIDE], then row slots [2][GR][GC][ROW_STRIDE]; zeroed per launch
     unsigned* error_word;
-    int B, N, M, iters, ngroups, G;
-    // fused arg-max of the match extraction (mdgat.py:441-483): per row over the columns, per column over this
-    // workgroup's rows (merged later); ext_mode < 0: off.  Z may be NULL when only the matches are wanted.
+    int B, N, M, iters, ngroups, GR, GC;
+    // fused arg-max of the match extraction (mdgat.py:441-483): per row over this workgroup's columns, per column over
+    // its rows (merged later); ext_mode < 0: off.  Z may be NULL when only the matches are wanted.
     int ext_mode;
-    int* rbest_idx;      // [B][N]
-    float* rbest_val;    // [B][N]
-    int* cbest_idx;      // [B][4][M]
-    float* cbest_val;    // [B][4][M]
+    int* rbest_idx;      // [B][GC][N]
+    float* rbest_val;    // [B][GC][N]
+    int* cbest_idx;      // [B][GR][M]
+    float* cbest_val;    // [B][GR][M]
 };
 
 constexpr int SKS_THREADS = 512;
 constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8 + 8 * 512;
+constexpr int ROW_STRIDE = 136;
 
-// RPW = rows per wave: 16 -> 128 rows per workgroup, up to 4 workgroups per pair, one workgroup per CU.
-// Per-row quantities (absorbed potential, dustbin-column entry, scaling a) live in lane r of the wave for
-// row r; the scaling is broadcast for the column pass with v_readlane.  Per-column quantities of the
-// lane's 8 columns live in registers; the thread that finalises column t keeps its own copies.
-template <int RPW>
+// Poll the granules `base[p * stride]`, p in [0, n) except `self`, until they carry `tag`; all outstanding partners are
+// polled concurrently.  vals[p] receives the payloads.  Bounded: a timeout sets the error word.
+template <int NMAX>
+__device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, int self, unsigned tag, float (&vals)[NMAX],
+                                              bool& failed, unsigned* error_word) {
+    unsigned pending = ((1u << n) - 1u) & ~(1u << self);
+    unsigned spins = 0;
+    while (pending) {
+        unsigned long long x[NMAX];
+#pragma unroll
+        for (int p = 0; p < NMAX; ++p)
+            if (pending & (1u << p)) x[p] = __hip_atomic_load(base + (size_t)p * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int p = 0; p < NMAX; ++p)
+            if ((pending & (1u << p)) && (unsigned)(x[p] >> 32) == tag) {
+                vals[p] = __builtin_bit_cast(float, (unsigned)x[p]);
+                pending &= ~(1u << p);
+            }
+        if (pending) {
+            if (failed || ++spins > (1u << 22)) { failed = true; atomicOr(error_word, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+// The pair's matrix is tiled GR x GC: workgroup (jr, jc) keeps rows [128 jr, 128 jr + 128) x columns [512 jc, 512 jc + 512)
+// in registers: wave w 16 of those rows, lane l the 8 columns 8 l .. 8 l + 7 (RPW x 8 block, 128 VGPRs).  Per-row
+// quantities (absorbed potential, dustbin-column entry, scaling a) live in lane r of the wave for row r; the scaling is
+// broadcast for the column pass with v_readlane.  Per-column quantities of the lane's 8 columns live in registers; the
+// thread that finalises column t keeps its own copies.  Row sums cross the GC column slabs, column sums the GR row slabs
+// (TWO_D = more than one column slab: N, M up to 2048).
+// GMAX = compile-time bound on the row slabs (4: N <= 512, 16: N <= 2048)
+template <int RPW, bool TWO_D, int GMAX>
 __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArgs a) {
-    constexpr int MAXG = 512 / (8 * RPW);
     __shared__ __attribute__((aligned(16))) float lds[SKS_LDS_FLOATS];
-    float* bvec = lds;                    // [M+1] column scalings (padded to 520)
+    float* bvec = lds;                    // [512] column scalings of the slab, [512] = dustbin column
     float* colp = lds + 520;              // [8 waves][512] per-wave column sums
     float* pdust = colp + 8 * 512;        // [8] per-wave sums of the dustbin column
-    int* flags = reinterpret_cast<int*>(pdust + 8);   // [0]: a column scaling left the safe range
+    int* flags = reinterpret_cast<int*>(pdust + 8);   // [0]: a column scaling of the slab left the safe range
     int* colpi = flags + 8;               // [8 waves][512] row indices of the per-wave column maxima (fused extraction)
 
-    const int N = a.N, M = a.M, G = a.G;
+    const int N = a.N, M = a.M, GR = a.GR, GC = TWO_D ? a.GC : 1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int group, j;
+    const int P = GR * GC;
+    int group, w;
     if ((a.ngroups & 7) == 0) {           // partners share blockIdx % 8 (observed: the XCD)
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
-        j = q % G;
-        group = (q / G) * 8 + xcd;
+        w = q % P;
+        group = (q / P) * 8 + xcd;
     } else {
-        group = blockIdx.x / G;
-        j = blockIdx.x % G;
+        group = blockIdx.x / P;
+        w = blockIdx.x % P;
     }
+    const int jr = w / GC, jc = w % GC;
     const float alpha = (a.alpha_dev ? *a.alpha_dev : a.alpha_host) * MDGAT_LOG2E;
     const float norm = -logf((float)(N + M));
     const float mu = 1.0f / (float)(N + M);                    // exp(log_mu) of mdgat.py:302 (rows 0..N-1)
     const float muN = (float)M / (float)(N + M);               // dustbin row
     const float nu = mu;                                       // columns 0..M-1 (mdgat.py:303)
     const float nuM = (float)N / (float)(N + M);               // dustbin column
-    const int row0 = (j * 8 + wave) * RPW;    // first row of this wave
-    const int col0 = lane * 8;                // first column of this lane
+    const int row0 = (jr * 8 + wave) * RPW;   // first row of this wave
+    const int col0 = lane * 8;                // first local column of this lane
+    const int gcol0 = jc * 512 + col0;        // ... global
     const bool my_row_valid = lane < RPW && row0 + lane < N;   // lane r carries the per-row state of row r
-    gu64* slots = (gu64*)(a.slots) + (size_t)group * 2 * G * SLOT_STRIDE;
-    unsigned epoch = 0;
+    const size_t col_slots = (size_t)2 * GC * GR * SLOT_STRIDE, row_slots = (size_t)2 * GR * GC * ROW_STRIDE;
+    gu64* cslots = (gu64*)(a.slots) + (size_t)group * (col_slots + row_slots);
+    gu64* rslots = cslots + col_slots;
+    unsigned cep = 0, rep_ = 0;           // column / row exchange counters (granule tags)
     bool failed = false;
     const float RANGE_HI = 1.099511627776e12f, RANGE_LO = 9.094947017729282e-13f;   // 2^40, 2^-40
+
+    // sum (or max) of one per-row value (lanes < RPW, plus lane RPW of wave 0 for the dustbin row) over the GC column slabs
+    auto row_exchange = [&](float v, bool take_max) -> float {
+        if (!TWO_D) return v;
+        ++rep_;
+        const bool active = lane <= RPW;          // lane RPW: the dustbin row (every wave publishes / polls the same value)
+        const int idx = lane < RPW ? wave * RPW + lane : 128;
+        float out = v;
+        if (active) {
+            gu64* base = rslots + ((size_t)(rep_ & 1) * GR + jr) * GC * ROW_STRIDE + idx;
+            __hip_atomic_store(base + (size_t)jc * ROW_STRIDE, ((unsigned long long)rep_ << 32) | __builtin_bit_cast(unsigned, v),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float vals[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) vals[p] = take_max ? NEG_BIG : 0.f;
+            poll_partners<4>(base, ROW_STRIDE, GC, jc, rep_, vals, failed, a.error_word);
+            out = take_max ? NEG_BIG : 0.f;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {             // fixed order: bit-identical in every partner (GC <= 4)
+                const float x = (p == jc) ? v : vals[p];
+                out = take_max ? fmaxf(out, x) : out + x;
+            }
+        }
+        return out;
+    };
 
     for (int pair = group; pair < a.B; pair += a.ngroups) {
         const float* S = a.scores + (size_t)pair * N * M;
         // ---- this lane's RPW x 8 block of scores (base-2 log units); invalid entries -> exp2 gives 0 ----
         float K[RPW][8];
-        const bool vec_ok = (M & 3) == 0 && col0 + 8 <= M;
+        const bool vec_ok = (M & 3) == 0 && gcol0 + 8 <= M;
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int i = row0 + r;
             const float* row = S + (size_t)min(i, N - 1) * M;
             if (vec_ok) {
-                const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + col0);
-                const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + col0 + 4);
+                const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + gcol0);
+                const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + gcol0 + 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     K[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
@@ -291,37 +349,46 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float x = row[min(col0 + c, M - 1)];
-                    K[r][c] = (i < N && col0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
+                    const float x = row[min(gcol0 + c, M - 1)];
+                    K[r][c] = (i < N && gcol0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
                 }
             }
         }
-        // ---- absorb the row maximum (dustbin column included): every row of K then has largest entry 1 ----
+        // ---- absorb the row maximum (all column slabs, dustbin column included): every row of K has largest entry <= 1 ----
         float u0r = 0.f, kbr = 0.f, ar = 0.f;     // lane r: absorbed potential, dustbin-column entry, scaling of row r
+        {
+            float mrow = NEG_BIG;
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            float m = K[r][0];
+            for (int r = 0; r < RPW; ++r) {
+                float m = K[r][0];
 #pragma unroll
-            for (int c = 1; c < 8; ++c) m = fmaxf(m, K[r][c]);
-            m = fmaxf(wave_max_dpp(m), alpha);     // wave-uniform
-            if (lane == r) u0r = -m;
+                for (int c = 1; c < 8; ++c) m = fmaxf(m, K[r][c]);
+                m = wave_max_dpp(m);                   // wave-uniform
+                mrow = (lane == r) ? m : mrow;
+            }
+            mrow = fmaxf(row_exchange(mrow, true), alpha);
+            u0r = -mrow;
 #pragma unroll
-            for (int c = 0; c < 8; ++c) K[r][c] = ex2(K[r][c] - m);
+            for (int r = 0; r < RPW; ++r) {
+                const float m = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mrow), r));
+#pragma unroll
+                for (int c = 0; c < 8; ++c) K[r][c] = ex2(K[r][c] - m);
+            }
         }
         if (my_row_valid) { kbr = ex2(alpha + u0r); ar = 1.f; } else { u0r = 0.f; }
         // absorbed dustbin row: u0_N = -alpha, so its entries are exp2(v0_j) = 1
         float u0N = -alpha, aN = 1.f;
         float v0[8], kr[8], b[8];         // per lane column: absorbed potential, dustbin-row entry, column scaling
 #pragma unroll
-        for (int c = 0; c < 8; ++c) { v0[c] = 0.f; kr[c] = (col0 + c < M) ? 1.f : 0.f; b[c] = (col0 + c < M) ? 1.f : 0.f; }
+        for (int c = 0; c < 8; ++c) { v0[c] = 0.f; kr[c] = (gcol0 + c < M) ? 1.f : 0.f; b[c] = (gcol0 + c < M) ? 1.f : 0.f; }
         float v0M = 0.f, kc = 1.f, bM = 1.f;
-        // state of the columns this thread finalises: t = tid (rep 0) and t = tid + 512 (rep 1: only t == M == 512)
-        float krt = 1.f, v0t0 = 0.f, bt0 = 1.f, v0t1 = 0.f, bt1 = 1.f;
+        // state of the columns this thread finalises: local column tid (global 512 jc + tid); thread 0 also the dustbin column
+        const bool tcol_valid = jc * 512 + tid < M;
+        float krt = 1.f, v0t = 0.f, bt = 1.f;
         __syncthreads();                  // previous pair's readers of the LDS vectors are done
         if (tid == 0) flags[0] = 0;
 
         for (int it = 0; it < a.iters; ++it) {
-            ++epoch;
             // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
             float psum = 0.f;
 #pragma unroll
@@ -336,7 +403,12 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 float pd = kr[0] * b[0];
 #pragma unroll
                 for (int c = 1; c < 8; ++c) pd = fmaf(kr[c], b[c], pd);
-                pd = wave_sum_dpp(pd);
+                pd = wave_sum_dpp(pd);                         // dustbin row over this slab's columns
+                if (TWO_D) {
+                    psum = (lane == RPW) ? pd : psum;
+                    psum = row_exchange(psum, false);          // rows of this wave and the dustbin row, over all column slabs
+                    pd = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, psum), RPW));
+                }
                 aN = muN * __builtin_amdgcn_rcpf(fmaf(kc, bM, pd));
             }
             ar = my_row_valid ? mu * __builtin_amdgcn_rcpf(fmaf(kbr, bM, psum)) : 0.f;
@@ -358,43 +430,45 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 if (lane == 0) pdust[wave] = dsum;
             }
             __syncthreads();
-            // ---- merge the 8 waves, exchange with the partner workgroups, new column scalings ----
+            // ---- merge the 8 waves, exchange with the row-slab partners, new column scalings ----
+            ++cep;
+            {
+                gu64* base = cslots + ((size_t)(cep & 1) * GC + jc) * GR * SLOT_STRIDE;
+                const unsigned long long tagbits = (unsigned long long)cep << 32;
+                // (a) every thread: its own column of the slab, all row-slab partners polled concurrently
+                if (tcol_valid) {
+                    float loc = colp[tid];
 #pragma unroll
-            for (int rep = 0; rep < 2; ++rep) {
-                const int t = tid + rep * SKS_THREADS;
-                if (t <= M) {
-                    float loc;
-                    if (t < M) {
-                        loc = colp[t];
+                    for (int ww = 1; ww < 8; ++ww) loc += colp[ww * 512 + tid];
+                    float vals[GMAX];
 #pragma unroll
-                        for (int w = 1; w < 8; ++w) loc += colp[w * 512 + t];
-                    } else {
-                        loc = pdust[0];
-#pragma unroll
-                        for (int w = 1; w < 8; ++w) loc += pdust[w];
-                    }
-                    float vals[MAXG];
-#pragma unroll
-                    for (int pp = 0; pp < MAXG; ++pp) vals[pp] = 0.f;
-                    if (G > 1) {
-                        gu64* base = slots + (size_t)(epoch & 1) * G * SLOT_STRIDE + t;
-                        __hip_atomic_store(base + (size_t)j * SLOT_STRIDE, ((unsigned long long)epoch << 32) | __builtin_bit_cast(unsigned, loc),
+                    for (int pp = 0; pp < GMAX; ++pp) vals[pp] = 0.f;
+                    if (GR > 1) {
+                        __hip_atomic_store(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc),
                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        unsigned pending = ((1u << G) - 1u) & ~(1u << j);
-                        unsigned spins = 0;
-                        while (pending) {
-                            unsigned long long x[MAXG];
+                        poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word);
+                    }
+                    float total = 0.f;
 #pragma unroll
-                            for (int pp = 0; pp < MAXG; ++pp)      // all outstanding partners polled concurrently
-                                if (pending & (1u << pp))
-                                    x[pp] = __hip_atomic_load(base + (size_t)pp * SLOT_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (int pp = 0; pp < GMAX; ++pp) total += (pp == jr) ? loc : vals[pp];   // fixed order: bit-identical in every partner
+                    bt = nu * __builtin_amdgcn_rcpf(fmaf(krt, aN, total));
+                    bvec[tid] = bt;
+                    if (!(bt > RANGE_LO && bt < RANGE_HI)) flags[0] = 1;
+                }
+                // (b) wave 7: the dustbin column (slot 512), lane p polls row slab p
+                if (wave == 7) {
+                    float loc = pdust[0];
 #pragma unroll
-                            for (int pp = 0; pp < MAXG; ++pp)
-                                if ((pending & (1u << pp)) && (unsigned)(x[pp] >> 32) == epoch) {
-                                    vals[pp] = __builtin_bit_cast(float, (unsigned)x[pp]);
-                                    pending &= ~(1u << pp);
-                                }
-                            if (pending) {
+                    for (int ww = 1; ww < 8; ++ww) loc += pdust[ww];
+                    float mine = loc;
+                    if (GR > 1) {
+                        if (lane == 0) __hip_atomic_store(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, loc),
+                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane < GR && lane != jr) {
+                            unsigned spins = 0;
+                            while (true) {
+                                const unsigned long long x = __hip_atomic_load(base + (size_t)lane * SLOT_STRIDE + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if ((unsigned)(x >> 32) == cep) { mine = __builtin_bit_cast(float, (unsigned)x); break; }
                                 if (failed || ++spins > (1u << 22)) { failed = true; atomicOr(a.error_word, 1u); break; }
                                 __builtin_amdgcn_s_sleep(1);
                             }
@@ -402,13 +476,9 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     }
                     float total = 0.f;
 #pragma unroll
-                    for (int pp = 0; pp < MAXG; ++pp) total += (pp == j) ? loc : vals[pp];   // fixed order: bit-identical in every partner
-                    float bt;
-                    if (t < M) bt = nu * __builtin_amdgcn_rcpf(fmaf(krt, aN, total));
-                    else bt = nuM * __builtin_amdgcn_rcpf(fmaf(kc, aN, total));
-                    if (rep == 0) bt0 = bt; else bt1 = bt;
-                    bvec[t] = bt;
-                    if (!(bt > RANGE_LO && bt < RANGE_HI)) flags[0] = 1;
+                    for (int pp = 0; pp < GMAX; ++pp)
+                        if (pp < GR) total += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, mine), pp));
+                    if (lane == 0) bvec[512] = nuM * __builtin_amdgcn_rcpf(fmaf(kc, aN, total));
                 }
             }
             __syncthreads();
@@ -417,14 +487,14 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(bvec + col0 + 4);
                 b[0] = x0[0]; b[1] = x0[1]; b[2] = x0[2]; b[3] = x0[3]; b[4] = x1[0]; b[5] = x1[1]; b[6] = x1[2]; b[7] = x1[3];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) if (col0 + c >= M) b[c] = 0.f;
-                bM = bvec[M];
+                for (int c = 0; c < 8; ++c) if (gcol0 + c >= M) b[c] = 0.f;
+                bM = bvec[512];
             }
             // ---- fold scalings that left [2^-40, 2^40] back into K and the absorbed potentials (rare) ----
-            if (flags[0] != 0) {                   // identical in all partner workgroups (same b everywhere)
+            if (flags[0] != 0) {                   // identical in all row-slab partners (same b for this column slab)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    if (col0 + c < M) {
+                    if (gcol0 + c < M) {
 #pragma unroll
                         for (int r = 0; r < RPW; ++r) K[r][c] *= b[c];
                         v0[c] += lg2(b[c]);
@@ -432,17 +502,17 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                         b[c] = 1.f;
                     }
                 }
+                if (tcol_valid) { krt *= bt; v0t += lg2(bt); bt = 1.f; }
+                __syncthreads();                   // everyone has read the flag and bvec
+                if (tid == 0) flags[0] = 0;
+            }
+            if (!(bM > RANGE_LO && bM < RANGE_HI)) {      // uniform everywhere: bM is replicated bit-identically
                 kbr *= bM;
                 kc *= bM;
                 v0M += lg2(bM);
                 bM = 1.f;
-                if (tid < M) { krt *= bt0; v0t0 += lg2(bt0); bt0 = 1.f; }
-                if (tid == M) { v0t0 += lg2(bt0); bt0 = 1.f; }
-                if (tid + SKS_THREADS == M) { v0t1 += lg2(bt1); bt1 = 1.f; }
-                __syncthreads();                   // everyone has read the flag and bvec
-                if (tid == 0) flags[0] = 0;
             }
-            if (!(aN > RANGE_LO && aN < RANGE_HI)) {      // uniform everywhere: aN is replicated bit-identically
+            if (!(aN > RANGE_LO && aN < RANGE_HI)) {      // uniform everywhere
 #pragma unroll
                 for (int c = 0; c < 8; ++c) kr[c] *= aN;
                 krt *= aN;
@@ -451,8 +521,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 aN = 1.f;
             }
             {
-                const bool fold = my_row_valid && !(ar > RANGE_LO && ar < RANGE_HI);
-                const unsigned long long fm = __ballot(fold);        // rows of this wave to fold (purely local)
+                const bool fold = my_row_valid && !(ar > RANGE_LO && ar < RANGE_HI);   // identical in all column-slab partners
+                const unsigned long long fm = __ballot(fold);
                 if (fm) {
 #pragma unroll
                     for (int r = 0; r < RPW; ++r) {
@@ -469,16 +539,17 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
-        const float poison = (G > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+        const float poison = (P > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
                                  ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
         const float VM = ran ? v0M + lg2(bM) + poison : 0.f;
         const float Ur = (ran && my_row_valid) ? u0r + lg2(ar) : 0.f;    // lane r: potential of row r
         float V[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) V[c] = (ran && col0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
+        for (int c = 0; c < 8; ++c) V[c] = (ran && gcol0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
         const bool ext = a.ext_mode >= 0;
         const bool inner = a.ext_mode >= MDGAT_EXTRACT_THRESHOLD;   // arg-max over the inner N x M block only
+        const bool last_c = jc == GC - 1, last_r = jr == GR - 1;
         float cbv[8];
         int cbi[8];
 #pragma unroll
@@ -492,30 +563,33 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 float z[8];
 #pragma unroll
                 for (int c = 0; c < 8; ++c)
-                    z[c] = (col0 + c < M) ? (row[min(col0 + c, M - 1)] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm : -__builtin_inff();
+                    z[c] = (gcol0 + c < M) ? (row[min(gcol0 + c, M - 1)] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm : -__builtin_inff();
                 const float zM = (alpha + U + VM) * MDGAT_LN2 - norm;
                 if (Zp) {
                     float* zr = Zp + (size_t)i * (M + 1);
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if (col0 + c < M) zr[col0 + c] = z[c];
-                    if (lane == 0) zr[M] = zM;
+                        if (gcol0 + c < M) zr[gcol0 + c] = z[c];
+                    if (last_c && lane == 0) zr[M] = zM;
                 }
                 if (ext) {
-                    // row: first maximal column (torch.max), the dustbin column included unless `inner`
+                    // row: first maximal column of this slab (torch.max); the last slab adds the dustbin column unless `inner`
                     float bv = z[0];
-                    int bi = col0;
+                    int bi = gcol0;
 #pragma unroll
                     for (int c = 1; c < 8; ++c)
-                        if (z[c] > bv) { bv = z[c]; bi = col0 + c; }
+                        if (z[c] > bv) { bv = z[c]; bi = gcol0 + c; }
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) {
                         const float ov = __shfl_xor(bv, o, 64);
                         const int oi = __shfl_xor(bi, o, 64);
                         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                     }
-                    if (!inner && zM > bv) { bv = zM; bi = M; }
-                    if (lane == 0) { a.rbest_idx[(size_t)pair * N + i] = bi; a.rbest_val[(size_t)pair * N + i] = bv; }
+                    if (!inner && last_c && zM > bv) { bv = zM; bi = M; }
+                    if (lane == 0) {
+                        a.rbest_idx[((size_t)pair * GC + jc) * N + i] = bi;
+                        a.rbest_val[((size_t)pair * GC + jc) * N + i] = bv;
+                    }
                     // columns: first maximal row among this wave's rows (ascending, strict compare)
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
@@ -524,14 +598,14 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
         }
         const float UN = ran ? u0N + lg2(aN) : 0.f;
-        const float zN0 = (alpha + UN + (ran ? v0t0 + lg2(bt0) + poison : 0.f)) * MDGAT_LN2 - norm;   // Z[N][tid]
-        if (j == G - 1 && Zp) {
+        const float zNt = (alpha + UN + (ran ? v0t + lg2(bt) + poison : 0.f)) * MDGAT_LN2 - norm;   // Z[N][512 jc + tid]
+        if (last_r && Zp) {
             float* zl = Zp + (size_t)N * (M + 1);
-            if (tid <= M) zl[tid] = zN0;
-            if (tid + SKS_THREADS <= M) zl[tid + SKS_THREADS] = (alpha + UN + (ran ? v0t1 + lg2(bt1) + poison : 0.f)) * MDGAT_LN2 - norm;
+            if (tcol_valid) zl[jc * 512 + tid] = zNt;
+            if (last_c && tid == 0) zl[M] = (alpha + UN + VM) * MDGAT_LN2 - norm;
         }
         if (ext) {
-            // merge the 8 waves (ascending rows), add the dustbin row (last row, only in the last workgroup, not `inner`)
+            // merge the 8 waves (ascending rows), add the dustbin row (last row slab only, not `inner`)
             __syncthreads();             // colp's readers of the last iteration are done
             {
                 f32x4* qw = reinterpret_cast<f32x4*>(colp + wave * 512 + col0);
@@ -542,17 +616,17 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 for (int c = 0; c < 8; ++c) qi[c] = cbi[c];
             }
             __syncthreads();
-            if (tid < M) {
+            if (tcol_valid) {
                 float bv = colp[tid];
                 int bi = colpi[tid];
 #pragma unroll
-                for (int w = 1; w < 8; ++w) {
-                    const float v = colp[w * 512 + tid];
-                    if (v > bv) { bv = v; bi = colpi[w * 512 + tid]; }
+                for (int ww = 1; ww < 8; ++ww) {
+                    const float v = colp[ww * 512 + tid];
+                    if (v > bv) { bv = v; bi = colpi[ww * 512 + tid]; }
                 }
-                if (!inner && j == G - 1 && zN0 > bv) { bv = zN0; bi = N; }
-                a.cbest_val[((size_t)pair * 4 + j) * M + tid] = bv;
-                a.cbest_idx[((size_t)pair * 4 + j) * M + tid] = bi;
+                if (!inner && last_r && zNt > bv) { bv = zNt; bi = N; }
+                a.cbest_val[((size_t)pair * GR + jr) * M + jc * 512 + tid] = bv;
+                a.cbest_idx[((size_t)pair * GR + jr) * M + jc * 512 + tid] = bi;
             }
         }
     }
@@ -567,8 +641,9 @@ struct ExArgs {
     int64_t* m0; int64_t* m1;
     float* s0; float* s1;
     int* valid_count;   // global count of valid frame-0 rows (dustbin modes; mdgat.py:465 quirk)
-    // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests; column bests per row slab, G slabs)
-    const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int G;
+    // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
+    // per row slab [B][GR][M])
+    const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int GR, GC;
 };
 
 __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
@@ -588,14 +663,20 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
 
     if (!a.Z) {
         for (int i = tid; i < N; i += 1024) {
-            idx0[i] = a.rbest_idx[(size_t)blockIdx.x * N + i];
-            val0[i] = a.rbest_val[(size_t)blockIdx.x * N + i];
+            const size_t base = (size_t)blockIdx.x * a.GC * N + i;
+            float bv = a.rbest_val[base];
+            int bi = a.rbest_idx[base];
+            for (int g = 1; g < a.GC; ++g) {         // ascending column slabs, strict compare: first maximal column
+                const float v = a.rbest_val[base + (size_t)g * N];
+                if (v > bv) { bv = v; bi = a.rbest_idx[base + (size_t)g * N]; }
+            }
+            idx0[i] = bi; val0[i] = bv;
         }
         for (int j = tid; j < M; j += 1024) {
-            const size_t base = (size_t)blockIdx.x * 4 * M + j;
+            const size_t base = (size_t)blockIdx.x * a.GR * M + j;
             float bv = a.cbest_val[base];
             int bi = a.cbest_idx[base];
-            for (int g = 1; g < a.G; ++g) {          // ascending row slabs, strict compare: first maximal row
+            for (int g = 1; g < a.GR; ++g) {         // ascending row slabs, strict compare: first maximal row
                 const float v = a.cbest_val[base + (size_t)g * M];
                 if (v > bv) { bv = v; bi = a.cbest_idx[base + (size_t)g * M]; }
             }
@@ -712,11 +793,26 @@ int launch_sk(const SkArgs& a, int B, hipStream_t s) {
 
 }  // namespace
 
-static size_t slots_bytes() { return 256 + (size_t)64 * 2 * 4 * SLOT_STRIDE * sizeof(unsigned long long); }
+// tiling of a pair: GR row slabs of 128 rows x GC column slabs of 512 columns, one workgroup each
+static void sk_tiling(int N, int M, int& GR, int& GC) { GR = (N + 127) / 128; GC = (M + 511) / 512; }
+static int sk_max_groups(int N, int M) {      // pairs in flight on a 256-CU part (upper bound used for sizing)
+    int GR, GC;
+    sk_tiling(N, M, GR, GC);
+    int g = 256 / (GR * GC);
+    return g > 64 ? 64 : (g < 1 ? 1 : g);
+}
+static size_t slots_bytes(int N, int M) {
+    int GR, GC;
+    sk_tiling(N, M, GR, GC);
+    const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
+    return (256 + per_group * sk_max_groups(N, M) + 255) & ~(size_t)255;
+}
 size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
-    if (N > 512 || M > 512) return 0;
-    // exchange slots + fused arg-max scratch: row bests [B][N] (int + float), column bests [B][4][M] (int + float)
-    return slots_bytes() + ((size_t)B * N * 2 + (size_t)B * 4 * M * 2) * sizeof(float);
+    if (N > 2048 || M > 2048) return 0;
+    int GR, GC;
+    sk_tiling(N, M, GR, GC);
+    // exchange slots + fused arg-max scratch: row bests [B][GC][N] (int + float), column bests [B][GR][M] (int + float)
+    return slots_bytes(N, M) + ((size_t)B * GC * N * 2 + (size_t)B * GR * M * 2) * sizeof(float);
 }
 
 static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s);
@@ -724,33 +820,36 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s);
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
                           float* Z, void* ws, int num_cu, const SkExtract* ex, hipStream_t s) {
     constexpr int RPW = 16;
-    const int G = (N + 8 * RPW - 1) / (8 * RPW);   // workgroups per pair
-    const int occ = RPW == 8 ? 2 : 1;              // resident workgroups per CU by registers
-    int ngroups = (num_cu * occ) / G;
-    if (ngroups > 64) ngroups = 64;
+    int GR, GC;
+    sk_tiling(N, M, GR, GC);
+    const int P = GR * GC;                         // workgroups per pair, one per CU
+    int ngroups = num_cu / P;
+    if (ngroups > sk_max_groups(N, M)) ngroups = sk_max_groups(N, M);
     if (ngroups > B) ngroups = B;
     if (ngroups >= 8) ngroups &= ~7;
-    if (ngroups < 1) return MDGAT_ERR_UNSUPPORTED;
-    const size_t ws_bytes = 256 + (size_t)ngroups * 2 * G * SLOT_STRIDE * sizeof(unsigned long long);
-    if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, ws_bytes, s), "memset(sinkhorn slots)")) return rc;
+    if (ngroups < 1) { mdgat_set_error("sinkhorn: %d workgroups per pair do not fit the device", P); return MDGAT_ERR_UNSUPPORTED; }
+    const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
+    if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, G, -1, nullptr, nullptr, nullptr, nullptr};
+              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, GR, GC, -1, nullptr, nullptr, nullptr, nullptr};
     if (ex) {
-        char* p = static_cast<char*>(ws) + slots_bytes();
+        char* p = static_cast<char*>(ws) + slots_bytes(N, M);
         a.ext_mode = ex->mode;
-        a.rbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * N * sizeof(int);
-        a.rbest_val = reinterpret_cast<float*>(p);                    p += (size_t)B * N * sizeof(float);
-        a.cbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * 4 * M * sizeof(int);
+        a.rbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * GC * N * sizeof(int);
+        a.rbest_val = reinterpret_cast<float*>(p);                    p += (size_t)B * GC * N * sizeof(float);
+        a.cbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * GR * M * sizeof(int);
         a.cbest_val = reinterpret_cast<float*>(p);
     }
     void* args[] = {&a};
-    // cooperative launch: the runtime checks that all ngroups * G workgroups can be co-resident
-    hipError_t e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW>), dim3(ngroups * G),
-                                              dim3(SKS_THREADS), args, 0, s);
+    // cooperative launch: the runtime checks that all ngroups * P workgroups can be co-resident
+    const void* kern = GC > 1 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, true, 16>)
+                     : GR > 4 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 16>)
+                              : reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 4>);
+    hipError_t e = hipLaunchCooperativeKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
     if (ex) {
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr,
-                 a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, G};
+                 a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s);
     }
     return MDGAT_OK;
@@ -815,6 +914,6 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s) {
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1};
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, a, s);
 }

@@ -37,6 +37,12 @@ def main():
             continue
         ms = t_ms(fn)
         print(f'{name}: {ms:.4f} ms  ({fl / ms / 1e9:.1f} TFLOP/s fp32-equivalent, incl. the fp32->f16 split pre-pass)')
+    if not only or 'post' in only:
+        k0 = torch.randn(B, n, 3, device=dev, generator=g) * 20
+        k1 = torch.randn(B, n, 3, device=dev, generator=g) * 20
+        m0 = torch.randint(-1, n, (B, n), device=dev, generator=g)
+        print(f'pose_from_matches: {t_ms(lambda: ops.pose_from_matches(k0, k1, m0)):.4f} ms')
+        print(f'gt_matches: {t_ms(lambda: ops.gt_matches(k0, k1)):.4f} ms')
     if only and 'sinkhorn' not in only:
         return
     scores = torch.randn(B, n, n, device=dev, generator=g) * 3
