@@ -152,10 +152,13 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         for (int jb = 0; jb < NBLK; ++jb) {
 #pragma unroll
             for (int r = 0; r < 16; r += 4) {
-                acc0 = __builtin_amdgcn_alignbit(acc0, __builtin_bit_cast(unsigned, S[jb][r + 0] - t), 31);
-                acc1 = __builtin_amdgcn_alignbit(acc1, __builtin_bit_cast(unsigned, S[jb][r + 1] - t), 31);
-                acc2 = __builtin_amdgcn_alignbit(acc2, __builtin_bit_cast(unsigned, S[jb][r + 2] - t), 31);
-                acc3 = __builtin_amdgcn_alignbit(acc3, __builtin_bit_cast(unsigned, S[jb][r + 3] - t), 31);
+                // four independent chains, kept interleaved (the scheduler would otherwise run them one after the other)
+                const float d0 = S[jb][r + 0] - t, d1 = S[jb][r + 1] - t, d2 = S[jb][r + 2] - t, d3 = S[jb][r + 3] - t;
+                // (volatile asm keeps this order; the builtin form gets re-associated into one chain per accumulator)
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc0) : "v"(d0));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc1) : "v"(d1));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc2) : "v"(d2));
+                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc3) : "v"(d3));
             }
             if ((jb & 7) == 7 || jb == NBLK - 1) {     // 4 x 32 sign bits collected
                 below += __builtin_popcount(acc0) + __builtin_popcount(acc1) + __builtin_popcount(acc2) + __builtin_popcount(acc3);
