@@ -68,54 +68,19 @@ struct WaveComm {
         return c + xor32i(c);
     }
 };
-// SplitComm: the keys of a row are split over waves w and w ^ 4 of an 8-wave workgroup (same lane = same
-// query).  Partials cross through a double-buffered LDS slot with ONE barrier per exchange; every wave of the
-// workgroup makes the same sequence of calls (the search below is lockstep by construction).
-struct SplitComm {
-    float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
-    int wave, lane, par;
-    __device__ __forceinline__ float exch(float v) {
-        float* b = buf + par * 512;
-        b[wave * 64 + lane] = v;
-        __syncthreads();
-        const float o = b[(wave ^ 4) * 64 + lane];
-        par ^= 1;
-        return o;
-    }
-    __device__ __forceinline__ float rsum(float v) { v += xor32(v); return v + exch(v); }
-    __device__ __forceinline__ int rsum(int v) { v += xor32i(v); return v + __builtin_bit_cast(int, exch(__builtin_bit_cast(float, v))); }
-    __device__ __forceinline__ float rmin(float v) { v = fminf(v, xor32(v)); return fminf(v, exch(v)); }
-    __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, xor32(v)); return fmaxf(v, exch(v)); }
-    __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p) != 0; }
-    __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) {
-        mn = fminf(mn, xor32(mn)); sum += xor32(sum); sq += xor32(sq);
-        float* b0 = buf + par * 512;          // three values per lane pair: lanes < 32 carry (mn, sum), lanes >= 32 carry sq
-        float* b1 = buf + (par ^ 1) * 512;    // (both slots: once per row, followed by a second barrier)
-        b0[wave * 64 + lane] = lane < 32 ? mn : sq;
-        b1[wave * 64 + lane] = sum;
-        __syncthreads();
-        const int o = (wave ^ 4) * 64;
-        mn = fminf(mn, b0[o + (lane & 31)]);
-        sq += b0[o + 32 + (lane & 31)];
-        sum += b1[o + lane];
-        __syncthreads();
-    }
+// QuadComm: the row lives in four lanes of one wave (l & 15 = query; 16x16 MFMA fragments).
+struct QuadComm {
+    __device__ __forceinline__ float rsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+    __device__ __forceinline__ int rsum(int v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+    __device__ __forceinline__ float rmin(float v) { v = fminf(v, __shfl_xor(v, 16, 64)); return fminf(v, __shfl_xor(v, 32, 64)); }
+    __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+    __device__ __forceinline__ bool any(bool p) { return __any(p); }
+    __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) { mn = rmin(mn); sum = rsum(sum); sq = rsum(sq); }
     __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
-        c += xor32i(c);
-        float* b = buf + par * 512;
-        b[wave * 64 + lane] = __builtin_bit_cast(float, c);
-        if (lane == 0) reinterpret_cast<int*>(buf)[1024 + par * 8 + wave] = 0;
-        __builtin_amdgcn_wave_barrier();
-        if (probing) reinterpret_cast<int*>(buf)[1024 + par * 8 + wave] = 1;
-        __syncthreads();
-        const int* f = reinterpret_cast<const int*>(buf) + 1024 + par * 8;
-        any_probing = (f[0] | f[1] | f[2] | f[3] | f[4] | f[5] | f[6] | f[7]) != 0;
-        const int o = __builtin_bit_cast(int, b[(wave ^ 4) * 64 + lane]);
-        par ^= 1;
-        return c + o;
+        any_probing = __any(probing);
+        return rsum(c);
     }
 };
-
 // Exact k-th largest logit of every row (this wave holds 16 NBLK logits of the row per lane; Comm combines
 // the partials of a row).  Probe thresholds t, count(s >= t) per row, keep a bracket lo < thr <= hv with counts
 // clo > k > chi.  The first probe is the normal quantile of the row (mean + zq * sd); later probes step by
@@ -450,19 +415,18 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
     }
 }
 
-// Dynamic attention for exactly 512 keys per frame with TWO waves per query tile: waves w and w + 4 of an
-// 8-wave workgroup serve the same 32 queries, wave w keys [0, 256), wave w + 4 keys [256, 512).  Each keeps
-// its half row in 128 registers (two waves per SIMD instead of one wave with 256 registers spread over the
-// VGPR / AGPR halves); row maximum, top-k counts (SplitComm), the row sum and the output partials cross
-// through LDS.
-__global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a) {
-    constexpr int NBLK = 8;
+// Dynamic attention for exactly 512 keys per frame, one wave = 16 queries, no cross-wave traffic at all:
+// S^T = K Q^T on v_mfma_f32_16x16x32_f16 (the whole 32-dim head in one k-step) puts the logits of a query in the
+// four lanes (q, q + 16, q + 32, q + 48): lane (q, g) holds keys 16 b + 4 g + r of every 16-key block b, 128 registers
+// for 512 keys, two waves per SIMD.  Row statistics and top-k counts are two lane shuffles (QuadComm), so the 8 waves
+// of the workgroup search independently.  K sits in LDS as [plane][dim chunk g][key] 16-byte units (conflict free for
+// this fragment shape), V^T as in the other kernels; P.V pairs two key blocks per k-step.
+__global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int qgroup = wave & 3, khalf = wave >> 2;
+    const int l15 = lane & 15, g = lane >> 4;
     const int head = blockIdx.y;
     const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
     const int P = a.N + a.M;
@@ -473,11 +437,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a
     const int k_off = src ? a.N : 0;
     constexpr int VSTR = 512 + 8;
 
-    _Float16* Ks = smem;                          // [512][KROWH]
-    _Float16* Vs = smem + 512 * KROWH;            // [2 planes][32 dims][VSTR]
-    float* xbuf = reinterpret_cast<float*>(Vs + 64 * VSTR);   // SplitComm: 1040 floats
-    float* obuf = xbuf + 1040;                    // [4 query groups][17][64]: output partials and row sums of the upper key half
-
+    _Float16* Ks = smem;                          // [2 planes][4 chunks][512 keys][8 halves]
+    _Float16* Vs = smem + 2 * 4 * 512 * 8;        // [2 planes][32 dims][VSTR]
     {
         const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
         for (int base = tid; base < 512 * 8; base += 4 * 512) {
@@ -490,7 +451,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * 512;
-                *reinterpret_cast<f32x4*>(Ks + (idx >> 3) * KROWH + (idx & 7) * 8) = x[u];
+                const int key = idx >> 3, c = idx & 7;           // c = plane * 4 + chunk
+                *reinterpret_cast<f32x4*>(Ks + ((size_t)c * 512 + key) * 8) = x[u];
             }
         }
         const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
@@ -510,105 +472,100 @@ __global__ __launch_bounds__(512, 2) void attention_topk_split_kernel(AttnArgs a
     }
     __syncthreads();
 
-    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);   // bits 2 <-> 3
-    SplitComm comm{xbuf, wave, lane, 0};
-    const int npass = (nq + 127) / 128;       // every wave runs every pass (barriers inside)
-
-    for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
-        const int qw = pass * 128 + qgroup * 32;
-        f16x8 qh[2], ql[2];
+    QuadComm comm;
+    for (int q0 = blockIdx.x * 128; q0 < nq; q0 += gridDim.x * 128) {
+        const int qw = q0 + wave * 16;
+        if (qw >= nq) continue;             // wave-uniform; no barrier inside the loop
+        // query fragment: dims 8 g .. 8 g + 7 of query l15 (B operand), planes hi / lo
+        f16x8 qh, ql;
         {
-            const int qrow = min(qw + l31, nq - 1);
-            const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * hi;
-            qh[0] = *reinterpret_cast<const f16x8*>(p);
-            qh[1] = *reinterpret_cast<const f16x8*>(p + 16);
-            ql[0] = *reinterpret_cast<const f16x8*>(p + 32);
-            ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
+            const int qrow = min(qw + l15, nq - 1);
+            const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * g;
+            qh = *reinterpret_cast<const f16x8*>(p);
+            ql = *reinterpret_cast<const f16x8*>(p + 32);
         }
-        f32x16 S[NBLK];
+        // ---- S^T: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
+        f32x16 S[8];
 #pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb) {
-            const _Float16* kp = Ks + ((khalf * NBLK + jb) * 32 + krow) * KROWH + 8 * hi;
-            const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
-            const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
-            const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
-            const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-            f32x16 acc, acx;
+        for (int c = 0; c < 8; ++c) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
-            acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) {
+                const int blk = 4 * c + j;
+                const _Float16* kp = Ks + ((size_t)g * 512 + blk * 16 + l15) * 8;     // A operand: key l15 of the block, dims 8 g ..
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kp);
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + 4 * 512 * 8);
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
-            S[jb] = acc;
+                for (int r = 0; r < 4; ++r) S[c][4 * j + r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+            }
         }
         float m = -__builtin_inff();
 #pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb)
+        for (int c = 0; c < 8; ++c)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
+            for (int r = 0; r < 16; ++r) m = fmaxf(m, S[c][r]);
         m = comm.rmax(m);
-        const float thr = topk_threshold<NBLK, true>(S, m, a.topk, nk, a.zq, comm);
+        const float thr = topk_threshold<8, true>(S, m, a.topk, nk, a.zq, comm);
 
+        // ---- P' = 2048 exp2(s - m), masked; O = P' V with two key blocks per k-step ----
         const float m11 = m - 11.0f;
         float l = 0.f;
-        f32x16 Om, Ox;
+        f32x4 Om[2], Ox[2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+        for (int t = 0; t < 2; ++t) { Om[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ox[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int jb = 0; jb < NBLK; ++jb) {
+        for (int c = 0; c < 8; ++c) {
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int jj = 0; jj < 2; ++jj) {             // key blocks 4 c + 2 jj and 4 c + 2 jj + 1
                 float p[8];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float s = S[jb][8 * t + j];
+                for (int i = 0; i < 8; ++i) {
+                    const float s = S[c][8 * jj + i];
                     float e = __builtin_amdgcn_exp2f(s - m11);
                     e = (s >= thr) ? e : 0.f;
-                    p[j] = e;
+                    p[i] = e;
                     l += e;
                 }
                 f16x8 ph, pl;
                 split8(p, ph, pl);
-                const _Float16* vp = Vs + l31 * VSTR + (khalf * NBLK + jb) * 32 + t * 16 + 8 * hi;
-                const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
-                const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
-                Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
-                Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
-                Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                const int key0 = (4 * c + 2 * jj) * 16 + 4 * g;  // this lane's keys: key0 .. key0 + 3 and key0 + 16 .. key0 + 19
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {                   // dims 16 t + l15
+                    const _Float16* vp = Vs + (16 * t + l15) * VSTR + key0;
+                    f16x8 vh, vl;
+                    const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vp), vh1 = *reinterpret_cast<const f16x4*>(vp + 16);
+                    const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vp + 32 * VSTR), vl1 = *reinterpret_cast<const f16x4*>(vp + 32 * VSTR + 16);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { vh[i] = vh0[i]; vh[4 + i] = vh1[i]; vl[i] = vl0[i]; vl[4 + i] = vl1[i]; }
+                    Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, Om[t], 0, 0, 0);
+                    Ox[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, Ox[t], 0, 0, 0);
+                    Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, Om[t], 0, 0, 0);
+                }
             }
         }
-        l += xor32(l);
-        // ---- the upper key half hands its partial output and row sum to the lower half ----
-        float* ob = obuf + qgroup * 17 * 64;
-        if (khalf == 1) {
+        l = comm.rsum(l);
+        const float inv_l = 1.0f / l;
+        // ---- message rows: lane (dim l15 (+16 t), g) holds queries 4 g + r ----
+        float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l15;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]);
-            ob[16 * 64 + lane] = l;
-        }
-        __syncthreads();
-        if (khalf == 0 && qw < nq) {
-            const float inv_l = 1.0f / (l + ob[16 * 64 + lane]);
-            float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = mfma32_row(r, hi);
-                const float inv = __shfl(inv_l, row, 64);
-                const int q = qw + row;
-                const float o = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]) + ob[r * 64 + lane];
-                if (q < nq) out[(size_t)q * 128] = o * inv;
+        for (int r = 0; r < 4; ++r) {
+            const int row = 4 * g + r;
+            const float inv = __shfl(inv_l, row, 64);
+            const int q = qw + row;
+            if (q < nq) {
+                out[(size_t)q * 128] = fmaf(Ox[0][r], MDGAT_SPLIT_INV, Om[0][r]) * inv;
+                out[(size_t)q * 128 + 16] = fmaf(Ox[1][r], MDGAT_SPLIT_INV, Om[1][r]) * inv;
             }
         }
-        __syncthreads();     // obuf is reused by the next pass
     }
 }
 
 // WideComm: the keys of a row are spread over NW consecutive waves of an 8-wave workgroup (same lane = same
-// query).  Same protocol as SplitComm: one barrier per exchange, every wave makes the same calls.
+// query).  Partials cross through a double-buffered LDS slot with ONE barrier per exchange; every wave of the
+// workgroup makes the same sequence of calls (the search is lockstep by construction).
 template <int NW>
 struct WideComm {
     float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
@@ -917,13 +874,13 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
         if (nblk <= 4) go(attention_kernel<true, 4, false, false>, 512);
         else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false>, 512); else go(attention_kernel<true, 8, false, false>, 512); }
         else if (N == 512 && M == 512) {
-            // 512 keys in both frames: the split-key kernel (two waves per query tile)
-            const size_t lds2 = ((size_t)512 * KROWH + (size_t)64 * 520) * sizeof(_Float16) + (1040 + 4 * 17 * 64) * sizeof(float);
+            // 512 keys in both frames: one wave = 16 queries, the row in four lanes
             int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
             if (qsplit > 4) qsplit = 4;
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk_split_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
-            hipLaunchKernelGGL(attention_topk_split_kernel, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds2, s, a);
+            const size_t lds3 = ((size_t)2 * 4 * 512 * 8 + (size_t)64 * 520) * sizeof(_Float16);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL(attention_topk16_kernel, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
         } else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
         else return launch_attention_topk_wide(a, B, nk_max, s);
     } else {
