@@ -93,20 +93,38 @@ template <int NBLK, bool EXACT, typename Comm>
 __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
     const float INF = __builtin_inff();
     float smin = INF, sum = 0.f, sq = 0.f;
+    float mu, sd;
+    if (EXACT) {
+        // every logit is finite; mean and deviation only seed the search: every 4th register is enough for them
 #pragma unroll
-    for (int jb = 0; jb < NBLK; ++jb)
+        for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float s = S[jb][r];
-            if (!EXACT) { smin = fminf(smin, s == -INF ? INF : s); s = (s == -INF) ? 0.f : s; }
-            else smin = fminf(smin, s);
-            sum += s;
-            sq = fmaf(s, s, sq);
-        }
-    comm.stats(smin, sum, sq);
-    const float inv_n = 1.0f / (float)nk;
-    const float mu = sum * inv_n;
-    const float sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
+            for (int r = 0; r < 16; r += 4) {
+                const float s = S[jb][r];
+                smin = fminf(fminf(smin, s), fminf(fminf(S[jb][r + 1], S[jb][r + 2]), S[jb][r + 3]));
+                sum += s;
+                sq = fmaf(s, s, sq);
+            }
+        comm.stats(smin, sum, sq);
+        const float inv_n = 4.0f / (float)nk;
+        mu = sum * inv_n;
+        sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
+    } else {
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float s = S[jb][r];
+                smin = fminf(smin, s == -INF ? INF : s);
+                s = (s == -INF) ? 0.f : s;
+                sum += s;
+                sq = fmaf(s, s, sq);
+            }
+        comm.stats(smin, sum, sq);
+        const float inv_n = 1.0f / (float)nk;
+        mu = sum * inv_n;
+        sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
+    }
     const float inv_sd = 1.0f / sd;
     // count(s >= t) without the VCC-serialised compare/add-carry chain: the sign bits of s - t are shifted into
     // four independent accumulators (v_alignbit) and counted 32 at a time (v_bcnt)
@@ -135,13 +153,17 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     auto count_ge = [&](float t) { return comm.rsum(count_local(t)); };
     float thr = -INF;
     float lo = smin, hv = m;
-    int clo = nk, chi = count_ge(m);
-    // state: 0 probing, 1 done, 2 finish from above (k - chi == 1), 3 finish from below (clo - k == 1)
+    // ties AT the maximum only matter for tiny k (with chi taken as 1 a tied maximum still ends in "collapsed", which
+    // keeps all ties); the exact count costs a pass, so it is only made when it can change the outcome
+    int clo = nk, chi = (!EXACT || k <= 4) ? count_ge(m) : 1;
+    // state: 0 probing, 1 done, 2 finish from above (k - chi == 1), 3 finish from below (clo - k == 1; !EXACT only:
+    // with whole blocks two more probes are cheaper than the three passes of that finish)
     int state = 0;
+    bool hv_est = EXACT && k > 4;                    // chi is still the assumption, not a measured count
     if (chi >= k) { thr = m; state = 1; }            // ties at the maximum (or k == 1)
-    if (nk <= k) { thr = smin; state = 1; }          // this frame has exactly k keys: keep all
+    if (nk <= k) { thr = -INF; state = 1; }          // this frame has exactly k keys: keep all
     if (state == 0 && k - chi == 1) state = 2;
-    if (state == 0 && clo - k == 1) state = 3;
+    if (!EXACT && state == 0 && clo - k == 1) state = 3;
     float t = mu + zq * sd;
     for (int it = 0; it < 64; ++it) {
         if (!(t > lo && t < hv)) {
@@ -149,16 +171,18 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
             if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
         }
         const bool collapsed = !(t > lo && t < hv);   // no float strictly inside the bracket
+        if (EXACT && collapsed && hv_est) t = hv;      // the count at the maximum was assumed: this pass measures it
         bool any_probing;
         const int c = comm.count_vote(count_local(t), state == 0, any_probing);   // one exchange per probe
         if (!any_probing) break;                       // every row had finished before this probe
         if (state == 0) {
-            if (collapsed) { thr = lo; state = 1; }            // ties at the k-th value: keep them all
+            // ties at the k-th value: keep them all (k or more of them at the maximum: only those)
+            if (collapsed) { thr = (EXACT && hv_est && c >= k) ? hv : lo; state = 1; }
             else if (c == k) { thr = t; state = 1; }
             else {
-                if (c > k) { lo = t; clo = c; } else { hv = t; chi = c; }
+                if (c > k) { lo = t; clo = c; } else { hv = t; chi = c; hv_est = false; }
                 if (k - chi == 1) state = 2;
-                else if (clo - k == 1) state = 3;
+                else if (!EXACT && clo - k == 1) state = 3;
                 else {
                     const float z = (t - mu) * inv_sd;
                     const float dens = (float)nk * 0.3989422804f * inv_sd * __builtin_amdgcn_exp2f(-0.7213475204f * z * z);
@@ -178,7 +202,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         mx = comm.rmax(mx);
         if (state == 2) thr = mx;
     }
-    if (comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
+    if (!EXACT && comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
         float e1 = INF;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)

@@ -138,6 +138,30 @@ def test_attention_topk_with_ties():
     assert torch.isfinite(out).all()
 
 
+@pytest.mark.parametrize('n', [256, 512, 1024])
+def test_attention_topk_unmeasured_bracket_ends(n):
+    # Shapes whose rows fill whole 32-key blocks seed the threshold search from sub-sampled statistics and an
+    # assumed count at the maximum; these rows force the search to measure both ends after all:
+    #  (a) k-th value far below mean - 8 sd (three outlier keys, k drops only two of them),
+    #  (b) more than k keys tied at the maximum (identical keys AND values: any k of them give the same message).
+    rs = np.random.RandomState(n)
+    qkv = torch.from_numpy(rs.standard_normal((2, 2 * n, 3, 4, 32)))
+    qkv[:, :, 0, :, 0] = 5.0
+    a = qkv.clone()
+    a[:, [3, 77, n - 1], 1, :, 0] = -200.0
+    a[:, [n + 5, n + 64, 2 * n - 2], 1, :, 0] = -200.0
+    b = qkv.clone()
+    for base in (0, n):
+        b[:, base + 20:base + 30, 1:] = b[:, base + 20:base + 21, 1:]
+        b[:, base + 20:base + 30, 1, :, 0] = 200.0
+    for x, k in ((a, n - 2), (b, 8)):
+        out = ops.attention(x.to(DEV), n, n, False, topk=k).cpu().double()
+        for lo, hi in ((0, n), (n, 2 * n)):
+            q, kk, v = (x[:, lo:hi, i].permute(0, 3, 2, 1) for i in range(3))
+            ref, _ = O.dynamic_attention(q, kk, v, k)
+            assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < 1e-5
+
+
 @pytest.mark.parametrize('tag', ['sk_7x5', 'sk_64x64', 'sk_48x64'])
 def test_sinkhorn_golden(golden_dir, tag):
     g = _g(golden_dir, 'op_vectors')
