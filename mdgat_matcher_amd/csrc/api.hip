@@ -67,9 +67,13 @@ struct mdgat_handle {
     long long prof_launches[MDGAT_PROF_CLASSES];
 };
 
-// split-weight buffer: per layer [w1 256x2x256 | w2 128x2x256 | qkv 384x2x128], then final_proj 128x2x128
-static constexpr size_t WS_W1 = 0, WS_W2 = 256 * 512, WS_QKV = WS_W2 + 128 * 512, WS_LAYER = WS_QKV + 384 * 256;
-static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + 128 * 256 + MDGAT_ENC_SPLIT_HALVES; }
+// split-weight buffer: per layer the LDS images of layer.hip [w1 256 rows x 520 | w2 128 x 520 | qkv 384 x 264]
+// (row = hi plane | lo plane | 16 B pad, zero filled), then final_proj 128 x 264, then the encoder matrices.
+// The stage copies of layer.hip read whole KB: up to 512 B past a K = 256 block, hence the slack after final_proj.
+static constexpr size_t WS_ROW256 = 520, WS_ROW128 = 264;
+static constexpr size_t WS_W1 = 0, WS_W2 = 256 * WS_ROW256, WS_QKV = WS_W2 + 128 * WS_ROW256, WS_LAYER = WS_QKV + 384 * WS_ROW128;
+static constexpr size_t WS_FINAL = 128 * WS_ROW128 + 512;
+static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + WS_FINAL + MDGAT_ENC_SPLIT_HALVES; }
 
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
@@ -98,6 +102,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMalloc(split weights)");
+    if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMemset(split weights)");
     (void)hipSetDevice(prev);
     if (rc) { if (h->weights) (void)hipFree(h->weights); delete h; return rc; }
     *out = h;
@@ -124,18 +129,18 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
     for (int i = 0; i < 2 * h->cfg.L && !rc; ++i) {
         const float* lw = h->weights + bl.layer0 + (size_t)i * bl.layer_stride;
         _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
-        rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, nullptr);
-        if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, nullptr);
-        if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, nullptr);
+        rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, WS_ROW256, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, WS_ROW256, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, WS_ROW128, nullptr);
     }
-    if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, nullptr);
+    if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, WS_ROW128, nullptr);
     {
-        _Float16* es = h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L) + 128 * 256;
-        if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.kenc2_w, es + 64 * 64, 128, 64, nullptr);
+        _Float16* es = h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L) + WS_FINAL;
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, 64, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc2_w, es + 64 * 64, 128, 64, 128, nullptr);
         if (!rc) rc = launch_split_rows_pad(h->weights + bl.denc0_w, es + 64 * 64 + 128 * 128, 64, 33, 48, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.denc1_w, es + 64 * 64 + 128 * 128 + 64 * 96, 128, 64, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.encl_w, es + 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128, 128, 256, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.denc1_w, es + 64 * 64 + 128 * 128 + 64 * 96, 128, 64, 128, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.encl_w, es + 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128, 128, 256, 512, nullptr);
     }
     if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "split weights");
     (void)hipSetDevice(prev);
@@ -250,7 +255,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         EncoderLaunch e{};
         e.kpts0 = kpts0; e.sigma0 = sigma0; e.fpfh0 = fpfh0; e.kpts1 = kpts1; e.sigma1 = sigma1; e.fpfh1 = fpfh1;
         e.rec0 = rec0; e.rec1 = rec1; e.normalize = normalize_fpfh;
-        e.w = w; e.bl = &bl; e.es = h->wsplit + WS_LAYER * (size_t)L2 + 128 * 256;
+        e.w = w; e.bl = &bl; e.es = h->wsplit + WS_LAYER * (size_t)L2 + WS_FINAL;
         e.x = ws.x; e.B = B; e.N = N; e.M = M;
         if ((rc = launch_encoder(e, s))) return rc;
     }

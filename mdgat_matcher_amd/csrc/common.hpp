@@ -98,7 +98,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
 // fused layer tail (layer.hip): [mlp.0 -> mlp.3 -> residual] of one layer + q|k|v projection of the next
 struct LayerLaunch {
     float* x; const float* msg;
-    const _Float16 *w1s, *w2s, *w3s;   // split weights [rows][2][K]
+    const _Float16 *w1s, *w2s, *w3s;   // split weight images [rows][hi K | lo K | 8 pad]
     const float *b1, *b2, *b3;
     Qkv16 out;                         // mode3 == 1
     float* mdesc;                      // mode3 == 2
@@ -107,7 +107,7 @@ struct LayerLaunch {
     int mode3;                         // 1: q|k|v, 2: final_proj
 };
 int launch_layer(const LayerLaunch& p, hipStream_t s);
-int launch_split_rows(const float* w, _Float16* out, int rows, int K, hipStream_t s);
+int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, hipStream_t s);   // rowh >= 2 K: row pitch (halves)
 
 struct SkExtract {   // match extraction to run after (or fused into) the Sinkhorn kernel
     int mode; float thr;

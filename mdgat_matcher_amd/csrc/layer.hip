@@ -15,171 +15,266 @@
 // output channels per 32-channel row block.  The W rows are fed in a permuted order (bits 2 and 3 of
 // the row index swapped) so that the 8 registers of a half block are 8 CONSECUTIVE channels - which is
 // exactly the B-operand fragment of the next product (k-slots 8 hi .. 8 hi + 7 of a 16-deep k-step).
-// So relu(hid) and the new x are split to f16 in place and feed the next GEMM without touching LDS or
-// memory; only x (fp32, for the residual) and the q/k/v operands are written.  The weights (pre-split
-// at load time, [row][hi plane | lo plane]) stream through LDS one 32-row block at a time (33 KB,
-// double buffered, 24 stages per tile), shared by the 4 waves; rows are padded by 16 bytes so that the
-// ds_read_b128 fragment reads are bank-conflict free.  V uses the non-swapped product (the same x
-// fragments as A operand) so that a lane holds 4 consecutive keypoints of one dim: 8-byte stores into
-// the transposed V^T layout.  One wave per SIMD (about 370 registers), the MFMA pipe is the bound.
+// So relu(hid) and the new x are split to f16 in place and feed the next GEMM without touching memory.
+//
+// Weights: pre-split at load time into the LDS image itself ([row][hi plane | lo plane | 16 B pad], the pad
+// makes the ds_read_b128 fragment reads conflict free), so a stage (32 rows of K = 256 or 64 rows of K = 128,
+// 33 KB) is a flat copy: global_load_lds_dwordx4 moves it L2 -> LDS without passing through registers, issued at
+// the start of the stage that precedes its use, double buffered, one barrier per stage (18 stages per tile).
+//
+// One wave per SIMD (its 32 keypoints need ~430 registers), so nothing but the wave's own instruction stream
+// can overlap the matrix pipe with the rest: the epilogue of block n (accumulator combine, bias, ReLU, f16
+// split, output staging and stores) is sliced and issued inside the k-loop of block n + 1 (block_mma_il), two
+// accumulator sets alternate.
+//
+// Global traffic is whole rows only: a wave-private LDS tile transposes between "a half wave / 8 lanes / 4
+// lanes per contiguous row" (what the memory system wants) and the fragment order (what the MFMAs want).
+// V uses the non-swapped product (a lane holds 4 consecutive keypoints of one dim) for the transposed V^T layout.
 #include "common.hpp"
 #include "mma_chain.hpp"
 
-
 namespace {
 
-constexpr int ROWH256 = 520;                 // LDS row (halves) for K = 256: 256 hi | 256 lo | 8 pad
-constexpr int STAGE_HALVES = 32 * ROWH256;   // one staging buffer (33280 B)
+constexpr int ROWH256 = 520;                 // LDS / image row (halves) for K = 256: 256 hi | 256 lo | 8 pad
+constexpr int ROWH128 = 264;                 // K = 128
+constexpr int STAGE_BYTES = 33 * 1024;       // one staging buffer: 33 DMA chunks (32 x 1040 B rounded up, or 64 x 528 B)
+constexpr int STAGE_HALVES = STAGE_BYTES / 2;
+constexpr int TROW = 132;                    // floats per row of a wave's activation tile (128 channels + 16 B pad)
+constexpr int TILE_FLOATS = 32 * TROW;       // [32 keypoints][TROW]: 16896 B per wave
+constexpr int QKROW = 72;                    // halves per row of the q/k store tile (32 hi | 32 lo | 16 B pad)
+constexpr int VROW = 40;                     // halves per row of the V^T store tile (32 keypoints | 16 B pad)
+
+// the store tiles are written as halves and read back as 16-byte pieces: accesses that must not be reordered
+// on the strength of their types
+typedef f16x8 __attribute__((may_alias)) f16x8_a;
+typedef f16x4 __attribute__((may_alias)) f16x4_a;
+typedef f32x4 __attribute__((may_alias)) f32x4_a;
 
 struct LayerArgs {
     float* x;               // [R][128] descriptors, updated in place by phase 2
     const float* msg;       // [R][128] attention output (head-major channels)
-    const _Float16* w1s;    // [256][2][256] split
+    const _Float16* w1s;    // [256][ROWH256] split image
     const float* b1;        // [256]
-    const _Float16* w2s;    // [128][2][256]
+    const _Float16* w2s;    // [128][ROWH256]
     const float* b2;        // [128]
-    const _Float16* w3s;    // [384][2][128] (q|k|v of the next layer) or [128][2][128] (final_proj)
+    const _Float16* w3s;    // [384][ROWH128] (q|k|v of the next layer) or [128][ROWH128] (final_proj)
     const float* b3;        // [384] or [128]
     _Float16* q16;          // outputs of phase 3 (mode 1)
     _Float16* k16;
     _Float16* vt16;
     float* mdesc;           // [R][128] output of phase 3 (mode 2)
     int R, N, M, Npad, PP;
-    int do_mlp;             // 0: phase 3 only (first layer / no layers)
-    int mode3;              // 1: q|k|v, 2: final projection
 };
 
-// ---- weight staging: a row block = 32 rows x 2K halves, contiguous in memory ----
-template <int K>
-__device__ __forceinline__ void stage_issue(const _Float16* g, f32x4 (&st)[8], int tid) {
-    constexpr int NU = (32 * 2 * K * 2 / 16) / 256;   // 16-byte chunks per thread: 8 (K = 256) or 4 (K = 128)
+// One 33 KB stage: chunk c (1 KB) is moved by wave c & 3; the LDS address comes from M0, the lanes supply
+// consecutive 16-byte pieces.  Inline asm: the compiler must not know that LDS is written (it would order every
+// later ds_read behind the copy); completion is awaited explicitly (stage_wait) before the stage barrier.
+__device__ __forceinline__ void stage_dma(const _Float16* g, unsigned lds_addr, int wave, int lane) {
+    const char* src = reinterpret_cast<const char*>(g) + lane * 16;
 #pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        st[u] = *reinterpret_cast<const f32x4*>(g + (size_t)(tid + 256 * u) * 8);
+    for (int i = 0; i < 9; ++i) {
+        const int c = min(wave + 4 * i, 32);      // (waves 1-3 copy the last chunk once more: no branch)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                     :: "s"(lds_addr + c * 1024), "v"(src + c * 1024) : "memory");
     }
 }
-template <int K>
-__device__ __forceinline__ void stage_commit(_Float16* buf, const f32x4 (&st)[8], int tid) {
-    constexpr int NU = (32 * 2 * K * 2 / 16) / 256;
-    constexpr int CPR = 2 * K * 2 / 16;               // chunks per row
-    constexpr int ROWH = 2 * K + 8;
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        const int c = tid + 256 * u;
-        *reinterpret_cast<f32x4*>(buf + (c / CPR) * ROWH + (c % CPR) * 8) = st[u];
-    }
+__device__ __forceinline__ void stage_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
 }
 
+// DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 row blocks), 2: final projection (4).
+template <int DO_MLP, int MODE3>
 __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 2 x STAGE_HALVES + 768 floats of biases
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 2 stages, 768 floats of biases, 4 tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wrow = perm32(l31);
-    const int pt_raw = blockIdx.x * 128 + wave * 32 + l31;
-    const int pt = min(pt_raw, a.R - 1);               // clamped loads; stores are masked
-    _Float16* buf0 = smem;
-    _Float16* buf1 = smem + STAGE_HALVES;
+    // (no pointer tables here: a generic pointer loaded from a constant table is taken for a GLOBAL pointer)
+    auto bufp = [&](int i) __attribute__((always_inline)) { return smem + (i & 1) * STAGE_HALVES; };
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)smem;
+    auto ldsb = [&](int i) __attribute__((always_inline)) { return lds0 + (unsigned)(i & 1) * STAGE_BYTES; };
     float* bias1 = reinterpret_cast<float*>(smem + 2 * STAGE_HALVES);   // [256]
     float* bias2 = bias1 + 256;                                         // [128]
     float* bias3 = bias2 + 128;                                         // [384]
-    f32x4 st[8];
+    // Wave-private tile.  Same wave, in-order LDS: no barriers.  It holds x (fp32) through phases 1-2 (residual
+    // source, new x written in place), then serves as the staging tile of the phase-3 outputs.
+    float* tile = bias3 + 384 + wave * TILE_FLOATS;
+    _Float16* tile16 = reinterpret_cast<_Float16*>(tile);
+    const int wave_pt0 = blockIdx.x * 128 + wave * 32;
+    constexpr int NB3 = MODE3 == 1 ? 12 : 4;      // row blocks of phase 3 (two per stage)
 
-    const int n3 = a.mode3 == 1 ? 12 : 4;    // row blocks of phase 3
-    {
-        if (a.do_mlp) {
-            bias1[tid] = a.b1[tid];
-            if (tid < 128) bias2[tid] = a.b2[tid];
-        }
-        for (int i = tid; i < n3 * 32; i += 256) bias3[i] = a.b3[i];
+    stage_dma(DO_MLP ? a.w1s : a.w3s, ldsb(0), wave, lane);
+    if (DO_MLP) {
+        bias1[tid] = a.b1[tid];
+        if (tid < 128) bias2[tid] = a.b2[tid];
     }
+    for (int i = tid; i < NB3 * 32; i += 256) bias3[i] = a.b3[i];
+
+    // [R][128] fp32 rows of this wave's 32 keypoints <-> tile: half a wave per 512-byte row
+    auto rows_to_tile = [&](const float* src) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            f32x4 t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int gp = min(wave_pt0 + 2 * (8 * h + i) + hi, a.R - 1);
+                t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gp * 128 + l31 * 4);
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                *reinterpret_cast<f32x4_a*>(tile + (2 * (8 * h + i) + hi) * TROW + l31 * 4) = t[i];
+        }
+    };
+    auto tile_to_rows = [&](float* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int p = 2 * i + hi;
+            const f32x4 t = *reinterpret_cast<const f32x4_a*>(tile + p * TROW + l31 * 4);
+            // rows past the end hold copies of the last keypoint (clamped loads): they rewrite the same values
+            const int gp = min(wave_pt0 + p, a.R - 1);
+            *reinterpret_cast<f32x4*>(dst + (size_t)gp * 128 + l31 * 4) = t;
+        }
+    };
+
+    SplitAcc acc[2];          // alternate between consecutive blocks
+    f32x16 o;                 // combined output of the block whose epilogue is in flight
+    auto combine = [&](const SplitAcc& c, int ks) __attribute__((always_inline)) {      // ks 0, 1: eight registers each
+#pragma unroll
+        for (int r = 0; r < 8; ++r) o[8 * ks + r] = fmaf(c.x[8 * ks + r], MDGAT_SPLIT_INV, c.m[8 * ks + r]);
+    };
 
     f16x8 xnh[8], xnl[8];     // the (new) descriptors of this lane's keypoint as 8 k-step fragments
 
-    // phase-3 epilogue of row block qb
-    auto epilogue3 = [&](int qb, const f32x16& o) {
-        if (a.mode3 == 1 && qb < 8) {
+    // ---- sliced epilogues: slice ks runs next to k-step ks of the following block (ks 0, 1 = combine) ----
+    // phase 3, row block qb
+    auto e3 = [&](int qb, const SplitAcc& c, int ks) __attribute__((always_inline)) {
+        if (ks < 2) { combine(c, ks); return; }
+        if (MODE3 == 1 && qb < 8) {
             // q or k of head qb & 3: [pt][head][plane][32 dims]; this lane's dims 16 t + 8 hi .. + 7
-            const float sc = qb < 4 ? MDGAT_LOG2E * 0.17677669529663687f : 1.0f;   // log2(e) / sqrt(32) on q
-            _Float16* dst = (qb < 4 ? a.q16 : a.k16) + ((size_t)pt * 4 + (qb & 3)) * 64 + 8 * hi;
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            if (ks == 2 || ks == 3) {
+                const int t = ks - 2;
+                const float sc = qb < 4 ? MDGAT_LOG2E * 0.17677669529663687f : 1.0f;   // log2(e) / sqrt(32) on q
                 float bias[8], v[8];
                 load8(bias3 + qb * 32 + 16 * t + 8 * hi, bias);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) v[j] = (o[8 * t + j] + bias[j]) * sc;
                 f16x8 h, l;
                 split8s(v, h, l);
-                // lanes past the end hold a copy of the last keypoint (clamped loads): they rewrite the same values
-                *reinterpret_cast<f16x8*>(dst + 16 * t) = h;
-                *reinterpret_cast<f16x8*>(dst + 32 + 16 * t) = l;
+                *reinterpret_cast<f16x8_a*>(tile16 + l31 * QKROW + 16 * t + 8 * hi) = h;
+                *reinterpret_cast<f16x8_a*>(tile16 + l31 * QKROW + 32 + 16 * t + 8 * hi) = l;
+            } else if (ks == 4) {
+                // 128 contiguous bytes per keypoint: 8 lanes per row, 8 keypoints per store
+                _Float16* dst = (qb < 4 ? a.q16 : a.k16) + (size_t)(qb & 3) * 64;
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const int row = 8 * p + (lane >> 3), cc = lane & 7;
+                    const f32x4 d = *reinterpret_cast<const f32x4_a*>(tile16 + row * QKROW + cc * 8);
+                    const int gp = min(wave_pt0 + row, a.R - 1);     // rows past the end: copies of the last keypoint
+                    *reinterpret_cast<f32x4*>(dst + (size_t)gp * 256 + cc * 8) = d;
+                }
             }
-        } else if (a.mode3 == 1) {
+        } else if (MODE3 == 1) {
             // v of head qb & 3 (non-swapped product): lane = dim l31, registers = keypoints mfma32_row(r, hi) of this wave
             const int head = qb & 3;
-            const float bias = bias3[qb * 32 + l31];
             const int P = a.N + a.M;
-            const int wave_pt0 = blockIdx.x * 128 + wave * 32;
-            const bool fast = ((a.N | a.M) & 3) == 0;          // 4 consecutive keypoints share frame and pair, 8-byte aligned
+            if (((a.N | a.M) & 31) == 0) {
+                // the 32 keypoints of the wave share frame and pair: 64 contiguous bytes per (plane, dim) row,
+                // gathered through the tile so that a lane quad writes one row
+                if (wave_pt0 < a.R) {
+                    if (ks == 2 || ks == 3) {
+                        const float bias = bias3[qb * 32 + l31];
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int p0 = wave_pt0 + 8 * g + 4 * hi;
-                if (p0 >= a.R) continue;
-                _Float16 h[4], l[4];
+                        for (int g = 2 * (ks - 2); g < 2 * (ks - 2) + 2; ++g) {
+                            _Float16 h[4], l[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
-                if (fast) {
-                    const int bb = p0 / P, pp = p0 - bb * P;
-                    _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + l31) * a.PP;
-                    const int col = pp < a.N ? pp : a.Npad + pp - a.N;
-                    *reinterpret_cast<f16x4*>(row_h + col) = f16x4{h[0], h[1], h[2], h[3]};
-                    *reinterpret_cast<f16x4*>(row_h + (size_t)32 * a.PP + col) = f16x4{l[0], l[1], l[2], l[3]};
-                } else {
+                            for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
+                            *reinterpret_cast<f16x4_a*>(tile16 + l31 * VROW + 8 * g + 4 * hi) = f16x4{h[0], h[1], h[2], h[3]};
+                            *reinterpret_cast<f16x4_a*>(tile16 + (32 + l31) * VROW + 8 * g + 4 * hi) = f16x4{l[0], l[1], l[2], l[3]};
+                        }
+                    } else if (ks == 4) {
+                        const int bb = wave_pt0 / P, pp = wave_pt0 - bb * P;
+                        const int col0 = pp < a.N ? pp : a.Npad + pp - a.N;
+                        _Float16* base = a.vt16 + ((size_t)bb * 4 + head) * 64 * a.PP + col0;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int pj = p0 + j;
-                        if (pj >= a.R) break;
-                        const int bj = pj / P, qj = pj - bj * P;
-                        const int col = qj < a.N ? qj : a.Npad + qj - a.N;
-                        _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + l31) * a.PP;
-                        rh[col] = h[j];
-                        rh[(size_t)32 * a.PP + col] = l[j];
+                        for (int p = 0; p < 4; ++p) {
+                            const int row = 16 * p + (lane >> 2), cc = lane & 3;     // row = 32 plane + dim
+                            const f32x4 d = *reinterpret_cast<const f32x4_a*>(tile16 + row * VROW + cc * 8);
+                            *reinterpret_cast<f32x4*>(base + (size_t)row * a.PP + cc * 8) = d;
+                        }
+                    }
+                }
+            } else if (ks == 4) {
+                // ragged frames: 4 consecutive keypoints per lane (8-byte stores) or single halves
+                const float bias = bias3[qb * 32 + l31];
+                const bool fast = ((a.N | a.M) & 3) == 0;      // 4 consecutive keypoints share frame and pair, 8-byte aligned
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int p0 = wave_pt0 + 8 * g + 4 * hi;
+                    if (p0 >= a.R) continue;
+                    _Float16 h[4], l[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
+                    if (fast) {
+                        const int bb = p0 / P, pp = p0 - bb * P;
+                        _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + l31) * a.PP;
+                        const int col = pp < a.N ? pp : a.Npad + pp - a.N;
+                        *reinterpret_cast<f16x4*>(row_h + col) = f16x4{h[0], h[1], h[2], h[3]};
+                        *reinterpret_cast<f16x4*>(row_h + (size_t)32 * a.PP + col) = f16x4{l[0], l[1], l[2], l[3]};
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int pj = p0 + j;
+                            if (pj >= a.R) break;
+                            const int bj = pj / P, qj = pj - bj * P;
+                            const int col = qj < a.N ? qj : a.Npad + qj - a.N;
+                            _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + l31) * a.PP;
+                            rh[col] = h[j];
+                            rh[(size_t)32 * a.PP + col] = l[j];
+                        }
                     }
                 }
             }
-        } else {
+        } else if (ks == 2 || ks == 3) {
+            const int t = ks - 2;
+            float bias[8], v[8];
+            const int ch = qb * 32 + 16 * t + 8 * hi;
+            load8(bias3 + ch, bias);
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float bias[8], v[8];
-                const int ch = qb * 32 + 16 * t + 8 * hi;
-                load8(bias3 + ch, bias);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = o[8 * t + j] + bias[j];
-                store8(a.mdesc + (size_t)pt * 128 + ch, v);
-            }
+            for (int j = 0; j < 8; ++j) v[j] = o[8 * t + j] + bias[j];
+            store8(tile + l31 * TROW + ch, v);       // whole rows go out after the last block
         }
     };
+    constexpr int E_SLICES = 5;     // slices 0 .. 4 make a complete epilogue
+    constexpr bool kDefer = true;   // false: every epilogue right after its own block (debugging aid)
 
-    if (a.do_mlp) {
+    if (DO_MLP) {
         // ---- fragments of [x ; msg]: k-step ks covers channels 16 ks .. 16 ks + 15, this lane 8 hi .. 8 hi + 7 ----
         f16x8 ah[16], al[16];
-        stage_issue<256>(a.w1s, st, tid);
+        rows_to_tile(a.msg);
 #pragma unroll
-        for (int ks = 0; ks < 16; ++ks) {
-            const float* src = (ks < 8 ? a.x : a.msg) + (size_t)pt * 128 + 16 * (ks & 7) + 8 * hi;
+        for (int ks = 8; ks < 16; ++ks) {
             float v[8];
-            load8(src, v);
+            load8(tile + l31 * TROW + 16 * (ks & 7) + 8 * hi, v);
             split8s(v, ah[ks], al[ks]);
         }
-        stage_commit<256>(buf0, st, tid);
-        __syncthreads();
+        rows_to_tile(a.x);                       // stays in the tile: residual of phase 2
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) {
+            float v[8];
+            load8(tile + l31 * TROW + 16 * ks + 8 * hi, v);
+            split8s(v, ah[ks], al[ks]);
+        }
+        stage_wait();
 
         // ---- phase 1: 8 row blocks of W1 -> hidden fragments (k-steps 2 rb, 2 rb + 1 of phase 2) ----
         f16x8 hh[16], hl[16];
-        auto epilogue1 = [&](int rb, const f32x16& o) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
+        auto e1 = [&](int rb, const SplitAcc& c, int ks) __attribute__((always_inline)) {
+            if (ks < 2) { combine(c, ks); return; }
+            if (ks == 2 || ks == 3) {
+                const int t = ks - 2;
                 float bias[8], v[8];
                 load8(bias1 + rb * 32 + 16 * t + 8 * hi, bias);
 #pragma unroll
@@ -189,102 +284,126 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
         };
 #pragma unroll
         for (int rb = 0; rb < 8; ++rb) {
-            _Float16* cur = (rb & 1) ? buf1 : buf0;
-            _Float16* nxt = (rb & 1) ? buf0 : buf1;
-            if (rb < 7) stage_issue<256>(a.w1s + (size_t)(rb + 1) * 32 * 512, st, tid);
-            else stage_issue<256>(a.w2s, st, tid);
-            f32x16 o;
-            block_mma<16, true>(cur, wrow, hi, ah, al, o);
-            stage_commit<256>(nxt, st, tid);   // before the epilogue: its vmcnt wait must not cover this stage's stores
-            epilogue1(rb, o);
-            __syncthreads();
+            stage_dma(rb < 7 ? a.w1s + (size_t)(rb + 1) * 32 * ROWH256 : a.w2s, ldsb(rb + 1), wave, lane);
+            block_mma_il<16, true, ROWH256>(bufp(rb), wrow, hi, ah, al, acc[rb & 1],
+                                            [&](int ks) __attribute__((always_inline)) { if (kDefer && rb > 0) e1(rb - 1, acc[(rb - 1) & 1], ks); });
+            if (!kDefer) {
+#pragma unroll
+                for (int ks = 0; ks < E_SLICES; ++ks) e1(rb, acc[rb & 1], ks);
+            }
+            stage_wait();
         }
 
-        // ---- phase 2: 4 row blocks of W2, residual, new x (fp32 to memory, split fragments kept) ----
-        auto epilogue2 = [&](int ob, const f32x16& o, const float (&res)[16]) {
-#pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                float bias[8], v[8];
+        // ---- phase 2: 4 row blocks of W2, residual, new x (fp32 into the tile, split fragments kept) ----
+        auto e2 = [&](int ob, const SplitAcc& c, int ks) __attribute__((always_inline)) {
+            if (ks < 2) { combine(c, ks); return; }
+            if (ks == 2 || ks == 3) {
+                const int t = ks - 2;
+                float bias[8], res[8], v[8];
                 const int ch = ob * 32 + 16 * t + 8 * hi;
                 load8(bias2 + ch, bias);
+                load8(tile + l31 * TROW + ch, res);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[j] = res[8 * t + j] + (o[8 * t + j] + bias[j]);
-                store8(a.x + (size_t)pt * 128 + ch, v);
+                for (int j = 0; j < 8; ++j) v[j] = res[j] + (o[8 * t + j] + bias[j]);
+                store8(tile + l31 * TROW + ch, v);
                 split8s(v, xnh[2 * ob + t], xnl[2 * ob + t]);
             }
         };
 #pragma unroll
         for (int ob = 0; ob < 4; ++ob) {
-            _Float16* cur = (ob & 1) ? buf1 : buf0;
-            _Float16* nxt = (ob & 1) ? buf0 : buf1;
-            if (ob < 3) stage_issue<256>(a.w2s + (size_t)(ob + 1) * 32 * 512, st, tid);
-            else stage_issue<128>(a.w3s, st, tid);
-            float res[16];   // residual x of this block, loaded ahead of the MFMAs
-            {
-                float ra[8], rb8[8];
-                const int ch = ob * 32;
-                load8(a.x + (size_t)pt * 128 + ch + 8 * hi, ra);
-                load8(a.x + (size_t)pt * 128 + ch + 16 + 8 * hi, rb8);
+            stage_dma(ob < 3 ? a.w2s + (size_t)(ob + 1) * 32 * ROWH256 : a.w3s, ldsb(ob + 1), wave, lane);
+            block_mma_il<16, true, ROWH256>(bufp(ob), wrow, hi, hh, hl, acc[ob & 1], [&](int ks) __attribute__((always_inline)) {
+                if (!kDefer) return;
+                if (ob == 0) e1(7, acc[1], ks);
+                else e2(ob - 1, acc[(ob - 1) & 1], ks);
+            });
+            if (!kDefer) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { res[j] = ra[j]; res[8 + j] = rb8[j]; }
+                for (int ks = 0; ks < E_SLICES; ++ks) e2(ob, acc[ob & 1], ks);
             }
-            f32x16 o;
-            block_mma<16, true>(cur, wrow, hi, hh, hl, o);
-            if (ob < 3) stage_commit<256>(nxt, st, tid);
-            else stage_commit<128>(nxt, st, tid);
-            epilogue2(ob, o, res);
-            __syncthreads();
+            stage_wait();
         }
-
+        // the epilogue of the last block (set 1) is not overlapped: phase 3 needs all of the new x
+        if (kDefer) {
+#pragma unroll
+            for (int ks = 0; ks < E_SLICES; ++ks) e2(3, acc[1], ks);
+        }
+        tile_to_rows(a.x);                       // the tile is free afterwards
     } else {
-        stage_issue<128>(a.w3s, st, tid);
+        rows_to_tile(a.x);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
             float v[8];
-            load8(a.x + (size_t)pt * 128 + 16 * ks + 8 * hi, v);
+            load8(tile + l31 * TROW + 16 * ks + 8 * hi, v);
             split8s(v, xnh[ks], xnl[ks]);
         }
-        stage_commit<128>(buf0, st, tid);
-        __syncthreads();
+        stage_wait();
     }
 
-    // ---- phase 3: q | k | v of the next layer (12 row blocks) or the final projection (4); after an even
-    //      number of stages the first block of W3 is in buf0 in both branches ----
+    // ---- phase 3: q | k | v of the next layer (12 row blocks) or the final projection (4), two row blocks
+    //      per stage; after an even number of stages the first stage of W3 is in buffer 0 in both branches ----
 #pragma unroll
-    for (int qb = 0; qb < 12; ++qb) {
-        if (qb < n3) {
-            _Float16* cur = (qb & 1) ? buf1 : buf0;
-            _Float16* nxt = (qb & 1) ? buf0 : buf1;
-            const bool more = qb + 1 < n3;
-            if (more) stage_issue<128>(a.w3s + (size_t)(qb + 1) * 32 * 256, st, tid);
-            f32x16 o;
-            if (a.mode3 == 1 && qb >= 8) block_mma<8, false>(cur, l31, hi, xnh, xnl, o);
-            else block_mma<8, true>(cur, wrow, hi, xnh, xnl, o);
-            if (more) stage_commit<128>(nxt, st, tid);
-            epilogue3(qb, o);
-            __syncthreads();
+    for (int j = 0; j < NB3 / 2; ++j) {
+        if (j + 1 < NB3 / 2) stage_dma(a.w3s + (size_t)(j + 1) * 64 * ROWH128, ldsb(j + 1), wave, lane);
+        const _Float16* cur = bufp(j);
+        const int qa = 2 * j, qb = 2 * j + 1;
+        // block A (accumulator set 0); in its shadow: the epilogue of the previous block
+        auto inter_a = [&](int ks) __attribute__((always_inline)) { if (kDefer && j > 0) e3(qa - 1, acc[1], ks); };
+        if (MODE3 == 1 && qa >= 8) block_mma_il<8, false, ROWH128>(cur, l31, hi, xnh, xnl, acc[0], inter_a);
+        else block_mma_il<8, true, ROWH128>(cur, wrow, hi, xnh, xnl, acc[0], inter_a);
+        if (!kDefer) {
+#pragma unroll
+            for (int ks = 0; ks < E_SLICES; ++ks) e3(qa, acc[0], ks);
         }
+        // block B (set 1); in its shadow: the epilogue of block A
+        auto inter_b = [&](int ks) __attribute__((always_inline)) { if (kDefer) e3(qa, acc[0], ks); };
+        if (MODE3 == 1 && qb >= 8) block_mma_il<8, false, ROWH128>(cur + 32 * ROWH128, l31, hi, xnh, xnl, acc[1], inter_b);
+        else block_mma_il<8, true, ROWH128>(cur + 32 * ROWH128, wrow, hi, xnh, xnl, acc[1], inter_b);
+        if (!kDefer) {
+#pragma unroll
+            for (int ks = 0; ks < E_SLICES; ++ks) e3(qb, acc[1], ks);
+        }
+        if (j + 1 < NB3 / 2) stage_wait();
     }
+    if (kDefer) {
+#pragma unroll
+        for (int ks = 0; ks < E_SLICES; ++ks) e3(NB3 - 1, acc[1], ks);
+    }
+    if (MODE3 != 1) tile_to_rows(a.mdesc);
 }
 
-// fp32 [rows][K] -> split [rows][2][K] (hi plane | lo plane), once per weight load
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float16* out, int rows, int K) {
+// fp32 [rows][K] -> split image [rows][rowh] (hi plane | lo plane | pad), once per weight load
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float16* out, int rows, int K, int rowh) {
     const size_t total = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const size_t r = i / K, c = i - r * K;
         _Float16 h, l;
         mdgat_split(w[i], h, l);
-        out[r * 2 * K + c] = h;
-        out[r * 2 * K + K + c] = l;
+        out[r * rowh + c] = h;
+        out[r * rowh + K + c] = l;
     }
+}
+
+template <int DO_MLP, int MODE3>
+int launch_layer_t(const LayerArgs& a, hipStream_t s) {
+    const size_t lds = (size_t)2 * STAGE_BYTES + (768 + 4 * TILE_FLOATS) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer LDS attribute"))
+            return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + 127) / 128), dim3(256), lds, s, a);
+    return mdgat_check_hip(hipGetLastError(), "layer launch");
 }
 
 }  // namespace
 
-int launch_split_rows(const float* w, _Float16* out, int rows, int K, hipStream_t s) {
+int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, hipStream_t s) {
     const size_t total = (size_t)rows * K;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, w, out, rows, K);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, w, out, rows, K, rowh);
     return mdgat_check_hip(hipGetLastError(), "split_rows launch");
 }
 
@@ -295,15 +414,6 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     a.w1s = p.w1s; a.b1 = p.b1; a.w2s = p.w2s; a.b2 = p.b2; a.w3s = p.w3s; a.b3 = p.b3;
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
     a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP;
-    a.do_mlp = p.do_mlp; a.mode3 = p.mode3;
-    const size_t lds = (size_t)2 * STAGE_HALVES * sizeof(_Float16) + 768 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer LDS attribute"))
-            return rc;
-        attr = true;
-    }
-    hipLaunchKernelGGL(layer_kernel, dim3((p.R + 127) / 128), dim3(256), lds, s, a);
-    return mdgat_check_hip(hipGetLastError(), "layer launch");
+    if (p.do_mlp) return p.mode3 == 1 ? launch_layer_t<1, 1>(a, s) : launch_layer_t<1, 2>(a, s);
+    return p.mode3 == 1 ? launch_layer_t<0, 1>(a, s) : launch_layer_t<0, 2>(a, s);
 }

@@ -14,14 +14,15 @@ __device__ __forceinline__ void split8s(const float (&v)[8], f16x8& h, f16x8& l)
     for (int j = 0; j < 8; ++j) l[j] = (_Float16)((v[j] - (float)h[j]) * MDGAT_SPLIT_SCALE);
 }
 
+typedef f32x4 __attribute__((may_alias)) f32x4_alias;   // LDS tiles are reused with other element types
 __device__ __forceinline__ void load8(const float* p, float (&v)[8]) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(p);
-    const f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4_alias*>(p);
+    const f32x4 b = *reinterpret_cast<const f32x4_alias*>(p + 4);
     v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
 }
 __device__ __forceinline__ void store8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    *reinterpret_cast<f32x4_alias*>(p) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4_alias*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
 }
 
 // D^T block (32 channels x 32 keypoints) = W block (LDS) . X^T (register fragments), NK k-steps of 16.
@@ -62,6 +63,47 @@ __device__ __forceinline__ void block_mma(const _Float16* buf, int wrow, int hi,
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) out[r] = fmaf(aca[r] + acb[r], MDGAT_SPLIT_INV, acc[r]);
+}
+
+// Two accumulators per block: m = hi.hi, x = hi.lo + lo.hi (to be scaled by 1/2048 when combined).
+struct SplitAcc { f32x16 m, x; };
+
+// Same product as block_mma, with (a) the W fragments read three k-steps ahead, (b) the two cross products
+// sharing one accumulator, (c) a caller-supplied piece of independent work `inter(ks)` issued next to the MFMAs
+// of every k-step - the epilogue of the PREVIOUS block, so that its VALU / LDS / store instructions run in the
+// shadow of this block's matrix instructions instead of between blocks.  ROWH = LDS row pitch in halves.
+template <int NK, bool SWAP, int ROWH, typename Inter>
+__device__ __forceinline__ void block_mma_il(const _Float16* buf, int wrow, int hi, const f16x8* xh, const f16x8* xl,
+                                             SplitAcc& acc, Inter&& inter) {
+    constexpr int K = NK * 16, AHEAD = 3;
+    const _Float16* wp = buf + wrow * ROWH + 8 * hi;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc.m[r] = 0.f; acc.x[r] = 0.f; }
+    f16x8 wh[NK], wl[NK];
+#pragma unroll
+    for (int ks = 0; ks < AHEAD; ++ks) {
+        wh[ks] = *reinterpret_cast<const f16x8*>(wp + 16 * ks);
+        wl[ks] = *reinterpret_cast<const f16x8*>(wp + K + 16 * ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK; ++ks) {
+        if (ks + AHEAD < NK) {
+            wh[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + 16 * (ks + AHEAD));
+            wl[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + K + 16 * (ks + AHEAD));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of k-step ks + AHEAD ahead of the MFMAs of k-step ks
+        if (SWAP) {
+            acc.x = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[ks], acc.x, 0, 0, 0);
+            acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[ks], acc.m, 0, 0, 0);
+            acc.x = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[ks], acc.x, 0, 0, 0);
+        } else {
+            acc.x = __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], wh[ks], acc.x, 0, 0, 0);
+            acc.m = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wh[ks], acc.m, 0, 0, 0);
+            acc.x = __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wl[ks], acc.x, 0, 0, 0);
+        }
+        inter(ks);
+        __builtin_amdgcn_sched_barrier(0);
+    }
 }
 
 }  // namespace
