@@ -18,8 +18,8 @@ for sel in range(4):
     ev = [(buf[sel * 256 + i] >> 48, buf[sel * 256 + i] & 0xffffffffffff) for i in range(256) if buf[sel * 256 + i]]
     if not ev: continue
     t0 = ev[0][1]
-    print('== wg', 100 if sel < 2 else 400, 'wave', 0 if sel % 2 == 0 else 3, 'total', ev[-1][1] - t0)
+    print('== wg', 'first' if sel < 2 else 'last', 'wave', 0 if sel % 2 == 0 else 3, 'total', ev[-1][1] - t0)
     prev = t0; line = []
     for slot, t in ev:
         line.append('%d:%d' % (slot, t - prev)); prev = t
-        if (slot % 10 == 4 and slot < 40) or slot in (3, 25, 64): print('  ', ' '.join(line)); line = []
+        if slot in (2, 12, 22, 24, 31, 33, 40): print('  ', ' '.join(line)); line = []
