@@ -67,10 +67,10 @@ struct mdgat_handle {
     long long prof_launches[MDGAT_PROF_CLASSES];
 };
 
-// split-weight buffer: per layer the LDS images of layer.hip [w1 256 rows x 520 | w2 128 x 520 | qkv 384 x 264]
-// (row = hi plane | lo plane | 16 B pad, zero filled), then final_proj 128 x 264, then the encoder matrices.
+// split-weight buffer: per layer the LDS images of layer.hip [w1 256 rows x 528 | w2 128 x 528 | qkv 384 x 272]
+// (row = hi plane | lo plane | 32 B pad, zero filled; output rows in the P/Q order of layer.hip except the v rows), then final_proj 128 x 272, then the encoder matrices.
 // The stage copies of layer.hip read whole KB: up to 512 B past a K = 256 block, hence the slack after final_proj.
-static constexpr size_t WS_ROW256 = 520, WS_ROW128 = 264;
+static constexpr size_t WS_ROW256 = 528, WS_ROW128 = 272;
 static constexpr size_t WS_W1 = 0, WS_W2 = 256 * WS_ROW256, WS_QKV = WS_W2 + 128 * WS_ROW256, WS_LAYER = WS_QKV + 384 * WS_ROW128;
 static constexpr size_t WS_FINAL = 128 * WS_ROW128 + 512;
 static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + WS_FINAL + MDGAT_ENC_SPLIT_HALVES; }
@@ -129,18 +129,18 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
     for (int i = 0; i < 2 * h->cfg.L && !rc; ++i) {
         const float* lw = h->weights + bl.layer0 + (size_t)i * bl.layer_stride;
         _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
-        rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, WS_ROW256, nullptr);
-        if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, WS_ROW256, nullptr);
-        if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, WS_ROW128, nullptr);
+        rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, WS_ROW256, 256, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, WS_ROW256, 128, nullptr);
+        if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, WS_ROW128, 256, nullptr);
     }
-    if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, WS_ROW128, nullptr);
+    if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, WS_ROW128, 128, nullptr);
     {
         _Float16* es = h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L) + WS_FINAL;
-        if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, 64, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.kenc2_w, es + 64 * 64, 128, 64, 128, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, 64, 0, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.kenc2_w, es + 64 * 64, 128, 64, 128, 0, nullptr);
         if (!rc) rc = launch_split_rows_pad(h->weights + bl.denc0_w, es + 64 * 64 + 128 * 128, 64, 33, 48, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.denc1_w, es + 64 * 64 + 128 * 128 + 64 * 96, 128, 64, 128, nullptr);
-        if (!rc) rc = launch_split_rows(h->weights + bl.encl_w, es + 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128, 128, 256, 512, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.denc1_w, es + 64 * 64 + 128 * 128 + 64 * 96, 128, 64, 128, 0, nullptr);
+        if (!rc) rc = launch_split_rows(h->weights + bl.encl_w, es + 64 * 64 + 128 * 128 + 64 * 96 + 128 * 128, 128, 256, 512, 0, nullptr);
     }
     if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "split weights");
     (void)hipSetDevice(prev);

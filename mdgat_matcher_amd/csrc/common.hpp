@@ -107,7 +107,8 @@ struct LayerLaunch {
     int mode3;                         // 1: q|k|v, 2: final_proj
 };
 int launch_layer(const LayerLaunch& p, hipStream_t s);
-int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, hipStream_t s);   // rowh >= 2 K: row pitch (halves)
+// rowh >= 2 K: row pitch (halves); the first nperm rows are written in the P/Q row order of layer.hip
+int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, int nperm, hipStream_t s);
 
 struct SkExtract {   // match extraction to run after (or fused into) the Sinkhorn kernel
     int mode; float thr;

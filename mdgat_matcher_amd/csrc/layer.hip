@@ -7,36 +7,39 @@
 //                                                 the split-f16 operand layouts of the attention kernel
 //            (last layer: mdesc = Wf x + bf, final_proj of mdgat.py:397, instead of q|k|v)
 //
-// Arithmetic: split-f16 products on the f16 matrix cores (common.hpp: x = hi + lo/2048, three
-// v_mfma_f32_32x32x16_f16 per product, fp32 accumulation) - fp32-class accuracy at 16/3 the f32 MFMA rate.
+// Arithmetic: split-f16 products on the f16 matrix cores (common.hpp: x = hi + lo/2048, three MFMAs per
+// product, fp32 accumulation) - fp32-class accuracy at 16/3 the f32 MFMA rate.
 //
-// gfx950 mapping.  A wave owns 32 keypoints for the whole chain and computes every product "swapped"
-// (D^T = W X^T): in the 32x32 C/D fragment layout a lane then holds, for ITS keypoint (lane & 31), 16
-// output channels per 32-channel row block.  The W rows are fed in a permuted order (bits 2 and 3 of
-// the row index swapped) so that the 8 registers of a half block are 8 CONSECUTIVE channels - which is
-// exactly the B-operand fragment of the next product (k-slots 8 hi .. 8 hi + 7 of a 16-deep k-step).
-// So relu(hid) and the new x are split to f16 in place and feed the next GEMM without touching memory.
+// gfx950 mapping.  Measured (tools/ubench/mfma_valu.hip): a wave cannot overlap its OWN vector instructions with
+// its own matrix instructions - behind an 8-pass MFMA it issues next to nothing - while two waves of a SIMD overlap
+// perfectly.  So the chain is cut to fit two waves per SIMD (<= 256 registers each): a wave owns 16 keypoints and
+// works on v_mfma_f32_16x16x32_f16 tiles; 8 waves = 128 keypoints per workgroup, one workgroup per CU.
 //
-// Weights: pre-split at load time into the LDS image itself ([row][hi plane | lo plane | 16 B pad], the pad
-// makes the ds_read_b128 fragment reads conflict free), so a stage (32 rows of K = 256 or 64 rows of K = 128,
-// 33 KB) is a flat copy: global_load_lds_dwordx4 moves it L2 -> LDS without passing through registers, issued at
-// the start of the stage that precedes its use, double buffered, one barrier per stage (18 stages per tile).
+// Every product is computed "swapped" (D^T = W X^T): the B operand is the activation fragment (lane (n = keypoint,
+// g) holds channels 8 g .. 8 g + 7 of a 32-deep k-step), the D fragment gives lane (n, g) rows 4 g .. 4 g + 3 of a
+// 16-row block.  A 32-channel UNIT is two row blocks P and Q whose weight rows are ordered (at weight-split time,
+// in the image itself) so that P row i is channel 8 (i >> 2) + (i & 3) and Q row i is channel 8 (i >> 2) + 4 + (i & 3):
+// lane (n, g) then holds channels 8 g .. 8 g + 7 of the unit - exactly the B fragment of k-step `unit` of the next
+// product.  relu(hid) and the new x are split to f16 in place and feed the next GEMM without touching memory.
 //
-// One wave per SIMD (its 32 keypoints need ~430 registers), so nothing but the wave's own instruction stream
-// can overlap the matrix pipe with the rest: the epilogue of block n (accumulator combine, bias, ReLU, f16
-// split, output staging and stores) is sliced and issued inside the k-loop of block n + 1 (block_mma_il), two
-// accumulator sets alternate.
+// Weights: pre-split at load time into the LDS image itself ([row][hi plane | lo plane | 16 B pad], rows in
+// P/Q order, the pad makes the ds_read_b128 fragment reads conflict free), so a stage (one unit of K = 256 or two
+// units of K = 128, 33 KB) is a flat copy: global_load_lds_dwordx4 moves it L2 -> LDS without passing through
+// registers, issued during the stage that precedes its use, double buffered, one barrier per stage (18 stages).
 //
-// Global traffic is whole rows only: a wave-private LDS tile transposes between "a half wave / 8 lanes / 4
-// lanes per contiguous row" (what the memory system wants) and the fragment order (what the MFMAs want).
+// The epilogue of unit n (accumulator combine, bias, ReLU, f16 split, output staging and stores) is cut into
+// small steps that are issued between the matrix instructions of unit n + 1 (unit_mma16: six slots per k-step),
+// two accumulator sets alternate; the other wave of the SIMD fills the matrix pipe meanwhile.
+//
+// Global traffic is whole rows only: a wave-private LDS tile transposes between "a half wave / 8 lanes per
+// contiguous row" (what the memory system wants) and the fragment order (what the MFMAs want).
 // V uses the non-swapped product (a lane holds 4 consecutive keypoints of one dim) for the transposed V^T layout.
 #include <utility>
 #include "common.hpp"
-
 #ifdef LAYER_TRACE
 __device__ long long g_dbg[8192];
 extern "C" int mdgat_debug_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), n * sizeof(long long)); }
-#define TRACE_OFF (2 * 33 * 1024 + (768 + 4 * 4224) * 4)
+#define TRACE_OFF (4 * 17 * 1024 + (768 + 8 * 2112) * 4)
 __device__ __forceinline__ void trace_point(int slot) {
     extern __shared__ __attribute__((aligned(16))) char tsm[];
     if ((threadIdx.x & 63) == 0) {
@@ -47,7 +50,6 @@ __device__ __forceinline__ void trace_point(int slot) {
     }
 }
 #define TR(slot) trace_point(slot)
-#define MMA_TR(ks) if ((ks & 1) == 1) trace_point(50 + ks)
 #ifndef TRACE_MLP
 #define TRACE_MLP 1
 #endif
@@ -55,16 +57,26 @@ __device__ __forceinline__ void trace_point(int slot) {
 #define TR(slot)
 #endif
 #include "mma_chain.hpp"
+#include "mma_chain.hpp"
 namespace {
 
-constexpr int ROWH256 = 520;                 // LDS / image row (halves) for K = 256: 256 hi | 256 lo | 8 pad
-constexpr int ROWH128 = 264;                 // K = 128
-constexpr int STAGE_BYTES = 33 * 1024;       // one staging buffer: 33 DMA chunks (32 x 1040 B rounded up, or 64 x 528 B)
-constexpr int STAGE_HALVES = STAGE_BYTES / 2;
+// LDS / image row pitch (halves): hi plane | lo plane | 32 B pad.  A ds_read_b128 is served in four groups of 16
+// lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; MI355X guide, LDS section): with lane (row l15, 16-byte
+// column g) a pitch of 32 B mod 256 B puts the 16 lanes of every group on 16 different 16-byte bank groups.
+constexpr int ROWH256 = 528;                 // K = 256
+constexpr int ROWH128 = 272;                 // K = 128
+// A stage = 16 image rows of K = 256 (one row block, 16896 B) or 32 rows of K = 128 (one unit, 17408 B): 17 copies
+// of 1 KB.  Ring of NSLOT slots; the copy of stage h + LOOKAHEAD is issued during stage h (the stage copies take
+// about three stage times to land: every CU asks L2 for the same lines at the same time).
+constexpr int SLOT_CHUNKS = 17;
+constexpr int SLOT_BYTES = SLOT_CHUNKS * 1024;
+constexpr int SLOT_HALVES = SLOT_BYTES / 2;
+constexpr int NSLOT = 4, LOOKAHEAD = 3;
+constexpr int WPTS = 16;                     // keypoints per wave
 constexpr int TROW = 132;                    // floats per row of a wave's activation tile (128 channels + 16 B pad)
-constexpr int TILE_FLOATS = 32 * TROW;       // [32 keypoints][TROW]: 16896 B per wave
+constexpr int TILE_FLOATS = WPTS * TROW;     // [16 keypoints][TROW]: 8448 B per wave
 constexpr int QKROW = 72;                    // halves per row of the q/k store tile (32 hi | 32 lo | 16 B pad)
-constexpr int VROW = 40;                     // halves per row of the V^T store tile (32 keypoints | 16 B pad)
+constexpr int VROW = 24;                     // halves per row of the V^T store tile (16 keypoints | 16 B pad)
 
 // the store tiles are written as halves and read back as 16-byte pieces: accesses that must not be reordered
 // on the strength of their types
@@ -75,11 +87,11 @@ typedef f32x4 __attribute__((may_alias)) f32x4_a;
 struct LayerArgs {
     float* x;               // [R][128] descriptors, updated in place by phase 2
     const float* msg;       // [R][128] attention output (head-major channels)
-    const _Float16* w1s;    // [256][ROWH256] split image
+    const _Float16* w1s;    // [256][ROWH256] split image (rows in P/Q order)
     const float* b1;        // [256]
     const _Float16* w2s;    // [128][ROWH256]
     const float* b2;        // [128]
-    const _Float16* w3s;    // [384][ROWH128] (q|k|v of the next layer) or [128][ROWH128] (final_proj)
+    const _Float16* w3s;    // [384][ROWH128] (q|k|v of the next layer; v rows in natural order) or [128][ROWH128] (final_proj)
     const float* b3;        // [384] or [128]
     _Float16* q16;          // outputs of phase 3 (mode 1)
     _Float16* k16;
@@ -88,21 +100,21 @@ struct LayerArgs {
     int R, N, M, Npad, PP;
 };
 
-// One 33 KB stage: chunk c (1 KB) is moved by wave c & 3; the LDS address comes from M0, the lanes supply
-// consecutive 16-byte pieces.  Inline asm: the compiler must not know that LDS is written (it would order every
-// later ds_read behind the copy); completion is awaited explicitly (stage_wait) before the stage barrier.
-// The 9 copies of a wave are issued one per k-step inside the k-loop of the running block (stage_dma_slice), so
-// that their issue cost (address VALU, M0, the VMEM issue itself) also hides behind matrix instructions.
+// One stage: chunk c (1 KB) is moved by wave c & 7; the LDS address comes from M0, the lanes supply consecutive
+// 16-byte pieces.  Inline asm: the compiler must not know that LDS is written (it would order every later ds_read
+// behind the copy); completion is awaited explicitly (stage_wait) before the stage barrier.  The 3 copies of a
+// wave are issued one at a time between the matrix instructions of the running stage.
 __device__ __forceinline__ void stage_dma_slice(const _Float16* g, unsigned lds_addr, int wave, int lane, int i) {
-    const int c = min(wave + 4 * i, 32);      // (waves 1-3 copy the last chunk once more: no branch)
+    const int c = min(wave + 8 * i, SLOT_CHUNKS - 1);      // (waves 1-7 copy the last chunk once more: no branch)
     // scalar base + per-lane 32-bit offset: the address arithmetic stays on the scalar unit
     const char* src = reinterpret_cast<const char*>(g) + c * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_addr + c * 1024), "v"(lane * 16), "s"(src) : "memory");
 }
+constexpr int DMA_SLICES = 3;
 __device__ __forceinline__ void stage_dma(const _Float16* g, unsigned lds_addr, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) stage_dma_slice(g, lds_addr, wave, lane, i);
+    for (int i = 0; i < DMA_SLICES; ++i) stage_dma_slice(g, lds_addr, wave, lane, i);
 }
 // f(0), f(1), ... f(N - 1) with literal arguments (a `#pragma unroll` loop over large inlined bodies is not reliably
 // unrolled, and a rolled loop would index the register arrays of the epilogues dynamically)
@@ -111,33 +123,106 @@ __device__ __forceinline__ void for_each_unit(F&& f, std::integer_sequence<int, 
 template <int N, typename F>
 __device__ __forceinline__ void for_units(F&& f) { for_each_unit(f, std::make_integer_sequence<int, N>{}); }
 
+// End of a stage: the copy of the NEXT stage must have landed; the copies issued after it (YOUNGER instructions:
+// DMA_SLICES per later stage already under way) may stay in flight.  Vector memory operations retire in order, so
+// "at most YOUNGER outstanding" says exactly that (stores issued in between only make the wait stricter).
+template <int YOUNGER>
 __device__ __forceinline__ void stage_wait() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
     __syncthreads();
 }
 
-// DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 row blocks), 2: final projection (4).
+// Accumulators of one 32-channel unit: row blocks P and Q, each m = hi.hi and x = hi.lo + lo.hi (to be scaled by
+// 1/2048 when combined).
+struct UnitAcc { f32x4 pm, px, qm, qx; };
+
+// One unit (32 image rows at `buf`) times NK32 k-steps of 32.  SWAP: W is the A operand, X (fragments xh / xl) the
+// B operand; else X is A and W is B.  The W fragments are read AHEAD k-steps ahead; `inter(slot)` is issued behind
+// each of the six matrix instructions of a k-step (slots 6 ks .. 6 ks + 5).
+template <int NK32, bool SWAP, int ROWH, typename Inter>
+__device__ __forceinline__ void unit_mma16(const _Float16* buf, int l15, int g, const f16x8* xh, const f16x8* xl,
+                                           UnitAcc& acc, Inter&& inter) {
+    constexpr int K = NK32 * 32, AHEAD = 2;
+    const _Float16* wp = buf + l15 * ROWH + 8 * g;
+    const _Float16* wq = wp + 16 * ROWH;
+    acc.pm = f32x4{0.f, 0.f, 0.f, 0.f}; acc.px = acc.pm; acc.qm = acc.pm; acc.qx = acc.pm;
+    f16x8 ph[NK32], pl[NK32], qh[NK32], ql[NK32];
+#pragma unroll
+    for (int ks = 0; ks < AHEAD; ++ks) {
+        ph[ks] = *reinterpret_cast<const f16x8*>(wp + 32 * ks);
+        pl[ks] = *reinterpret_cast<const f16x8*>(wp + K + 32 * ks);
+        qh[ks] = *reinterpret_cast<const f16x8*>(wq + 32 * ks);
+        ql[ks] = *reinterpret_cast<const f16x8*>(wq + K + 32 * ks);
+    }
+    auto mm = [&](const f16x8& w, const f16x8& x, const f32x4& c) __attribute__((always_inline)) {
+        return SWAP ? __builtin_amdgcn_mfma_f32_16x16x32_f16(w, x, c, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_16x16x32_f16(x, w, c, 0, 0, 0);
+    };
+#pragma unroll
+    for (int ks = 0; ks < NK32; ++ks) {
+        if (ks + AHEAD < NK32) {
+            ph[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + 32 * (ks + AHEAD));
+            pl[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + K + 32 * (ks + AHEAD));
+            qh[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wq + 32 * (ks + AHEAD));
+            ql[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wq + K + 32 * (ks + AHEAD));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads of k-step ks + AHEAD ahead of the MFMAs of k-step ks
+        acc.px = mm(ph[ks], xl[ks], acc.px); inter(6 * ks); __builtin_amdgcn_sched_barrier(0);
+        acc.qx = mm(qh[ks], xl[ks], acc.qx); inter(6 * ks + 1); __builtin_amdgcn_sched_barrier(0);
+        acc.pm = mm(ph[ks], xh[ks], acc.pm); inter(6 * ks + 2); __builtin_amdgcn_sched_barrier(0);
+        acc.qm = mm(qh[ks], xh[ks], acc.qm); inter(6 * ks + 3); __builtin_amdgcn_sched_barrier(0);
+        acc.px = mm(pl[ks], xh[ks], acc.px); inter(6 * ks + 4); __builtin_amdgcn_sched_barrier(0);
+        acc.qx = mm(ql[ks], xh[ks], acc.qx); inter(6 * ks + 5); __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// One row block (16 image rows at `buf`) of a K = 256 unit: accumulators m / x of that block, three slots per k-step.
+template <int NK32, int ROWH, typename Inter>
+__device__ __forceinline__ void block_mma16(const _Float16* buf, int l15, int g, const f16x8* xh, const f16x8* xl,
+                                            f32x4& m, f32x4& x, Inter&& inter) {
+    constexpr int K = NK32 * 32, AHEAD = 3;
+    const _Float16* wp = buf + l15 * ROWH + 8 * g;
+    m = f32x4{0.f, 0.f, 0.f, 0.f}; x = m;
+    f16x8 ph[NK32], pl[NK32];
+#pragma unroll
+    for (int ks = 0; ks < AHEAD; ++ks) {
+        ph[ks] = *reinterpret_cast<const f16x8*>(wp + 32 * ks);
+        pl[ks] = *reinterpret_cast<const f16x8*>(wp + K + 32 * ks);
+    }
+#pragma unroll
+    for (int ks = 0; ks < NK32; ++ks) {
+        if (ks + AHEAD < NK32) {
+            ph[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + 32 * (ks + AHEAD));
+            pl[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + K + 32 * (ks + AHEAD));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[ks], xl[ks], x, 0, 0, 0); inter(3 * ks); __builtin_amdgcn_sched_barrier(0);
+        m = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph[ks], xh[ks], m, 0, 0, 0); inter(3 * ks + 1); __builtin_amdgcn_sched_barrier(0);
+        x = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[ks], xh[ks], x, 0, 0, 0); inter(3 * ks + 2); __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 units), 2: final projection (4).
 template <int DO_MLP, int MODE3>
-__global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
-    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 2 stages, 768 floats of biases, 4 tiles
+__global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 4 stage slots, 768 floats of biases, 8 tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int wrow = perm32(l31);
+    const int l15 = lane & 15, g = lane >> 4;
     // (no pointer tables here: a generic pointer loaded from a constant table is taken for a GLOBAL pointer)
-    auto bufp = [&](int i) __attribute__((always_inline)) { return smem + (i & 1) * STAGE_HALVES; };
+    auto bufp = [&](int i) __attribute__((always_inline)) { return smem + (i % NSLOT) * SLOT_HALVES; };
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) _Float16*)smem;
-    auto ldsb = [&](int i) __attribute__((always_inline)) { return lds0 + (unsigned)(i & 1) * STAGE_BYTES; };
-    float* bias1 = reinterpret_cast<float*>(smem + 2 * STAGE_HALVES);   // [256]
+    auto ldsb = [&](int i) __attribute__((always_inline)) { return lds0 + (unsigned)(i % NSLOT) * SLOT_BYTES; };
+    float* bias1 = reinterpret_cast<float*>(smem + NSLOT * SLOT_HALVES);   // [256]
     float* bias2 = bias1 + 256;                                         // [128]
     float* bias3 = bias2 + 128;                                         // [384]
     // Wave-private tile.  Same wave, in-order LDS: no barriers.  It holds x (fp32) through phases 1-2 (residual
     // source, new x written in place), then serves as the staging tile of the phase-3 outputs.
     float* tile = bias3 + 384 + wave * TILE_FLOATS;
     _Float16* tile16 = reinterpret_cast<_Float16*>(tile);
-    const int wave_pt0 = blockIdx.x * 128 + wave * 32;
-    constexpr int NB3 = MODE3 == 1 ? 12 : 4;      // row blocks of phase 3 (two per stage)
+    const int wave_pt0 = blockIdx.x * 128 + wave * WPTS;
+    constexpr int NB3 = MODE3 == 1 ? 12 : 4;      // units of phase 3 (two per stage)
 
 #ifdef LAYER_TRACE
     const bool trace_on = (blockIdx.x == 3 || blockIdx.x == gridDim.x - 2) && (wave == 0 || wave == 3) && DO_MLP == TRACE_MLP && MODE3 == 1;
@@ -145,30 +230,41 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
     long long* tlds = reinterpret_cast<long long*>(reinterpret_cast<char*>(smem) + TRACE_OFF) + wave * 256;
     if (lane == 0) tlds[255] = 0;
 #endif
+    // stages of the tile: 16 row blocks of W1, 8 of W2, then the units of W3
+    constexpr int NSTAGE = (DO_MLP ? 24 : 0) + NB3;
+    auto stage_src = [&](int h) __attribute__((always_inline)) -> const _Float16* {
+        if (DO_MLP && h < 16) return a.w1s + (size_t)h * 16 * ROWH256;
+        if (DO_MLP && h < 24) return a.w2s + (size_t)(h - 16) * 16 * ROWH256;
+        return a.w3s + (size_t)(h - (DO_MLP ? 24 : 0)) * 32 * ROWH128;
+    };
+    // copy of stage h + LOOKAHEAD, slice i (issued during stage h)
+    auto copy_ahead = [&](int h, int i) __attribute__((always_inline)) {
+        if (h + LOOKAHEAD < NSTAGE) stage_dma_slice(stage_src(h + LOOKAHEAD), ldsb(h + LOOKAHEAD), wave, lane, i);
+    };
     TR(0);
-    stage_dma(DO_MLP ? a.w1s : a.w3s, ldsb(0), wave, lane);
     if (DO_MLP) {
-        bias1[tid] = a.b1[tid];
-        if (tid < 128) bias2[tid] = a.b2[tid];
+        if (tid < 256) bias1[tid] = a.b1[tid];
+        else if (tid < 384) bias2[tid - 256] = a.b2[tid - 256];
     }
-    for (int i = tid; i < NB3 * 32; i += 256) bias3[i] = a.b3[i];
+    for (int i = tid; i < NB3 * 32; i += 512) bias3[i] = a.b3[i];
 
-    // [R][128] fp32 rows of this wave's 32 keypoints <-> tile: half a wave per 512-byte row; all 16 loads of a
+    // [R][128] fp32 rows of this wave's 16 keypoints <-> tile: half a wave per 512-byte row; all 8 loads of a
     // matrix are in flight together
-    auto rows_load = [&](const float* src, f32x4 (&t)[16]) __attribute__((always_inline)) {
+    const int l31 = lane & 31, hi = lane >> 5;
+    auto rows_load = [&](const float* src, f32x4 (&t)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int gp = min(wave_pt0 + 2 * i + hi, a.R - 1);
             t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gp * 128 + l31 * 4);
         }
     };
-    auto rows_to_tile = [&](const f32x4 (&t)[16]) __attribute__((always_inline)) {
+    auto rows_to_tile = [&](const f32x4 (&t)[8]) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) *reinterpret_cast<f32x4_a*>(tile + (2 * i + hi) * TROW + l31 * 4) = t[i];
+        for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4_a*>(tile + (2 * i + hi) * TROW + l31 * 4) = t[i];
     };
     auto tile_to_rows = [&](float* dst) __attribute__((always_inline)) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
+        for (int i = 0; i < 8; ++i) {
             const int p = 2 * i + hi;
             const f32x4 t = *reinterpret_cast<const f32x4_a*>(tile + p * TROW + l31 * 4);
             // rows past the end hold copies of the last keypoint (clamped loads): they rewrite the same values
@@ -176,139 +272,130 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
             *reinterpret_cast<f32x4*>(dst + (size_t)gp * 128 + l31 * 4) = t;
         }
     };
-
-    SplitAcc acc[2];          // alternate between consecutive blocks
-    f32x16 o;                 // combined output of the block whose epilogue is in flight
-    f16x8 xnh[8], xnl[8];     // the (new) descriptors of this lane's keypoint as 8 k-step fragments
-
-    // ---- epilogues as sequences of small UNITS.  block_mma_il offers three slots per k-step, one behind each
-    //      matrix instruction; a unit placed in a slot runs in the shadow of that instruction (32 cycles = 8 VALU
-    //      issues of this wave).  With one wave per SIMD nothing hides the latency of a DEPENDENT VALU chain either,
-    //      so a unit applies ONE operation to all 16 values of the block (8 independent packed instructions) rather
-    //      than all operations to one value; LDS operands are read a few units before their use. ----
-    float pbias[16], pv[16], phf[16];  // bias, values in flight, their f16 heads converted back
-    float pbias_v = 0.f;
-    f16x8 sth[2], stl[2];             // split halves on their way to the store tile
-    f32x4 pback[4];                   // store tile read back
-    constexpr int E_UNITS = 22;
-
-    auto combine4 = [&](const SplitAcc& c, int i) __attribute__((always_inline)) {
-#pragma unroll
-        for (int r = 4 * i; r < 4 * i + 4; ++r) o[r] = fmaf(c.x[r], MDGAT_SPLIT_INV, c.m[r]);
+    // fragment of k-step ks (channels 32 ks .. 32 ks + 31) of the fp32 rows in the tile
+    auto tile_fragment = [&](int ks, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+        float v[8];
+        load8(tile + l15 * TROW + 32 * ks + 8 * g, v);
+        split8s(v, h, l);
     };
-    auto load_bias16 = [&](const float* b) __attribute__((always_inline)) {   // this lane's 2 x 8 channels of a row block
+
+    UnitAcc acc[2];           // alternate between consecutive units
+    float o[8];               // combined output of the unit whose epilogue is in flight: channels 8 g .. 8 g + 7
+    f16x8 xnh[4], xnl[4];     // the (new) descriptors of this lane's keypoint as 4 k-step fragments
+
+    // ---- epilogues as sequences of small STEPS placed in the slots of the next unit.  A step applies ONE
+    //      operation to all 8 values of the unit (independent instructions); LDS operands are read a few steps
+    //      before their use. ----
+    float pbias[8], pv[8], phf[8];    // bias, values in flight, their f16 heads converted back
+    float pbias_v[2] = {0.f, 0.f};
+    f16x8 sth, stl;                   // split halves on their way to the store tile
+    f32x4 pback[2];                   // store tile read back
+    constexpr int E_STEPS = 16;
+
+    auto combine = [&](const UnitAcc& c, int half) __attribute__((always_inline)) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            float b8[8];
-            load8(b + 16 * t + 8 * hi, b8);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) pbias[8 * t + j] = b8[j];
-        }
+        for (int r = 0; r < 4; ++r)
+            o[4 * half + r] = half == 0 ? fmaf(c.px[r], MDGAT_SPLIT_INV, c.pm[r]) : fmaf(c.qx[r], MDGAT_SPLIT_INV, c.qm[r]);
     };
-    // the split pv -> (h, l) in five units of eight independent instructions: s = 0 .. 5
-    auto split_unit = [&](int s_, f16x8 (&h)[2], f16x8 (&l)[2]) __attribute__((always_inline)) {
+    auto load_bias8 = [&](const float* b) __attribute__((always_inline)) { load8(b + 8 * g, pbias); };
+    // the split pv -> (h, l) in five steps
+    auto split_step = [&](int s_, f16x8& h, f16x8& l) __attribute__((always_inline)) {
         if (s_ == 0) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) h[j >> 3][j & 7] = (_Float16)pv[j];
-        } else if (s_ == 1 || s_ == 2) {
+            for (int j = 0; j < 8; ++j) h[j] = (_Float16)pv[j];
+        } else if (s_ == 1) {
 #pragma unroll
-            for (int j = 8 * (s_ - 1); j < 8 * s_; ++j) phf[j] = (float)h[j >> 3][j & 7];
+            for (int j = 0; j < 8; ++j) phf[j] = (float)h[j];
+        } else if (s_ == 2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) pv[j] -= phf[j];
         } else if (s_ == 3) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] -= phf[j];
+            for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_SPLIT_SCALE;
         } else if (s_ == 4) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) pv[j] *= MDGAT_SPLIT_SCALE;
-        } else if (s_ == 5) {
-#pragma unroll
-            for (int j = 0; j < 16; ++j) l[j >> 3][j & 7] = (_Float16)pv[j];
+            for (int j = 0; j < 8; ++j) l[j] = (_Float16)pv[j];
         }
     };
 
-    // phase 3, row block qb.  Units: 0 bias read | 1-4 combine | 5 + bias | 6 scale | 7-12 split | 13 tile write |
-    //                                14 tile read | 15-18 stores
-    auto e3 = [&](int qb, const SplitAcc& c, int u) __attribute__((always_inline)) {
-        if (u >= 1 && u <= 4) { combine4(c, u - 1); return; }
+    // phase 3, unit qb.  Steps: 0 bias read | 1, 2 combine | 3 + bias | 4 scale | 5-9 split | 10 tile write |
+    //                           11 tile read | 12, 13 stores
+    auto e3 = [&](int qb, const UnitAcc& c, int u) __attribute__((always_inline)) {
+        if (u == 1 || u == 2) { combine(c, u - 1); return; }
         if (MODE3 == 1 && qb < 8) {
-            // q or k of head qb & 3: [pt][head][plane][32 dims]; this lane's dims 16 t + 8 hi .. + 7
-            if (u == 0) load_bias16(bias3 + qb * 32);
-            else if (u == 5) {
+            // q or k of head qb & 3: [pt][head][plane][32 dims]; this lane's dims 8 g .. 8 g + 7
+            if (u == 0) load_bias8(bias3 + qb * 32);
+            else if (u == 3) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) pv[j] = o[j] + pbias[j];
-            } else if (u == 6) {
+                for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias[j];
+            } else if (u == 4) {
                 if (qb < 4) {
 #pragma unroll
-                    for (int j = 0; j < 16; ++j) pv[j] *= MDGAT_LOG2E * 0.17677669529663687f;   // log2(e) / sqrt(32) on q
+                    for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_LOG2E * 0.17677669529663687f;   // log2(e) / sqrt(32) on q
                 }
-            } else if (u <= 12) split_unit(u - 7, sth, stl);
-            else if (u == 13) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    *reinterpret_cast<f16x8_a*>(tile16 + l31 * QKROW + 16 * t + 8 * hi) = sth[t];
-                    *reinterpret_cast<f16x8_a*>(tile16 + l31 * QKROW + 32 + 16 * t + 8 * hi) = stl[t];
-                }
-            } else if (u == 14) {
+            } else if (u <= 9) split_step(u - 5, sth, stl);
+            else if (u == 10) {
+                *reinterpret_cast<f16x8_a*>(tile16 + l15 * QKROW + 8 * g) = sth;
+                *reinterpret_cast<f16x8_a*>(tile16 + l15 * QKROW + 32 + 8 * g) = stl;
+            } else if (u == 11) {
                 // 128 contiguous bytes per keypoint: 8 lanes per row, 8 keypoints per store
 #pragma unroll
-                for (int p = 0; p < 4; ++p)
+                for (int p = 0; p < 2; ++p)
                     pback[p] = *reinterpret_cast<const f32x4_a*>(tile16 + (8 * p + (lane >> 3)) * QKROW + (lane & 7) * 8);
-            } else if (u <= 18) {
-                const int p = u - 15;
+            } else if (u <= 13) {
+                const int p = u - 12;
                 _Float16* dst = (qb < 4 ? a.q16 : a.k16) + (size_t)(qb & 3) * 64;
                 const int row = 8 * p + (lane >> 3), cc = lane & 7;
                 const int gp = min(wave_pt0 + row, a.R - 1);     // rows past the end: copies of the last keypoint
                 *reinterpret_cast<f32x4*>(dst + (size_t)gp * 256 + cc * 8) = pback[p];
             }
         } else if (MODE3 == 1) {
-            // v of head qb & 3 (non-swapped product): lane = dim l31, registers = keypoints mfma32_row(r, hi) of this wave
+            // v of head qb & 3 (non-swapped product): lane (n, g) = dims n (block P) and 16 + n (block Q), keypoints
+            // 4 g .. 4 g + 3 of this wave: o[0..3] / o[4..7]
             const int head = qb & 3;
             const int P = a.N + a.M;
-            if (((a.N | a.M) & 31) == 0) {
-                // the 32 keypoints of the wave share frame and pair: 64 contiguous bytes per (plane, dim) row,
-                // gathered through the tile so that a lane quad writes one row
+            if (((a.N | a.M) & 15) == 0) {
+                // the 16 keypoints of the wave share frame and pair: 32 contiguous bytes per (plane, dim) row,
+                // gathered through the tile so that a lane writes one whole row
                 if (wave_pt0 < a.R) {
-                    if (u == 0) pbias_v = bias3[qb * 32 + l31];
-                    else if (u == 5) {
+                    if (u == 0) { pbias_v[0] = bias3[qb * 32 + l15]; pbias_v[1] = bias3[qb * 32 + 16 + l15]; }
+                    else if (u == 3) {
 #pragma unroll
-                        for (int j = 0; j < 16; ++j) pv[j] = o[j] + pbias_v;
-                    } else if (u >= 7 && u <= 12) split_unit(u - 7, sth, stl);
-                    else if (u == 13) {
-                        // registers 4 g .. 4 g + 3 = keypoints 8 g + 4 hi .. + 3 of this dim
+                        for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias_v[j >> 2];
+                    } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl);
+                    else if (u == 10) {
+                        // tile rows: 32 plane + dim; 16 keypoints (halves) per row
+                        *reinterpret_cast<f16x4_a*>(tile16 + l15 * VROW + 4 * g) = f16x4{sth[0], sth[1], sth[2], sth[3]};
+                        *reinterpret_cast<f16x4_a*>(tile16 + (16 + l15) * VROW + 4 * g) = f16x4{sth[4], sth[5], sth[6], sth[7]};
+                        *reinterpret_cast<f16x4_a*>(tile16 + (32 + l15) * VROW + 4 * g) = f16x4{stl[0], stl[1], stl[2], stl[3]};
+                        *reinterpret_cast<f16x4_a*>(tile16 + (48 + l15) * VROW + 4 * g) = f16x4{stl[4], stl[5], stl[6], stl[7]};
+                    } else if (u == 11) {
 #pragma unroll
-                        for (int g = 0; g < 4; ++g) {
-                            const int t = g >> 1, e0 = 4 * (g & 1);
-                            *reinterpret_cast<f16x4_a*>(tile16 + l31 * VROW + 8 * g + 4 * hi) =
-                                f16x4{sth[t][e0], sth[t][e0 + 1], sth[t][e0 + 2], sth[t][e0 + 3]};
-                            *reinterpret_cast<f16x4_a*>(tile16 + (32 + l31) * VROW + 8 * g + 4 * hi) =
-                                f16x4{stl[t][e0], stl[t][e0 + 1], stl[t][e0 + 2], stl[t][e0 + 3]};
-                        }
-                    } else if (u == 14) {
-#pragma unroll
-                        for (int p = 0; p < 4; ++p)     // row = 32 plane + dim
-                            pback[p] = *reinterpret_cast<const f32x4_a*>(tile16 + (16 * p + (lane >> 2)) * VROW + (lane & 3) * 8);
-                    } else if (u >= 15 && u <= 18) {
-                        const int p = u - 15;
+                        for (int p = 0; p < 2; ++p)     // lane = row (32 plane + dim), two 16-byte halves of it
+                            pback[p] = *reinterpret_cast<const f32x4_a*>(tile16 + lane * VROW + p * 8);
+                    } else if (u == 12 || u == 13) {
+                        const int p = u - 12;
                         const int bb = wave_pt0 / P, pp = wave_pt0 - bb * P;
                         const int col0 = pp < a.N ? pp : a.Npad + pp - a.N;
                         _Float16* base = a.vt16 + ((size_t)bb * 4 + head) * 64 * a.PP + col0;
-                        const int row = 16 * p + (lane >> 2), cc = lane & 3;
-                        *reinterpret_cast<f32x4*>(base + (size_t)row * a.PP + cc * 8) = pback[p];
+                        *reinterpret_cast<f32x4*>(base + (size_t)lane * a.PP + p * 8) = pback[p];
                     }
                 }
-            } else if (u == 14) {
+            } else if (u == 11) {
                 // ragged frames: 4 consecutive keypoints per lane (8-byte stores) or single halves
-                const float bias = bias3[qb * 32 + l31];
                 const bool fast = ((a.N | a.M) & 3) == 0;      // 4 consecutive keypoints share frame and pair, 8-byte aligned
+                const int p0 = wave_pt0 + 4 * g;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int p0 = wave_pt0 + 8 * g + 4 * hi;
+                for (int blk = 0; blk < 2; ++blk) {
                     if (p0 >= a.R) continue;
+                    const int dim = 16 * blk + l15;
+                    const float bias = bias3[qb * 32 + dim];
                     _Float16 h[4], l[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mdgat_split(o[4 * g + j] + bias, h[j], l[j]);
+                    for (int j = 0; j < 4; ++j) mdgat_split(o[4 * blk + j] + bias, h[j], l[j]);
                     if (fast) {
                         const int bb = p0 / P, pp = p0 - bb * P;
-                        _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + l31) * a.PP;
+                        _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + dim) * a.PP;
                         const int col = pp < a.N ? pp : a.Npad + pp - a.N;
                         *reinterpret_cast<f16x4*>(row_h + col) = f16x4{h[0], h[1], h[2], h[3]};
                         *reinterpret_cast<f16x4*>(row_h + (size_t)32 * a.PP + col) = f16x4{l[0], l[1], l[2], l[3]};
@@ -319,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
                             if (pj >= a.R) break;
                             const int bj = pj / P, qj = pj - bj * P;
                             const int col = qj < a.N ? qj : a.Npad + qj - a.N;
-                            _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + l31) * a.PP;
+                            _Float16* rh = a.vt16 + (((size_t)bj * 4 + head) * 2 * 32 + dim) * a.PP;
                             rh[col] = h[j];
                             rh[(size_t)32 * a.PP + col] = l[j];
                         }
@@ -327,166 +414,140 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
                 }
             }
         } else {
-            if (u == 0) load_bias16(bias3 + qb * 32);
-            else if (u == 5) {
+            if (u == 0) load_bias8(bias3 + qb * 32);
+            else if (u == 3) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) pv[j] = o[j] + pbias[j];
-            } else if (u == 6) {                 // whole rows go out after the last block
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float v8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v8[j] = pv[8 * t + j];
-                    store8(tile + l31 * TROW + qb * 32 + 16 * t + 8 * hi, v8);
-                }
-            }
+                for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias[j];
+            } else if (u == 4) store8(tile + l15 * TROW + qb * 32 + 8 * g, pv);   // whole rows go out after the last unit
         }
     };
 
     if (DO_MLP) {
-        // ---- fragments of [x ; msg]: k-step ks covers channels 16 ks .. 16 ks + 15, this lane 8 hi .. 8 hi + 7 ----
-        f16x8 ah[16], al[16];
+        // ---- fragments of [x ; msg]: k-step ks covers channels 32 ks .. 32 ks + 31, this lane 8 g .. 8 g + 7 ----
+        f16x8 ah[8], al[8];
         {
-            f32x4 tm[16], tx[16];
+            f32x4 tm[8], tx[8];
             rows_load(a.msg, tm);
             rows_load(a.x, tx);
+            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tm);
-#pragma unroll
-            for (int ks = 8; ks < 16; ++ks) {
-                float v[8];
-                load8(tile + l31 * TROW + 16 * (ks & 7) + 8 * hi, v);
-                split8s(v, ah[ks], al[ks]);
-            }
+            for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[4 + ks], al[4 + ks]); });
             rows_to_tile(tx);                    // stays in the tile: residual of phase 2
         }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            float v[8];
-            load8(tile + l31 * TROW + 16 * ks + 8 * hi, v);
-            split8s(v, ah[ks], al[ks]);
-        }
+        for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[ks], al[ks]); });
         TR(1);
-        stage_wait();
+        stage_wait<(LOOKAHEAD - 1) * DMA_SLICES>();
         TR(2);
 
-        // ---- phase 1: 8 row blocks of W1 -> hidden fragments (k-steps 2 rb, 2 rb + 1 of phase 2) ----
-        f16x8 hh[16], hl[16];
-        // units: 0 bias read | 1-4 combine | 5 + bias | 6, 7 ReLU | 8-13 split
-        auto e1 = [&](int rb, const SplitAcc& c, int u) __attribute__((always_inline)) {
-            if (u == 0) load_bias16(bias1 + rb * 32);
-            else if (u <= 4) combine4(c, u - 1);
-            else if (u == 5) {
+        // ---- phase 1: 8 units of W1 -> hidden fragments (k-step rb of phase 2) ----
+        f16x8 hh[8], hl[8];
+        // steps: 0 bias read | 1, 2 combine | 3 + bias | 4 ReLU | 5-9 split
+        auto e1 = [&](int rb, const UnitAcc& c, int u) __attribute__((always_inline)) {
+            if (u == 0) load_bias8(bias1 + rb * 32);
+            else if (u <= 2) combine(c, u - 1);
+            else if (u == 3) {
 #pragma unroll
-                for (int j = 0; j < 16; ++j) pv[j] = o[j] + pbias[j];
-            } else if (u == 6 || u == 7) {
+                for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias[j];
+            } else if (u == 4) {
 #pragma unroll
-                for (int j = 8 * (u - 6); j < 8 * (u - 5); ++j) pv[j] = fmaxf(pv[j], 0.f);
-            } else if (u <= 13) split_unit(u - 8, *reinterpret_cast<f16x8(*)[2]>(&hh[2 * rb]), *reinterpret_cast<f16x8(*)[2]>(&hl[2 * rb]));
+                for (int j = 0; j < 8; ++j) pv[j] = fmaxf(pv[j], 0.f);
+            } else if (u <= 9) split_step(u - 5, hh[rb], hl[rb]);
         };
-        // K = 256 blocks have 48 slots: a unit in every other one, a stage copy in the slot behind it
+        // K = 256 units have 48 slots: a step in every other one, the stage copies in slots 6 i + 1
+        // end of stage h: the copies of stages h + 2 and h + 3 may still be in flight
+        auto end_stage = [&](int h) __attribute__((always_inline)) {
+            if (h + 3 < NSTAGE) stage_wait<2 * DMA_SLICES>();
+            else if (h + 2 < NSTAGE) stage_wait<DMA_SLICES>();
+            else stage_wait<0>();
+        };
         for_units<8>([&](int rb) __attribute__((always_inline)) {
-            const _Float16* wnext = rb < 7 ? a.w1s + (size_t)(rb + 1) * 32 * ROWH256 : a.w2s;
             TR(10);
-            block_mma_il<16, true, ROWH256>(bufp(rb), wrow, hi, ah, al, acc[rb & 1], [&](int slot) __attribute__((always_inline)) {
-                if ((slot & 1) && slot < 18) stage_dma_slice(wnext, ldsb(rb + 1), wave, lane, slot >> 1);
-                if (!(slot & 1) && rb > 0) e1(rb - 1, acc[(rb - 1) & 1], slot >> 1);
-            });
+            // slots 0 .. 23: row block P, 24 .. 47: row block Q; the pending epilogue in every other slot
+            auto inter = [&](int h, int base) __attribute__((always_inline)) {
+                return [&, h, base](int slot) __attribute__((always_inline)) {
+                    if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(h, slot / 6);
+                    if (slot % 2 == 0 && rb > 0) e1(rb - 1, acc[(rb - 1) & 1], (base + slot) / 2);
+                };
+            };
+            block_mma16<8, ROWH256>(bufp(2 * rb), l15, g, ah, al, acc[rb & 1].pm, acc[rb & 1].px, inter(2 * rb, 0));
+            end_stage(2 * rb);
+            block_mma16<8, ROWH256>(bufp(2 * rb + 1), l15, g, ah, al, acc[rb & 1].qm, acc[rb & 1].qx, inter(2 * rb + 1, 24));
             TR(11);
-            stage_wait();
+            end_stage(2 * rb + 1);
             TR(12);
         });
 
-        // ---- phase 2: 4 row blocks of W2, residual, new x (fp32 into the tile, split fragments kept) ----
-        // units: 0 bias + residual read | 1-4 combine | 5 + bias | 6 + residual | 7 tile write | 8-13 split
-        auto e2 = [&](int ob, const SplitAcc& c, int u) __attribute__((always_inline)) {
+        // ---- phase 2: 4 units of W2, residual, new x (fp32 into the tile, split fragments kept) ----
+        // steps: 0 bias + residual read | 1, 2 combine | 3 + bias | 4 + residual | 5 tile write | 6-10 split
+        auto e2 = [&](int ob, const UnitAcc& c, int u) __attribute__((always_inline)) {
             if (u == 0) {
-                load_bias16(bias2 + ob * 32);
+                load_bias8(bias2 + ob * 32);
+                load8(tile + l15 * TROW + ob * 32 + 8 * g, phf);
+            } else if (u <= 2) combine(c, u - 1);
+            else if (u == 3) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float r8[8];
-                    load8(tile + l31 * TROW + ob * 32 + 16 * t + 8 * hi, r8);
+                for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias[j];
+            } else if (u == 4) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) phf[8 * t + j] = r8[j];
-                }
-            } else if (u <= 4) combine4(c, u - 1);
-            else if (u == 5) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) pv[j] = o[j] + pbias[j];
-            } else if (u == 6) {
-#pragma unroll
-                for (int j = 0; j < 16; ++j) pv[j] += phf[j];
-            } else if (u == 7) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    float v8[8];
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v8[j] = pv[8 * t + j];
-                    store8(tile + l31 * TROW + ob * 32 + 16 * t + 8 * hi, v8);
-                }
-            } else if (u <= 13) split_unit(u - 8, *reinterpret_cast<f16x8(*)[2]>(&xnh[2 * ob]), *reinterpret_cast<f16x8(*)[2]>(&xnl[2 * ob]));
+                for (int j = 0; j < 8; ++j) pv[j] += phf[j];
+            } else if (u == 5) store8(tile + l15 * TROW + ob * 32 + 8 * g, pv);
+            else if (u <= 10) split_step(u - 6, xnh[ob], xnl[ob]);
         };
         for_units<4>([&](int ob) __attribute__((always_inline)) {
-            const _Float16* wnext = ob < 3 ? a.w2s + (size_t)(ob + 1) * 32 * ROWH256 : a.w3s;
+            constexpr int H0 = 16;
             TR(20);
-            block_mma_il<16, true, ROWH256>(bufp(ob), wrow, hi, hh, hl, acc[ob & 1], [&](int slot) __attribute__((always_inline)) {
-                if ((slot & 1) && slot < 18) stage_dma_slice(wnext, ldsb(ob + 1), wave, lane, slot >> 1);
-                if (slot & 1) return;
-                if (ob == 0) e1(7, acc[1], slot >> 1);
-                else e2(ob - 1, acc[(ob - 1) & 1], slot >> 1);
-            });
+            auto inter = [&](int h, int base) __attribute__((always_inline)) {
+                return [&, h, base](int slot) __attribute__((always_inline)) {
+                    if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(h, slot / 6);
+                    if (slot % 2 != 0) return;
+                    if (ob == 0) e1(7, acc[1], (base + slot) / 2);
+                    else e2(ob - 1, acc[(ob - 1) & 1], (base + slot) / 2);
+                };
+            };
+            block_mma16<8, ROWH256>(bufp(H0 + 2 * ob), l15, g, hh, hl, acc[ob & 1].pm, acc[ob & 1].px, inter(H0 + 2 * ob, 0));
+            end_stage(H0 + 2 * ob);
+            block_mma16<8, ROWH256>(bufp(H0 + 2 * ob + 1), l15, g, hh, hl, acc[ob & 1].qm, acc[ob & 1].qx, inter(H0 + 2 * ob + 1, 24));
             TR(21);
-            stage_wait();
+            end_stage(H0 + 2 * ob + 1);
             TR(22);
         });
-        // the epilogue of the last block (set 1) is not overlapped: phase 3 needs all of the new x
-        for_units<E_UNITS>([&](int u) __attribute__((always_inline)) { e2(3, acc[1], u); });
+        // the epilogue of the last unit (set 1) is not overlapped: phase 3 needs all of the new x
+        for_units<E_STEPS>([&](int u) __attribute__((always_inline)) { e2(3, acc[1], u); });
         TR(23);
         tile_to_rows(a.x);                       // the tile is free afterwards
         TR(24);
     } else {
         {
-            f32x4 tx[16];
+            f32x4 tx[8];
             rows_load(a.x, tx);
+            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tx);
         }
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks) {
-            float v[8];
-            load8(tile + l31 * TROW + 16 * ks + 8 * hi, v);
-            split8s(v, xnh[ks], xnl[ks]);
-        }
-        stage_wait();
+        for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, xnh[ks], xnl[ks]); });
+        stage_wait<(LOOKAHEAD - 1) * DMA_SLICES>();
     }
 
-    // ---- phase 3: q | k | v of the next layer (12 row blocks) or the final projection (4), two row blocks
-    //      per stage; after an even number of stages the first stage of W3 is in buffer 0 in both branches.
-    //      K = 128 blocks have 24 slots for the 22 units; the stage copies ride in the first slot of a k-step ----
-    for_units<NB3 / 2>([&](int j) __attribute__((always_inline)) {
-        const bool more = j + 1 < NB3 / 2;
-        const _Float16* wnext = a.w3s + (size_t)(j + 1) * 64 * ROWH128;
-        const _Float16* cur = bufp(j);
+    // ---- phase 3: q | k | v of the next layer (12 units) or the final projection (4), one unit per stage.
+    //      K = 128 units have 24 slots: a step of the previous unit's epilogue in every slot up to E_STEPS ----
+    for_units<NB3>([&](int q) __attribute__((always_inline)) {
+        constexpr int H0 = DO_MLP ? 24 : 0;
+        const _Float16* cur = bufp(H0 + q);
         TR(30);
-        const int qa = 2 * j, qb = 2 * j + 1;
-        // block A (accumulator set 0); in its shadow: the epilogue of the previous block
-        auto inter_a = [&](int slot) __attribute__((always_inline)) {
-            if (more && slot % 3 == 0) stage_dma_slice(wnext, ldsb(j + 1), wave, lane, slot / 3);          // chunks 0 .. 7
-            if (j > 0) e3(qa - 1, acc[1], slot);
+        auto inter = [&](int slot) __attribute__((always_inline)) {
+            if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(H0 + q, slot / 6);
+            if (q > 0) e3(q - 1, acc[(q - 1) & 1], slot);
         };
-        if (MODE3 == 1 && qa >= 8) block_mma_il<8, false, ROWH128>(cur, l31, hi, xnh, xnl, acc[0], inter_a);
-        else block_mma_il<8, true, ROWH128>(cur, wrow, hi, xnh, xnl, acc[0], inter_a);
-        TR(31);
-        // block B (set 1); in its shadow: the epilogue of block A
-        auto inter_b = [&](int slot) __attribute__((always_inline)) {
-            if (more && slot == 0) stage_dma_slice(wnext, ldsb(j + 1), wave, lane, 8);
-            e3(qa, acc[0], slot);
-        };
-        if (MODE3 == 1 && qb >= 8) block_mma_il<8, false, ROWH128>(cur + 32 * ROWH128, l31, hi, xnh, xnl, acc[1], inter_b);
-        else block_mma_il<8, true, ROWH128>(cur + 32 * ROWH128, wrow, hi, xnh, xnl, acc[1], inter_b);
+        if (MODE3 == 1 && q >= 8) unit_mma16<4, false, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
+        else unit_mma16<4, true, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         TR(32);
-        if (more) stage_wait();
+        if (q + 1 < NB3) {
+            if (H0 + q + 3 < NSTAGE) stage_wait<2 * DMA_SLICES>();
+            else if (H0 + q + 2 < NSTAGE) stage_wait<DMA_SLICES>();
+            else stage_wait<0>();
+        }
         TR(33);
     });
-    for_units<E_UNITS>([&](int u) __attribute__((always_inline)) { e3(NB3 - 1, acc[1], u); });
+    for_units<E_STEPS>([&](int u) __attribute__((always_inline)) { e3(NB3 - 1, acc[(NB3 - 1) & 1], u); });
     if (MODE3 != 1) tile_to_rows(a.mdesc);
     TR(40);
 #ifdef LAYER_TRACE
@@ -494,23 +555,30 @@ __global__ __launch_bounds__(256, 1) void layer_kernel(LayerArgs a) {
 #endif
 }
 
-// fp32 [rows][K] -> split image [rows][rowh] (hi plane | lo plane | pad), once per weight load
-__global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float16* out, int rows, int K, int rowh) {
+// fp32 [rows][K] -> split image [rows][rowh] (hi plane | lo plane | pad), once per weight load.  The first `nperm`
+// rows (a multiple of 32) go out in the P/Q order of layer_kernel: within a unit of 32 channels, image row j < 16
+// holds channel 8 (j >> 2) + (j & 3), image row 16 + j holds channel 8 (j >> 2) + 4 + (j & 3).
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float16* out, int rows, int K, int rowh, int nperm) {
     const size_t total = (size_t)rows * K;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const size_t r = i / K, c = i - r * K;
+        const int r = (int)(i / K), c = (int)(i - (size_t)r * K);      // image row, column
+        int src = r;
+        if (r < nperm) {
+            const int j = r & 15, q = (r >> 4) & 1;
+            src = (r & ~31) + 8 * (j >> 2) + 4 * q + (j & 3);
+        }
         _Float16 h, l;
-        mdgat_split(w[i], h, l);
-        out[r * rowh + c] = h;
-        out[r * rowh + K + c] = l;
+        mdgat_split(w[(size_t)src * K + c], h, l);
+        out[(size_t)r * rowh + c] = h;
+        out[(size_t)r * rowh + K + c] = l;
     }
 }
 
 template <int DO_MLP, int MODE3>
 int launch_layer_t(const LayerArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)2 * STAGE_BYTES + (768 + 4 * TILE_FLOATS) * sizeof(float)
+    const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + 8 * TILE_FLOATS) * sizeof(float)
 #ifdef LAYER_TRACE
-        + 4 * 256 * 8
+        + 8 * 256 * 8
 #endif
         ;
     static bool attr = false;
@@ -520,16 +588,16 @@ int launch_layer_t(const LayerArgs& a, hipStream_t s) {
             return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + 127) / 128), dim3(256), lds, s, a);
+    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "layer launch");
 }
 
 }  // namespace
 
-int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, hipStream_t s) {
+int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, int nperm, hipStream_t s) {
     const size_t total = (size_t)rows * K;
     const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, w, out, rows, K, rowh);
+    hipLaunchKernelGGL(split_rows_kernel, dim3(blocks), dim3(256), 0, s, w, out, rows, K, rowh, nperm);
     return mdgat_check_hip(hipGetLastError(), "split_rows launch");
 }
 
