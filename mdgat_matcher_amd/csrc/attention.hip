@@ -47,8 +47,31 @@ __device__ __forceinline__ int xor32i(int v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)p[j];
+    // residual p - (float)h straight from the packed halves: one v_fma_mix_f32 per value instead of a conversion
+    // back and a subtraction (the kernels that use this are bound by their vector instruction count)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 hp = __builtin_bit_cast(u32x4, h);
+    float r[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) l[j] = (_Float16)(p[j] - (float)h[j]);
+    for (int j = 0; j < 4; ++j) {
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r[2 * j]) : "v"(p[2 * j]), "v"(hp[j]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[2 * j + 1]) : "v"(p[2 * j + 1]), "v"(hp[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = (_Float16)r[j];
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers); the row sum in two packed halves
+template <bool TOPK>
+__device__ __forceinline__ void softmax8(const float* s, float m11, float thr, float (&p)[8], f32x2& l2) {
+#pragma unroll
+    for (int j = 0; j < 8; j += 2) {
+        const f32x2 d = f32x2{s[j], s[j + 1]} - f32x2{m11, m11};
+        f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+        if (TOPK) { e[0] = (s[j] >= thr) ? e[0] : 0.f; e[1] = (s[j + 1] >= thr) ? e[1] : 0.f; }
+        p[j] = e[0]; p[j + 1] = e[1];
+        l2 += e;
+    }
 }
 
 // How the two lanes of a row (and, in the split-key kernel, the two waves of a row) combine per-row
@@ -320,7 +343,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
             ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
         }
 
-        float m_run = NEG_INF, l = 0.f;
+        float m_run = NEG_INF;
+        f32x2 l2 = {0.f, 0.f};
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
@@ -384,7 +408,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                     const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
                     m = m_new;
                     if (!__all(sc == 1.0f)) {
-                        l *= sc;
+                        l2 *= sc;
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
@@ -402,15 +426,10 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                     if (EXACT || c0 + jb < wnb) {
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            float p[8];
+                            float p[8], s8[8];
 #pragma unroll
-                            for (int j = 0; j < 8; ++j) {
-                                const float s = S[jb][8 * t + j];
-                                float e = __builtin_amdgcn_exp2f(s - m11);
-                                if (TOPK) e = (s >= thr) ? e : 0.f;
-                                p[j] = e;
-                                l += e;
-                            }
+                            for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
+                            softmax8<TOPK>(s8, m11, thr, p, l2);
                             f16x8 ph, pl;
                             split8(p, ph, pl);
                             const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
@@ -424,6 +443,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 }
             }
         }
+        float l = l2[0] + l2[1];
         l += xor32(l);
         const float inv_l = 1.0f / l;
 
@@ -536,7 +556,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 
         // ---- P' = 2048 exp2(s - m), masked; O = P' V with two key blocks per k-step ----
         const float m11 = m - 11.0f;
-        float l = 0.f;
+        f32x2 l2 = {0.f, 0.f};
         f32x4 Om[2], Ox[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { Om[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ox[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -544,15 +564,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         for (int c = 0; c < 8; ++c) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {             // key blocks 4 c + 2 jj and 4 c + 2 jj + 1
-                float p[8];
+                float p[8], s8[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float s = S[c][8 * jj + i];
-                    float e = __builtin_amdgcn_exp2f(s - m11);
-                    e = (s >= thr) ? e : 0.f;
-                    p[i] = e;
-                    l += e;
-                }
+                for (int i = 0; i < 8; ++i) s8[i] = S[c][8 * jj + i];
+                softmax8<true>(s8, m11, thr, p, l2);
                 f16x8 ph, pl;
                 split8(p, ph, pl);
                 const int key0 = (4 * c + 2 * jj) * 16 + 4 * g;  // this lane's keys: key0 .. key0 + 3 and key0 + 16 .. key0 + 19
@@ -570,7 +585,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 }
             }
         }
-        l = comm.rsum(l);
+        const float l = comm.rsum(l2[0] + l2[1]);
         const float inv_l = 1.0f / l;
         // ---- message rows: lane (dim l15 (+16 t), g) holds queries 4 g + r ----
         float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l15;
@@ -713,7 +728,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
 
         const float m11 = m - 11.0f;
-        float l = 0.f;
+        f32x2 l2 = {0.f, 0.f};
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
@@ -723,15 +738,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             if (gb < nblk) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
-                    float p[8];
+                    float p[8], s8[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float s = S[jb][8 * t + j];
-                        float e = __builtin_amdgcn_exp2f(s - m11);
-                        e = (s >= thr) ? e : 0.f;
-                        p[j] = e;
-                        l += e;
-                    }
+                    for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
+                    softmax8<true>(s8, m11, thr, p, l2);
                     f16x8 ph, pl;
                     split8(p, ph, pl);
                     const _Float16* vp = vg + gb * 32 + t * 16;
@@ -743,6 +753,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 }
             }
         }
+        float l = l2[0] + l2[1];
         l += xor32(l);
         float* ob = obuf + wave * 17 * 64;
 #pragma unroll
