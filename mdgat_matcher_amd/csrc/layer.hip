@@ -72,6 +72,7 @@ constexpr int SLOT_CHUNKS = 17;
 constexpr int SLOT_BYTES = SLOT_CHUNKS * 1024;
 constexpr int SLOT_HALVES = SLOT_BYTES / 2;
 constexpr int NSLOT = 4, LOOKAHEAD = 3;
+constexpr int NWAVE = 8;                     // waves per workgroup (16 keypoints each): 128 keypoints, one workgroup per CU
 constexpr int WPTS = 16;                     // keypoints per wave
 constexpr int TROW = 132;                    // floats per row of a wave's activation tile (128 channels + 16 B pad)
 constexpr int TILE_FLOATS = WPTS * TROW;     // [16 keypoints][TROW]: 8448 B per wave
@@ -105,13 +106,13 @@ struct LayerArgs {
 // behind the copy); completion is awaited explicitly (stage_wait) before the stage barrier.  The 3 copies of a
 // wave are issued one at a time between the matrix instructions of the running stage.
 __device__ __forceinline__ void stage_dma_slice(const _Float16* g, unsigned lds_addr, int wave, int lane, int i) {
-    const int c = min(wave + 8 * i, SLOT_CHUNKS - 1);      // (waves 1-7 copy the last chunk once more: no branch)
+    const int c = min(wave + NWAVE * i, SLOT_CHUNKS - 1);  // (the last chunk is copied more than once: no branch)
     // scalar base + per-lane 32-bit offset: the address arithmetic stays on the scalar unit
     const char* src = reinterpret_cast<const char*>(g) + c * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_addr + c * 1024), "v"(lane * 16), "s"(src) : "memory");
 }
-constexpr int DMA_SLICES = 3;
+constexpr int DMA_SLICES = (SLOT_CHUNKS + NWAVE - 1) / NWAVE;
 __device__ __forceinline__ void stage_dma(const _Float16* g, unsigned lds_addr, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < DMA_SLICES; ++i) stage_dma_slice(g, lds_addr, wave, lane, i);
@@ -131,6 +132,14 @@ __device__ __forceinline__ void stage_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
     __syncthreads();
 }
+// end of stage h of nstage: the copies of stages h + 2 .. h + LOOKAHEAD that exist may still be in flight
+__device__ __forceinline__ void end_of_stage(int h, int nstage) {
+    const int younger = min(LOOKAHEAD - 1, max(nstage - 2 - h, 0));
+    if (younger >= 2) stage_wait<2 * DMA_SLICES>();
+    else if (younger == 1) stage_wait<DMA_SLICES>();
+    else stage_wait<0>();
+}
+static_assert(LOOKAHEAD <= 3, "end_of_stage handles up to two copies in flight");
 
 // Accumulators of one 32-channel unit: row blocks P and Q, each m = hi.hi and x = hi.lo + lo.hi (to be scaled by
 // 1/2048 when combined).
@@ -204,7 +213,7 @@ __device__ __forceinline__ void block_mma16(const _Float16* buf, int l15, int g,
 
 // DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 units), 2: final projection (4).
 template <int DO_MLP, int MODE3>
-__global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
+__global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 4 stage slots, 768 floats of biases, 8 tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -221,7 +230,8 @@ __global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
     // source, new x written in place), then serves as the staging tile of the phase-3 outputs.
     float* tile = bias3 + 384 + wave * TILE_FLOATS;
     _Float16* tile16 = reinterpret_cast<_Float16*>(tile);
-    const int wave_pt0 = blockIdx.x * 128 + wave * WPTS;
+    constexpr int NT = 64 * NWAVE, TILE_PTS = WPTS * NWAVE;
+    const int wave_pt0 = blockIdx.x * TILE_PTS + wave * WPTS;
     constexpr int NB3 = MODE3 == 1 ? 12 : 4;      // units of phase 3 (two per stage)
 
 #ifdef LAYER_TRACE
@@ -243,10 +253,10 @@ __global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
     };
     TR(0);
     if (DO_MLP) {
-        if (tid < 256) bias1[tid] = a.b1[tid];
-        else if (tid < 384) bias2[tid - 256] = a.b2[tid - 256];
+        for (int i = tid; i < 256; i += NT) bias1[i] = a.b1[i];
+        for (int i = tid; i < 128; i += NT) bias2[i] = a.b2[i];
     }
-    for (int i = tid; i < NB3 * 32; i += 512) bias3[i] = a.b3[i];
+    for (int i = tid; i < NB3 * 32; i += NT) bias3[i] = a.b3[i];
 
     // [R][128] fp32 rows of this wave's 16 keypoints <-> tile: half a wave per 512-byte row; all 8 loads of a
     // matrix are in flight together
@@ -455,17 +465,13 @@ __global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
         };
         // K = 256 units have 48 slots: a step in every other one, the stage copies in slots 6 i + 1
         // end of stage h: the copies of stages h + 2 and h + 3 may still be in flight
-        auto end_stage = [&](int h) __attribute__((always_inline)) {
-            if (h + 3 < NSTAGE) stage_wait<2 * DMA_SLICES>();
-            else if (h + 2 < NSTAGE) stage_wait<DMA_SLICES>();
-            else stage_wait<0>();
-        };
+        auto end_stage = [&](int h) __attribute__((always_inline)) { end_of_stage(h, NSTAGE); };
         for_units<8>([&](int rb) __attribute__((always_inline)) {
             TR(10);
             // slots 0 .. 23: row block P, 24 .. 47: row block Q; the pending epilogue in every other slot
             auto inter = [&](int h, int base) __attribute__((always_inline)) {
                 return [&, h, base](int slot) __attribute__((always_inline)) {
-                    if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(h, slot / 6);
+                    if (slot % 4 == 1 && slot / 4 < DMA_SLICES) copy_ahead(h, slot / 4);
                     if (slot % 2 == 0 && rb > 0) e1(rb - 1, acc[(rb - 1) & 1], (base + slot) / 2);
                 };
             };
@@ -498,7 +504,7 @@ __global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
             TR(20);
             auto inter = [&](int h, int base) __attribute__((always_inline)) {
                 return [&, h, base](int slot) __attribute__((always_inline)) {
-                    if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(h, slot / 6);
+                    if (slot % 4 == 1 && slot / 4 < DMA_SLICES) copy_ahead(h, slot / 4);
                     if (slot % 2 != 0) return;
                     if (ob == 0) e1(7, acc[1], (base + slot) / 2);
                     else e2(ob - 1, acc[(ob - 1) & 1], (base + slot) / 2);
@@ -534,17 +540,13 @@ __global__ __launch_bounds__(512) void layer_kernel(LayerArgs a) {
         const _Float16* cur = bufp(H0 + q);
         TR(30);
         auto inter = [&](int slot) __attribute__((always_inline)) {
-            if (slot % 6 == 1 && slot / 6 < DMA_SLICES) copy_ahead(H0 + q, slot / 6);
+            if (slot % 4 == 1 && slot / 4 < DMA_SLICES) copy_ahead(H0 + q, slot / 4);
             if (q > 0) e3(q - 1, acc[(q - 1) & 1], slot);
         };
         if (MODE3 == 1 && q >= 8) unit_mma16<4, false, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         else unit_mma16<4, true, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         TR(32);
-        if (q + 1 < NB3) {
-            if (H0 + q + 3 < NSTAGE) stage_wait<2 * DMA_SLICES>();
-            else if (H0 + q + 2 < NSTAGE) stage_wait<DMA_SLICES>();
-            else stage_wait<0>();
-        }
+        if (q + 1 < NB3) end_of_stage(H0 + q, NSTAGE);
         TR(33);
     });
     for_units<E_STEPS>([&](int u) __attribute__((always_inline)) { e3(NB3 - 1, acc[(NB3 - 1) & 1], u); });
@@ -576,7 +578,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float1
 
 template <int DO_MLP, int MODE3>
 int launch_layer_t(const LayerArgs& a, hipStream_t s) {
-    const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + 8 * TILE_FLOATS) * sizeof(float)
+    const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + NWAVE * TILE_FLOATS) * sizeof(float)
 #ifdef LAYER_TRACE
         + 8 * 256 * 8
 #endif
@@ -588,7 +590,8 @@ int launch_layer_t(const LayerArgs& a, hipStream_t s) {
             return rc;
         attr = true;
     }
-    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + 127) / 128), dim3(512), lds, s, a);
+    constexpr int TILE_PTS = WPTS * NWAVE;
+    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "layer launch");
 }
 
