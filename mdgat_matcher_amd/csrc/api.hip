@@ -298,14 +298,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     // ---- final projection (mdgat.py:397, computed by the last launch above) and score matrix (430-431) ----
     if (taps && taps->mdesc)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
-    {
-        GemmArgs g{};
-        g.A0 = mdesc; g.lda0 = 128; g.K0 = 128; g.W = mdesc + (size_t)N * 128; g.ldw = 128;
-        g.C = ws.scores; g.ldc = M; g.M = N; g.N = M; g.K = 128; g.relu = 0;
-        g.scale = 0.08838834764831845f;   // 1 / sqrt(128)
-        g.batch = B; g.sA = (long long)P * 128; g.sW = (long long)P * 128; g.sC = (long long)N * M;
-        if ((rc = launch_gemm(g, s))) return rc;
-    }
+    if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s))) return rc;
     mark(MDGAT_PROF_SCORES);
     if (taps && taps->scores)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;

@@ -67,6 +67,8 @@ struct GemmArgs {
     long long sA, sW, sC;                // batch strides (elements) of A0, W, C
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
+// score matrix [B][N][M] = mdesc0 . mdesc1^T * scale from mdesc [B][N + M][128] (scores.hip)
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s);
 
 // fused encoders (encoder.hip).  es = split weights [kenc.3 64x2x32 | kenc.6 128x2x64 | denc.0 64x2x48 | denc.3 128x2x64 |
 // last convs 128x2x256]; inputs either as separate arrays or as raw 37-float frame records

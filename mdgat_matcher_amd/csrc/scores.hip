@@ -1,0 +1,106 @@
+// Score matrix of the optimal-transport layer: scores[b][i][j] = <mdesc0[b][i], mdesc1[b][j]> / sqrt(128)
+// (mdgat.py:430-431, einsum 'bdn,bdm->bnm' over the 128 projected channels).
+//
+// Split-f16 products like the rest of the network (common.hpp): a 128 x 128 tile per workgroup, both operand
+// tiles are split to f16 (hi | lo) on the way into LDS, 8 waves (2 per SIMD) of 64 x 32 outputs each, three
+// v_mfma_f32_32x32x16_f16 per product.  12.9 GFLOP executed per launch at B = 64, N = M = 512.
+#include "common.hpp"
+
+namespace {
+
+constexpr int SROW = 264;     // LDS row (halves): 128 hi | 128 lo | 8 pad (528 B: conflict-free ds_read_b128 fragments)
+
+struct ScoreArgs {
+    const float* mdesc;       // [B][N + M][128]
+    float* scores;            // [B][N][M]
+    int N, M;
+    float scale;
+};
+
+__global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
+    extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // As[128][SROW] | Bs[128][SROW]
+    _Float16* As = smem;
+    _Float16* Bs = smem + 128 * SROW;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
+    const int P = a.N + a.M;
+    const float* A = a.mdesc + (size_t)b * P * 128;
+    const float* Bm = A + (size_t)a.N * 128;
+
+    // ---- both operand tiles: fp32 rows -> (hi | lo) halves in LDS; 8 x 16-byte loads per thread and operand ----
+    auto stage = [&](const float* src, int r0, int nrows, _Float16* dst) {
+        f32x4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 512 + tid, row = idx >> 5, c = idx & 31;
+            x[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(r0 + row, nrows - 1) * 128 + c * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = u * 512 + tid, row = idx >> 5, c = idx & 31;
+            _Float16 h[4], l[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) mdgat_split(x[u][j], h[j], l[j]);
+            *reinterpret_cast<f16x4*>(dst + row * SROW + c * 4) = f16x4{h[0], h[1], h[2], h[3]};
+            *reinterpret_cast<f16x4*>(dst + row * SROW + 128 + c * 4) = f16x4{l[0], l[1], l[2], l[3]};
+        }
+    };
+    stage(A, i0, a.N, As);
+    stage(Bm, j0, a.M, Bs);
+    __syncthreads();
+
+    // ---- wave (wr, wc): rows 64 wr .. + 63, columns 32 wc .. + 31 of the tile ----
+    const int wr = wave >> 2, wc = wave & 3;
+    f32x16 acc[2], acx[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[t][r] = 0.f; acx[t][r] = 0.f; }
+    const _Float16* ap = As + (64 * wr + l31) * SROW + 8 * hi;
+    const _Float16* bp = Bs + (32 * wc + l31) * SROW + 8 * hi;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+        const f16x8 bh = *reinterpret_cast<const f16x8*>(bp + 16 * ks);
+        const f16x8 bl = *reinterpret_cast<const f16x8*>(bp + 128 + 16 * ks);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f16x8 ah = *reinterpret_cast<const f16x8*>(ap + 32 * t * SROW + 16 * ks);
+            const f16x8 al = *reinterpret_cast<const f16x8*>(ap + 32 * t * SROW + 128 + 16 * ks);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            acx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acx[t], 0, 0, 0);
+            acx[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acx[t], 0, 0, 0);
+        }
+    }
+    // ---- D fragment: lane (column l31, hi) holds rows mfma32_row(r, hi); a half wave writes 128 contiguous bytes ----
+    const int j = j0 + 32 * wc + l31;
+    if (j < a.M) {
+        float* out = a.scores + ((size_t)b * a.N) * a.M + j;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + 64 * wr + 32 * t + mfma32_row(r, hi);
+                if (i < a.N) out[(size_t)i * a.M] = fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale;
+            }
+    }
+}
+
+}  // namespace
+
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s) {
+    if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
+    ScoreArgs a{mdesc, scores, N, M, scale};
+    const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
+    static bool attr = false;
+    if (!attr) {
+        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_kernel),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "scores LDS attribute"))
+            return rc;
+        attr = true;
+    }
+    hipLaunchKernelGGL(scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
+    return mdgat_check_hip(hipGetLastError(), "scores launch");
+}
