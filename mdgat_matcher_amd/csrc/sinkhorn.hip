@@ -232,18 +232,34 @@ constexpr int SKS_THREADS = 512;
 constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8 + 8 * 512;
 constexpr int ROW_STRIDE = 136;
 
+// Granule traffic between the workgroups of a pair.  Agent scope (sc1) works wherever the partners run.  When all of
+// them report the same XCC_ID (checked per pair with an agent-scope exchange first), they share one L2, and
+// non-temporal 8-byte accesses (not kept in the CU's L1, served by that L2) carry the hand-off at lower latency.
+__device__ __forceinline__ unsigned long long xload(gu64* p, bool same_xcd) {
+    if (same_xcd) {
+        unsigned long long v;
+        asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        return v;
+    }
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xstore(gu64* p, unsigned long long v, bool same_xcd) {
+    if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+    else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // Poll the granules `base[p * stride]`, p in [0, n) except `self`, until they carry `tag`; all outstanding partners are
 // polled concurrently.  vals[p] receives the payloads.  Bounded: a timeout sets the error word.
 template <int NMAX>
 __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, int self, unsigned tag, float (&vals)[NMAX],
-                                              bool& failed, unsigned* error_word) {
+                                              bool& failed, unsigned* error_word, bool same_xcd = false) {
     unsigned pending = ((1u << n) - 1u) & ~(1u << self);
     unsigned spins = 0;
     while (pending) {
         unsigned long long x[NMAX];
 #pragma unroll
         for (int p = 0; p < NMAX; ++p)
-            if (pending & (1u << p)) x[p] = __hip_atomic_load(base + (size_t)p * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (pending & (1u << p)) x[p] = xload(base + (size_t)p * stride, same_xcd);
 #pragma unroll
         for (int p = 0; p < NMAX; ++p)
             if ((pending & (1u << p)) && (unsigned)(x[p] >> 32) == tag) {
@@ -300,7 +316,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
     const size_t col_slots = (size_t)2 * GC * GR * SLOT_STRIDE, row_slots = (size_t)2 * GR * GC * ROW_STRIDE;
     gu64* cslots = (gu64*)(a.slots) + (size_t)group * (col_slots + row_slots);
     gu64* rslots = cslots + col_slots;
-    unsigned cep = 0, rep_ = 0;           // column / row exchange counters (granule tags)
+    unsigned cep = 0, rep_ = 0, xep = 0;  // column / row / XCC-id exchange counters (granule tags)
     bool failed = false;
     const float RANGE_HI = 1.099511627776e12f, RANGE_LO = 9.094947017729282e-13f;   // 2^40, 2^-40
 
@@ -387,6 +403,28 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         float krt = 1.f, v0t = 0.f, bt = 1.f;
         __syncthreads();                  // previous pair's readers of the LDS vectors are done
         if (tid == 0) flags[0] = 0;
+        // do all row-slab partners of this pair sit on one XCD?  (slot 513 of the parity-0 buffer, agent scope)
+        bool same_xcd = false;
+        if (!TWO_D && GR > 1) {
+            ++xep;
+            if (tid == 0) {
+                const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;     // HW_REG_XCC_ID[3:0]
+                gu64* xb = cslots + (size_t)jc * GR * SLOT_STRIDE + 513;
+                const unsigned xtag = 0x80000000u | xep;
+                __hip_atomic_store(xb + (size_t)jr * SLOT_STRIDE, ((unsigned long long)xtag << 32) | my_xcc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                float ids[GMAX];
+#pragma unroll
+                for (int pp = 0; pp < GMAX; ++pp) ids[pp] = 0.f;
+                poll_partners<GMAX>(xb, SLOT_STRIDE, GR, jr, xtag, ids, failed, a.error_word);
+                bool same = !failed;
+#pragma unroll
+                for (int pp = 0; pp < GMAX; ++pp)
+                    if (pp < GR && pp != jr && __builtin_bit_cast(unsigned, ids[pp]) != my_xcc) same = false;
+                flags[1] = same ? 1 : 0;
+            }
+            __syncthreads();
+            same_xcd = flags[1] != 0;
+        }
 
         for (int it = 0; it < a.iters; ++it) {
             // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
@@ -444,9 +482,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
                     for (int pp = 0; pp < GMAX; ++pp) vals[pp] = 0.f;
                     if (GR > 1) {
-                        __hip_atomic_store(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word);
+                        xstore(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
+                        poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd);
                     }
                     float total = 0.f;
 #pragma unroll
@@ -462,12 +499,11 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     for (int ww = 1; ww < 8; ++ww) loc += pdust[ww];
                     float mine = loc;
                     if (GR > 1) {
-                        if (lane == 0) __hip_atomic_store(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, loc),
-                                                          __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (lane == 0) xstore(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
                         if (lane < GR && lane != jr) {
                             unsigned spins = 0;
                             while (true) {
-                                const unsigned long long x = __hip_atomic_load(base + (size_t)lane * SLOT_STRIDE + 512, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const unsigned long long x = xload(base + (size_t)lane * SLOT_STRIDE + 512, same_xcd);
                                 if ((unsigned)(x >> 32) == cep) { mine = __builtin_bit_cast(float, (unsigned)x); break; }
                                 if (failed || ++spins > (1u << 22)) { failed = true; atomicOr(a.error_word, 1u); break; }
                                 __builtin_amdgcn_s_sleep(1);
