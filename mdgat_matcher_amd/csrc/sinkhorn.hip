@@ -189,6 +189,41 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Sixteen wave-wide sums at once: acc[r] = this lane's partial of row r; returns, in lane r (< 16), the wave total of
+// row r.  Each stage halves the number of registers while doubling the lanes already summed: lane-half swap
+// (v_permlane32_swap), 16-lane-row swap (v_permlane16_swap), row rotation by 8, bank shifts by 4, two quad steps -
+// about 40 instructions and short dependency chains instead of sixteen 7-deep DPP chains.  (The permlane swaps go
+// through inline asm: the clang builtins of this ROCm return the first result twice.)
+__device__ __forceinline__ void swap_halves32(float& a, float& b) { asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+template <int CTRL, int BANK>
+__device__ __forceinline__ float dpp_bank_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));
+}
+__device__ __forceinline__ float wave_sum16(float (&acc)[16], int lane) {
+    float s[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { float x = acc[r], y = acc[r + 8]; swap_halves32(x, y); s[r] = x + y; }   // lanes < 32: row r, others row r + 8
+    float t[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float x = s[r], y = s[r + 4]; swap_rows16(x, y); t[r] = x + y; }      // 16-lane row q: row r + 4 q
+    const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+    float v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const float keep = b3 ? t[r + 2] : t[r], give = b3 ? t[r] : t[r + 2];
+        v[r] = keep + dpp_bank_move<0x128, 0xf>(0.f, give);            // row_ror:8
+    }
+    const float keep = b2 ? v[1] : v[0], give = b2 ? v[0] : v[1];
+    float o = dpp_bank_move<0x104, 0x5>(0.f, give);                    // row_shl:4 into lanes 0-3, 8-11 of each row
+    o = dpp_bank_move<0x114, 0xa>(o, give);                            // row_shr:4 into lanes 4-7, 12-15
+    float w = keep + o;
+    w += dpp_bank_move<0xb1, 0xf>(0.f, w);                             // quad_perm [1, 0, 3, 2]
+    w += dpp_bank_move<0x4e, 0xf>(0.f, w);                             // quad_perm [2, 3, 0, 1]
+    // lanes 4 q .. 4 q + 3 hold the total of row q: bring it to lane q
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * lane, __builtin_bit_cast(int, w)));
+}
+
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 
 // ------------------------------------------------------------------------------------------------
@@ -429,13 +464,26 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         for (int it = 0; it < a.iters; ++it) {
             // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
             float psum = 0.f;
+            if (RPW == 16) {
+                float racc[16];
 #pragma unroll
-            for (int r = 0; r < RPW; ++r) {
-                float acc = K[r][0] * b[0];
+                for (int r = 0; r < 16; ++r) {
+                    float acc = K[r][0] * b[0];
 #pragma unroll
-                for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
-                const float tot = wave_sum_dpp(acc);          // wave-uniform
-                psum = (lane == r) ? tot : psum;
+                    for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
+                    racc[r] = acc;
+                }
+                psum = wave_sum16(racc, lane);                 // lane r: row r (lanes >= 16 are not used)
+                psum = lane < 16 ? psum : 0.f;
+            } else {
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    float acc = K[r][0] * b[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
+                    const float tot = wave_sum_dpp(acc);          // wave-uniform
+                    psum = (lane == r) ? tot : psum;
+                }
             }
             {
                 float pd = kr[0] * b[0];
@@ -473,6 +521,15 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             {
                 gu64* base = cslots + ((size_t)(cep & 1) * GC + jc) * GR * SLOT_STRIDE;
                 const unsigned long long tagbits = (unsigned long long)cep << 32;
+                // (b0) wave 7 publishes the dustbin column's partial sum (slot 512) BEFORE the column exchange, so that its
+                //      own poll of the partners' dustbin slots after (a) finds them already there
+                float dloc = 0.f;
+                if (wave == 7) {
+                    dloc = pdust[0];
+#pragma unroll
+                    for (int ww = 1; ww < 8; ++ww) dloc += pdust[ww];
+                    if (GR > 1 && lane == 0) xstore(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, dloc), same_xcd);
+                }
                 // (a) every thread: its own column of the slab, all row-slab partners polled concurrently
                 if (tcol_valid) {
                     float loc = colp[tid];
@@ -494,12 +551,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 }
                 // (b) wave 7: the dustbin column (slot 512), lane p polls row slab p
                 if (wave == 7) {
-                    float loc = pdust[0];
-#pragma unroll
-                    for (int ww = 1; ww < 8; ++ww) loc += pdust[ww];
-                    float mine = loc;
+                    float mine = dloc;
                     if (GR > 1) {
-                        if (lane == 0) xstore(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
                         if (lane < GR && lane != jr) {
                             unsigned spins = 0;
                             while (true) {
