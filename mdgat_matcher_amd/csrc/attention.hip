@@ -481,7 +481,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     const int k_off = src ? a.N : 0;
     constexpr int VSTR = 512 + 8;
 
-    _Float16* Ks = smem;                          // [2 planes][4 chunks][512 keys][8 halves]
+    // K: [512 keys][8 chunks of 16 B: hi dims 0-7, 8-15, 16-23, 24-31, lo ...], chunk c of key k stored at position
+    // c ^ (k & 7): the staging writes (8 lanes = the 8 chunks of a key) and the fragment reads (lane = (key, chunk))
+    // are both free of bank conflicts for the lane groups the LDS serves together
+    _Float16* Ks = smem;
     _Float16* Vs = smem + 2 * 4 * 512 * 8;        // [2 planes][32 dims][VSTR]
     {
         const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
@@ -496,7 +499,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * 512;
                 const int key = idx >> 3, c = idx & 7;           // c = plane * 4 + chunk
-                *reinterpret_cast<f32x4*>(Ks + ((size_t)c * 512 + key) * 8) = x[u];
+                *reinterpret_cast<f32x4*>(Ks + ((size_t)key * 8 + (c ^ (key & 7))) * 8) = x[u];
             }
         }
         const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
@@ -529,15 +532,17 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             ql = *reinterpret_cast<const f16x8*>(p + 32);
         }
         // ---- S^T: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
+        const _Float16* kfrag_h = Ks + l15 * 64 + (g ^ (l15 & 7)) * 8;
+        const _Float16* kfrag_l = Ks + l15 * 64 + ((4 + g) ^ (l15 & 7)) * 8;
         f32x16 S[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int blk = 4 * c + j;
-                const _Float16* kp = Ks + ((size_t)g * 512 + blk * 16 + l15) * 8;     // A operand: key l15 of the block, dims 8 g ..
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(kp);
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kp + 4 * 512 * 8);
+                // A operand: key l15 of the block, dims 8 g ..; (key & 7) = (l15 & 7): the swizzle is a per-lane constant
+                const f16x8 kh = *reinterpret_cast<const f16x8*>(kfrag_h + blk * (16 * 64));
+                const f16x8 kl = *reinterpret_cast<const f16x8*>(kfrag_l + blk * (16 * 64));
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
                 acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
