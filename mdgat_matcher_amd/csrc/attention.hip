@@ -190,7 +190,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     float t = mu + zq * sd;
     for (int it = 0; it < 64; ++it) {
         if (!(t > lo && t < hv)) {
-            t = lo + (hv - lo) * (((float)(clo - k) + 0.5f) / (float)(clo - chi));
+            t = lo + (hv - lo) * (((float)(clo - k) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi)));   // (only steers the search)
             if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
         }
         const bool collapsed = !(t > lo && t < hv);   // no float strictly inside the bracket
@@ -209,7 +209,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
                 else {
                     const float z = (t - mu) * inv_sd;
                     const float dens = (float)nk * 0.3989422804f * inv_sd * __builtin_amdgcn_exp2f(-0.7213475204f * z * z);
-                    const float tn = t + (float)(c - k) / fmaxf(dens, 1e-3f * (float)nk * inv_sd);
+                    const float tn = t + (float)(c - k) * __builtin_amdgcn_rcpf(fmaxf(dens, 1e-3f * (float)nk * inv_sd));
                     t = ((it & 3) == 3) ? lo : tn;             // every 4th probe: interpolate inside the bracket
                 }
             }
