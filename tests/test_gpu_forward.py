@@ -258,6 +258,31 @@ def test_large_frames(n, m, L, S, k):
         assert (m0.cpu() != ref['matches0']).double().mean() < FLIP_FRAC
 
 
+@pytest.mark.parametrize('B,n,m,k', [(3, 37, 53, []), (2, 130, 75, []), (5, 20, 44, [8, None]), (1, 1, 9, [])])
+def test_ragged_shapes_vs_oracle(B, n, m, k):
+    """Keypoint counts that are not multiples of anything (tiles of 128 / waves of 16 keypoints straddle frames and
+    pairs, the last tile is partial, V^T goes through the element-wise store path): full-attention configurations
+    must match the fp64 oracle to 1e-4 on Z with identical matches, dynamic ones up to near-tie flips."""
+    L = 2
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=15)
+    sd = synth.make_state_dict(L=L, seed=3)
+    net = MDGAT(cfg)
+    net.load_state_dict(sd)
+    net = net.double().eval().to(DEV)
+    data = synth.make_batch(B, n, m, first_pair=2)
+    cap = {}
+    ref = O.mdgat_forward(sd, cfg, data, cap)
+    d = {kk: v.to(DEV) for kk, v in data.items()}
+    m0, m1, s0, s1, Z = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
+                                  d['scores0'], d['scores1'], return_scores=True)
+    err = (Z.cpu().double() - cap['Z']).abs()
+    if k == []:
+        assert err.max() < Z_TOL, err.max()
+        assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
+    else:
+        assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC
+
+
 def test_match_frames_raw_records():
     """Raw 37-float keypoint records (load_data.py:152-165) straight into the encoder kernel, FPFH normalisation
     (load_data.py:290-292) fused: same result as decoding with the oracle's restatement of the loader."""
