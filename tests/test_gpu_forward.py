@@ -283,6 +283,22 @@ def test_ragged_shapes_vs_oracle(B, n, m, k):
         assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC
 
 
+def test_repeatable_bitwise():
+    """Same inputs, same outputs, bit for bit: the cross-workgroup sums of the Sinkhorn kernel are taken in a fixed
+    order and nothing else in the path depends on scheduling."""
+    cfg = synth.default_config(L=3, k=[64, None, 32, None, None, None], sinkhorn_iterations=50)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=3, seed=5))
+    net = net.eval().to(DEV)
+    d = synth.make_batch(9, 512, 512, device=DEV, dtype=torch.float32)
+    args = (d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1'])
+    ref = [t.clone() for t in net.match(*args, return_scores=True)]
+    for _ in range(3):
+        out = net.match(*args, return_scores=True)
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b)
+
+
 def test_match_frames_raw_records():
     """Raw 37-float keypoint records (load_data.py:152-165) straight into the encoder kernel, FPFH normalisation
     (load_data.py:290-292) fused: same result as decoding with the oracle's restatement of the loader."""
