@@ -25,7 +25,7 @@
 // Weights: pre-split at load time into the LDS image itself ([row][hi plane | lo plane | 16 B pad], rows in
 // P/Q order, the pad makes the ds_read_b128 fragment reads conflict free), so a stage (one unit of K = 256 or two
 // units of K = 128, 33 KB) is a flat copy: global_load_lds_dwordx4 moves it L2 -> LDS without passing through
-// registers, issued during the stage that precedes its use, double buffered, one barrier per stage (18 stages).
+// registers, issued three stages ahead into a ring of five slots, one barrier per pair of stages (18 per tile).
 //
 // The epilogue of unit n (accumulator combine, bias, ReLU, f16 split, output staging and stores) is cut into
 // small steps that are issued between the matrix instructions of unit n + 1 (unit_mma16: six slots per k-step),
@@ -39,7 +39,7 @@
 #ifdef LAYER_TRACE
 __device__ long long g_dbg[8192];
 extern "C" int mdgat_debug_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), n * sizeof(long long)); }
-#define TRACE_OFF (4 * 17 * 1024 + (768 + 8 * 2112) * 4)
+#define TRACE_OFF (5 * 17 * 1024 + (768 + 8 * 2112) * 4)
 __device__ __forceinline__ void trace_point(int slot) {
     extern __shared__ __attribute__((aligned(16))) char tsm[];
     if ((threadIdx.x & 63) == 0) {
@@ -66,12 +66,13 @@ namespace {
 constexpr int ROWH256 = 528;                 // K = 256
 constexpr int ROWH128 = 272;                 // K = 128
 // A stage = 16 image rows of K = 256 (one row block, 16896 B) or 32 rows of K = 128 (one unit, 17408 B): 17 copies
-// of 1 KB.  Ring of NSLOT slots; the copy of stage h + LOOKAHEAD is issued during stage h (the stage copies take
+// of 1 KB.  Ring of NSLOT slots; stages are consumed in pairs (the two row blocks of a K = 256 unit, two K = 128 units)
+// with one barrier per pair; the copy of stage h + LOOKAHEAD is issued during stage h (the stage copies take
 // about three stage times to land: every CU asks L2 for the same lines at the same time).
 constexpr int SLOT_CHUNKS = 17;
 constexpr int SLOT_BYTES = SLOT_CHUNKS * 1024;
 constexpr int SLOT_HALVES = SLOT_BYTES / 2;
-constexpr int NSLOT = 4, LOOKAHEAD = 3;
+constexpr int NSLOT = 5, LOOKAHEAD = 3;
 constexpr int NWAVE = 8;                     // waves per workgroup (16 keypoints each): 128 keypoints, one workgroup per CU
 constexpr int WPTS = 16;                     // keypoints per wave
 constexpr int TROW = 132;                    // floats per row of a wave's activation tile (128 channels + 16 B pad)
@@ -140,6 +141,12 @@ __device__ __forceinline__ void end_of_stage(int h, int nstage) {
     else stage_wait<0>();
 }
 static_assert(LOOKAHEAD <= 3, "end_of_stage handles up to two copies in flight");
+// end of a PAIR of stages (last stage h1) that share one barrier: stages h1 + 1 and h1 + 2 must have landed, the copy of
+// stage h1 + 3 (issued during h1) may be in flight.  Needs NSLOT >= 5: stage h + 3 and h + 4 land in the slots of the pair before.
+__device__ __forceinline__ void end_of_pair(int h1, int nstage) {
+    if (h1 + 3 < nstage) stage_wait<DMA_SLICES>();
+    else stage_wait<0>();
+}
 
 // Accumulators of one 32-channel unit: row blocks P and Q, each m = hi.hi and x = hi.lo + lo.hi (to be scaled by
 // 1/2048 when combined).
@@ -446,7 +453,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         }
         for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[ks], al[ks]); });
         TR(1);
-        stage_wait<(LOOKAHEAD - 1) * DMA_SLICES>();
+        stage_wait<DMA_SLICES>();               // stages 0 and 1 have landed, stage 2 may be in flight
         TR(2);
 
         // ---- phase 1: 8 units of W1 -> hidden fragments (k-step rb of phase 2) ----
@@ -465,7 +472,6 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         };
         // K = 256 units have 48 slots: a step in every other one, the stage copies in slots 6 i + 1
         // end of stage h: the copies of stages h + 2 and h + 3 may still be in flight
-        auto end_stage = [&](int h) __attribute__((always_inline)) { end_of_stage(h, NSTAGE); };
         for_units<8>([&](int rb) __attribute__((always_inline)) {
             TR(10);
             // slots 0 .. 23: row block P, 24 .. 47: row block Q; the pending epilogue in every other slot
@@ -476,10 +482,9 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                 };
             };
             block_mma16<8, ROWH256>(bufp(2 * rb), l15, g, ah, al, acc[rb & 1].pm, acc[rb & 1].px, inter(2 * rb, 0));
-            end_stage(2 * rb);
             block_mma16<8, ROWH256>(bufp(2 * rb + 1), l15, g, ah, al, acc[rb & 1].qm, acc[rb & 1].qx, inter(2 * rb + 1, 24));
             TR(11);
-            end_stage(2 * rb + 1);
+            end_of_pair(2 * rb + 1, NSTAGE);
             TR(12);
         });
 
@@ -511,10 +516,9 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                 };
             };
             block_mma16<8, ROWH256>(bufp(H0 + 2 * ob), l15, g, hh, hl, acc[ob & 1].pm, acc[ob & 1].px, inter(H0 + 2 * ob, 0));
-            end_stage(H0 + 2 * ob);
             block_mma16<8, ROWH256>(bufp(H0 + 2 * ob + 1), l15, g, hh, hl, acc[ob & 1].qm, acc[ob & 1].qx, inter(H0 + 2 * ob + 1, 24));
             TR(21);
-            end_stage(H0 + 2 * ob + 1);
+            end_of_pair(H0 + 2 * ob + 1, NSTAGE);
             TR(22);
         });
         // the epilogue of the last unit (set 1) is not overlapped: phase 3 needs all of the new x
@@ -530,7 +534,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             rows_to_tile(tx);
         }
         for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, xnh[ks], xnl[ks]); });
-        stage_wait<(LOOKAHEAD - 1) * DMA_SLICES>();
+        stage_wait<DMA_SLICES>();
     }
 
     // ---- phase 3: q | k | v of the next layer (12 units) or the final projection (4), one unit per stage.
@@ -546,7 +550,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         if (MODE3 == 1 && q >= 8) unit_mma16<4, false, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         else unit_mma16<4, true, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         TR(32);
-        if (q + 1 < NB3) end_of_stage(H0 + q, NSTAGE);
+        if ((q & 1) && q + 1 < NB3) end_of_pair(H0 + q, NSTAGE);
         TR(33);
     });
     for_units<E_STEPS>([&](int u) __attribute__((always_inline)) { e3(NB3 - 1, acc[(NB3 - 1) & 1], u); });
