@@ -133,14 +133,6 @@ __device__ __forceinline__ void stage_wait() {
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
     __syncthreads();
 }
-// end of stage h of nstage: the copies of stages h + 2 .. h + LOOKAHEAD that exist may still be in flight
-__device__ __forceinline__ void end_of_stage(int h, int nstage) {
-    const int younger = min(LOOKAHEAD - 1, max(nstage - 2 - h, 0));
-    if (younger >= 2) stage_wait<2 * DMA_SLICES>();
-    else if (younger == 1) stage_wait<DMA_SLICES>();
-    else stage_wait<0>();
-}
-static_assert(LOOKAHEAD <= 3, "end_of_stage handles up to two copies in flight");
 // end of a PAIR of stages (last stage h1) that share one barrier: stages h1 + 1 and h1 + 2 must have landed, the copy of
 // stage h1 + 3 (issued during h1) may be in flight.  Needs NSLOT >= 5: stage h + 3 and h + 4 land in the slots of the pair before.
 __device__ __forceinline__ void end_of_pair(int h1, int nstage) {
