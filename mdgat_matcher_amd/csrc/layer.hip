@@ -57,7 +57,6 @@ __device__ __forceinline__ void trace_point(int slot) {
 #define TR(slot)
 #endif
 #include "mma_chain.hpp"
-#include "mma_chain.hpp"
 namespace {
 
 // LDS / image row pitch (halves): hi plane | lo plane | 32 B pad.  A ds_read_b128 is served in four groups of 16
