@@ -210,7 +210,9 @@ __device__ __forceinline__ void block_mma16(const _Float16* buf, int l15, int g,
 }
 
 // DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 units), 2: final projection (4).
-template <int DO_MLP, int MODE3>
+// VW 1 (MODE3 1, frames that are multiples of 128 keypoints): the V^T row pieces of the whole workgroup are gathered
+// in LDS, so that each (plane, dim) row goes out as 256 contiguous bytes instead of eight 32-byte pieces.
+template <int DO_MLP, int MODE3, int VW>
 __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 4 stage slots, 768 floats of biases, 8 tiles
     const int tid = threadIdx.x;
@@ -326,6 +328,26 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         }
     };
 
+    // VW: element (row, col) of gather buffer b, and the store of this wave's 8 rows (piece p: rows 4 p .. 4 p + 3,
+    // 16 lanes x 16 bytes per row) of unit qb
+    constexpr int VSH_OFF = 16 * QKROW, VSHROW = 136, VSH_BUF = 8 * VSHROW;
+    _Float16* tiles16 = reinterpret_cast<_Float16*>(bias3 + 384);
+    auto vsh = [&](int b, int row, int col) __attribute__((always_inline)) {
+        return tiles16 + (row >> 3) * (2 * TILE_FLOATS) + VSH_OFF + b * VSH_BUF + (row & 7) * VSHROW + col;
+    };
+    auto vstore = [&](int qb, int u) __attribute__((always_inline)) {
+        const int p = u >> 1, rl = 4 * p + g;
+        if ((u & 1) == 0) pback[p] = *reinterpret_cast<const f32x4_a*>(tile16 + VSH_OFF + (qb & 1) * VSH_BUF + rl * VSHROW + l15 * 8);
+        else {
+            const int P = a.N + a.M;
+            const int pt0 = blockIdx.x * (WPTS * NWAVE);
+            const int bb = pt0 / P, pp = pt0 - bb * P;
+            const int col0 = pp < a.N ? pp : a.Npad + pp - a.N;
+            _Float16* base = a.vt16 + (((size_t)bb * 4 + (qb & 3)) * 64 + 8 * wave + rl) * a.PP + col0;
+            *reinterpret_cast<f32x4*>(base + l15 * 8) = pback[p];
+        }
+    };
+
     // phase 3, unit qb.  Steps: 0 bias read | 1, 2 combine | 3 + bias | 4 scale | 5-9 split | 10 tile write |
     //                           11 tile read | 12, 13 stores
     auto e3 = [&](int qb, const UnitAcc& c, int u) __attribute__((always_inline)) {
@@ -362,7 +384,22 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             // 4 g .. 4 g + 3 of this wave: o[0..3] / o[4..7]
             const int head = qb & 3;
             const int P = a.N + a.M;
-            if (((a.N | a.M) & 15) == 0) {
+            if (VW) {
+                // shared gather: row 32 plane + dim of the workgroup lives in the tile of wave row >> 3, above the
+                // q/k staging rows; two buffers (qb & 1).  This wave fills columns 16 wave + 4 g .. + 3 of all 64 rows.
+                if (u == 0) { pbias_v[0] = bias3[qb * 32 + l15]; pbias_v[1] = bias3[qb * 32 + 16 + l15]; }
+                else if (u == 3) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias_v[j >> 2];
+                } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl);
+                else if (u == 10) {
+                    _Float16* c0 = vsh(qb & 1, l15, 16 * wave + 4 * g);
+                    *reinterpret_cast<f16x4_a*>(c0) = f16x4{sth[0], sth[1], sth[2], sth[3]};
+                    *reinterpret_cast<f16x4_a*>(c0 + 2 * 2 * TILE_FLOATS) = f16x4{sth[4], sth[5], sth[6], sth[7]};
+                    *reinterpret_cast<f16x4_a*>(c0 + 4 * 2 * TILE_FLOATS) = f16x4{stl[0], stl[1], stl[2], stl[3]};
+                    *reinterpret_cast<f16x4_a*>(c0 + 6 * 2 * TILE_FLOATS) = f16x4{stl[4], stl[5], stl[6], stl[7]};
+                }
+            } else if (((a.N | a.M) & 15) == 0) {
                 // the 16 keypoints of the wave share frame and pair: 32 contiguous bytes per (plane, dim) row,
                 // gathered through the tile so that a lane writes one whole row
                 if (wave_pt0 < a.R) {
@@ -537,14 +574,21 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         auto inter = [&](int slot) __attribute__((always_inline)) {
             if (slot % 4 == 1 && slot / 4 < DMA_SLICES) copy_ahead(H0 + q, slot / 4);
             if (q > 0) e3(q - 1, acc[(q - 1) & 1], slot);
+            if (VW && q >= 10 && slot >= 18 && slot < 22) vstore(q - 2, slot - 18);
         };
         if (MODE3 == 1 && q >= 8) unit_mma16<4, false, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         else unit_mma16<4, true, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         TR(32);
         if ((q & 1) && q + 1 < NB3) end_of_pair(H0 + q, NSTAGE);
+        else if (VW && q >= 10) __syncthreads();       // the gather buffers change hands every unit from here on
         TR(33);
     });
+    if (VW) for_units<4>([&](int u) __attribute__((always_inline)) { vstore(NB3 - 2, u); });
     for_units<E_STEPS>([&](int u) __attribute__((always_inline)) { e3(NB3 - 1, acc[(NB3 - 1) & 1], u); });
+    if (VW) {
+        __syncthreads();
+        for_units<4>([&](int u) __attribute__((always_inline)) { vstore(NB3 - 1, u); });
+    }
     if (MODE3 != 1) tile_to_rows(a.mdesc);
     TR(40);
 #ifdef LAYER_TRACE
@@ -571,7 +615,7 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float1
     }
 }
 
-template <int DO_MLP, int MODE3>
+template <int DO_MLP, int MODE3, int VW>
 int launch_layer_t(const LayerArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + NWAVE * TILE_FLOATS) * sizeof(float)
 #ifdef LAYER_TRACE
@@ -580,13 +624,13 @@ int launch_layer_t(const LayerArgs& a, hipStream_t s) {
         ;
     static bool attr = false;
     if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3>),
+        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3, VW>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer LDS attribute"))
             return rc;
         attr = true;
     }
     constexpr int TILE_PTS = WPTS * NWAVE;
-    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
+    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3, VW>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "layer launch");
 }
 
@@ -606,6 +650,7 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     a.w1s = p.w1s; a.b1 = p.b1; a.w2s = p.w2s; a.b2 = p.b2; a.w3s = p.w3s; a.b3 = p.b3;
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
     a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP;
-    if (p.do_mlp) return p.mode3 == 1 ? launch_layer_t<1, 1>(a, s) : launch_layer_t<1, 2>(a, s);
-    return p.mode3 == 1 ? launch_layer_t<0, 1>(a, s) : launch_layer_t<0, 2>(a, s);
+    const bool vw = p.mode3 == 1 && ((p.N | p.M) & 127) == 0;
+    if (p.do_mlp) return p.mode3 != 1 ? launch_layer_t<1, 2, 0>(a, s) : vw ? launch_layer_t<1, 1, 1>(a, s) : launch_layer_t<1, 1, 0>(a, s);
+    return p.mode3 != 1 ? launch_layer_t<0, 2, 0>(a, s) : vw ? launch_layer_t<0, 1, 1>(a, s) : launch_layer_t<0, 1, 0>(a, s);
 }

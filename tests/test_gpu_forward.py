@@ -258,7 +258,7 @@ def test_large_frames(n, m, L, S, k):
         assert (m0.cpu() != ref['matches0']).double().mean() < FLIP_FRAC
 
 
-@pytest.mark.parametrize('B,n,m,k', [(3, 37, 53, []), (2, 130, 75, []), (5, 20, 44, [8, None]), (1, 1, 9, [])])
+@pytest.mark.parametrize('B,n,m,k', [(3, 37, 53, []), (2, 130, 75, []), (5, 20, 44, [8, None]), (1, 1, 9, []), (2, 128, 256, [])])
 def test_ragged_shapes_vs_oracle(B, n, m, k):
     """Keypoint counts that are not multiples of anything (tiles of 128 / waves of 16 keypoints straddle frames and
     pairs, the last tile is partial, V^T goes through the element-wise store path): full-attention configurations
