@@ -25,6 +25,7 @@
 // equals softmax over the gathered top-k; exact ties at the k-th value are all kept (torch.topk would
 // keep an arbitrary subset of them).
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -896,6 +897,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     const int nblk = nkp / 32;
+    if (!dyn && attention_stream_supported(N, M) && !getenv("MDGAT_ATTN_NOSTREAM")) return launch_attention_stream(B, N, M, cross, qkv, msg, s);
     // one workgroup per (pair, frame, head) loops over its query tiles; split the tiles over more
     // workgroups only when there are too few (pair, frame, head) units to fill the chip twice
     auto go = [&](auto kern, int threads) {
