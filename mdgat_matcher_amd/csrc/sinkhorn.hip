@@ -194,8 +194,10 @@ __device__ __forceinline__ float wave_sum_dpp(float v) {
 // (v_permlane32_swap), 16-lane-row swap (v_permlane16_swap), row rotation by 8, bank shifts by 4, two quad steps -
 // about 40 instructions and short dependency chains instead of sixteen 7-deep DPP chains.  (The permlane swaps go
 // through inline asm: the clang builtins of this ROCm return the first result twice.)
-__device__ __forceinline__ void swap_halves32(float& a, float& b) { asm("v_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
-__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm("v_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+// The compiler does not see through an asm, so it inserts none of the wait states these instructions need after a
+// vector write of their operands / before a vector read of their results (observed: wrong values without them).
+__device__ __forceinline__ void swap_halves32(float& a, float& b) { asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void swap_rows16(float& a, float& b) { asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b)); }
 template <int CTRL, int BANK>
 __device__ __forceinline__ float dpp_bank_move(float old, float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));

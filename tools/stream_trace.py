@@ -17,4 +17,4 @@ for sel in range(4):
     prev = t0; line = []
     for slot, t in ev:
         line.append('%d:%d' % (slot, t - prev)); prev = t
-        if slot in (3, 16, 21): print('  ', ' '.join(line)); line = []
+        if slot in (3, 16, 21) or (slot == 15 and False): print('  ', ' '.join(line)); line = []
