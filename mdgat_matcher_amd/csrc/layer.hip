@@ -308,21 +308,24 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             o[4 * half + r] = half == 0 ? fmaf(c.px[r], MDGAT_SPLIT_INV, c.pm[r]) : fmaf(c.qx[r], MDGAT_SPLIT_INV, c.qm[r]);
     };
     auto load_bias8 = [&](const float* b) __attribute__((always_inline)) { load8(b + 8 * g, pbias); };
-    // the split pv -> (h, l) in five steps
+    // the split pv -> (h, l) in four steps (a fifth slot stays empty)
     auto split_step = [&](int s_, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         if (s_ == 0) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) h[j] = (_Float16)pv[j];
         } else if (s_ == 1) {
+            // residual pv - (float)h straight from the packed halves (one v_fma_mix_f32 per value)
+            const u32x4 hp = __builtin_bit_cast(u32x4, h);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) phf[j] = (float)h[j];
+            for (int j = 0; j < 4; ++j) {
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(pv[2 * j]) : "v"(pv[2 * j]), "v"(hp[j]));
+                asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(pv[2 * j + 1]) : "v"(pv[2 * j + 1]), "v"(hp[j]));
+            }
         } else if (s_ == 2) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] -= phf[j];
-        } else if (s_ == 3) {
-#pragma unroll
             for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_SPLIT_SCALE;
-        } else if (s_ == 4) {
+        } else if (s_ == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) l[j] = (_Float16)pv[j];
         }
