@@ -60,7 +60,7 @@ def _ref_msg_to_lib(msg):
 
 
 @pytest.mark.parametrize('N,M', [(64, 64), (40, 56), (128, 96), (512, 512), (257, 130), (33, 31), (600, 700), (1024, 1024),
-                                 (2048, 1300)])
+                                 (2048, 1300), (128, 320), (192, 64), (2048, 1344)])   # multiples of 64: the streamed kernel
 @pytest.mark.parametrize('cross', [False, True])
 def test_attention_full(N, M, cross):
     rs = np.random.RandomState(N * 7 + M)
