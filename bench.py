@@ -106,6 +106,8 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--batch', type=int, default=BATCH, help='pairs per GPU per step (BASELINE config: 64)')
+    ap.add_argument('--attention-dtype', default='fp32', choices=['fp32', 'f16'],
+                    help="'f16': single-f16 attention products (BASELINE configs[2]; outside the parity bar, not the headline)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     args = ap.parse_args()
@@ -115,6 +117,7 @@ def main():
     torch.cuda.set_device(dev)
 
     cfg = synth.default_config(L=L_LAYERS, sinkhorn_iterations=S_ITERS)
+    cfg['attention_dtype'] = args.attention_dtype
     net = MDGAT(cfg).eval()
     if rank == 0:
         net.load_state_dict(synth.make_state_dict(L=L_LAYERS, seed=0, dtype=torch.float32))
@@ -155,10 +158,11 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (products as 3 split-f16 MFMAs, fp32 accumulate)',
+            'dtype': 'f32 (products as 3 split-f16 MFMAs, fp32 accumulate)' if args.attention_dtype == 'fp32' else
+                     'f16 attention products (single f16 operands, fp32 accumulate), f32 elsewhere: NOT the parity path',
             'data': 'synthetic',
             'config': {'workload': f'batch={B} synthetic pairs per GPU, N=M={N_KPTS} keypoints, 33-D FPFH, L={L_LAYERS}, '
-                                   f'{S_ITERS} Sinkhorn iterations, fp32 (BASELINE.json configs[1])',
+                                   f'{S_ITERS} Sinkhorn iterations, ' + ('fp32 (BASELINE.json configs[1])' if args.attention_dtype == 'fp32' else 'f16 attention / fp32 Sinkhorn (BASELINE.json configs[2] at this batch)'),
                        'pairs_per_gpu': B, 'keypoints': N_KPTS, 'L': L_LAYERS, 'sinkhorn_iterations': S_ITERS,
                        'parallelism': f'pairs sharded {world}-way, no data-path collective'},
         }

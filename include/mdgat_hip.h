@@ -54,6 +54,13 @@ typedef enum {
     MDGAT_EXTRACT_THRESHOLD_MUTUAL = 3 /* loss_method == 'superglue', mutual_check True (447-453) */
 } mdgat_extract_mode;
 
+/* Arithmetic of the attention products (q.k and p.v).  The default carries every operand as two f16 halves and is
+ * fp32-faithful (the parity bar); MDGAT_ATTENTION_F16 rounds q, k, v and the probabilities to ONE f16 each (fp32
+ * accumulation, fp32 softmax statistics): a throughput mode outside the parity bar (max|dZ| ~ 2e-3), applied where a
+ * kernel implements it (full attention with key counts that are multiples of 64, dynamic attention at 512 keys)
+ * and ignored elsewhere. */
+typedef enum { MDGAT_ATTENTION_FP32 = 0, MDGAT_ATTENTION_F16 = 1 } mdgat_attention_mode;
+
 /* Replaces the config dict of MDGAT.__init__ (mdgat.py:325-367) for descriptor == 'FPFH'. */
 typedef struct {
     int32_t L;                         /* config['L']: 2L alternating self/cross layers (352-353) */
@@ -63,6 +70,7 @@ typedef struct {
                                           resolved by the host */
     int32_t extract_mode;              /* mdgat_extract_mode */
     float match_threshold;             /* config['match_threshold'] (322) */
+    int32_t attention_mode;            /* mdgat_attention_mode; not a reference key (BASELINE configs[2]) */
 } mdgat_config;
 
 typedef struct mdgat_handle mdgat_handle;

@@ -33,6 +33,7 @@ class MdgatConfig(C.Structure):
         ('topk', C.c_int32 * MAX_LAYERS),
         ('extract_mode', C.c_int32),
         ('match_threshold', C.c_float),
+        ('attention_mode', C.c_int32),
     ]
 
 

@@ -78,6 +78,7 @@ static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + WS_FINA
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
     if (cfg->L < 0 || 2 * cfg->L > MDGAT_MAX_LAYERS) { mdgat_set_error("mdgat_create: L=%d out of range", cfg->L); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->attention_mode != MDGAT_ATTENTION_FP32 && cfg->attention_mode != MDGAT_ATTENTION_F16) { mdgat_set_error("mdgat_create: bad attention_mode %d", cfg->attention_mode); return MDGAT_ERR_BAD_ARG; }
     if (cfg->extract_mode < 0 || cfg->extract_mode > 3) { mdgat_set_error("mdgat_create: bad extract_mode %d", cfg->extract_mode); return MDGAT_ERR_BAD_ARG; }
     for (int i = 0; i < 2 * cfg->L; ++i)
         if (cfg->topk[i] < 0) { mdgat_set_error("mdgat_create: topk[%d] < 0", i); return MDGAT_ERR_BAD_ARG; }
@@ -282,7 +283,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
         const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
-        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s))) return rc;
+        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s, h->cfg.attention_mode))) return rc;
         mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1;

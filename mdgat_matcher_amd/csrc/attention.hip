@@ -466,6 +466,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 // for 512 keys, two waves per SIMD.  Row statistics and top-k counts are two lane shuffles (QuadComm), so the 8 waves
 // of the workgroup search independently.  K sits in LDS as [plane][dim chunk g][key] 16-byte units (conflict free for
 // this fragment shape), V^T as in the other kernels; P.V pairs two key blocks per k-step.
+// FAST (mdgat_attention_mode F16): hi planes only, one MFMA per product.
+template <bool FAST>
 __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
@@ -546,10 +548,12 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 const f16x8 kl = *reinterpret_cast<const f16x8*>(kfrag_l + blk * (16 * 64));
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
                 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
+                if (!FAST) {
+                    acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
+                    acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
+                }
 #pragma unroll
-                for (int r = 0; r < 4; ++r) S[c][4 * j + r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+                for (int r = 0; r < 4; ++r) S[c][4 * j + r] = FAST ? acc[r] : fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
             }
         }
         float m = -__builtin_inff();
@@ -575,7 +579,11 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 for (int i = 0; i < 8; ++i) s8[i] = S[c][8 * jj + i];
                 softmax8<true>(s8, m11, thr, p, l2);
                 f16x8 ph, pl;
-                split8(p, ph, pl);
+                if (FAST) {
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) ph[i] = (_Float16)p[i];
+                    pl = ph;
+                } else split8(p, ph, pl);
                 const int key0 = (4 * c + 2 * jj) * 16 + 4 * g;  // this lane's keys: key0 .. key0 + 3 and key0 + 16 .. key0 + 19
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {                   // dims 16 t + l15
@@ -586,8 +594,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 #pragma unroll
                     for (int i = 0; i < 4; ++i) { vh[i] = vh0[i]; vh[4 + i] = vh1[i]; vl[i] = vl0[i]; vl[4 + i] = vl1[i]; }
                     Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, Om[t], 0, 0, 0);
-                    Ox[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, Ox[t], 0, 0, 0);
-                    Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, Om[t], 0, 0, 0);
+                    if (!FAST) {
+                        Ox[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, Ox[t], 0, 0, 0);
+                        Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, Om[t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -878,7 +888,7 @@ static float normal_quantile_upper(double p) {
     return (float)x;
 }
 
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s) {
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
     if (topk > 0) {
@@ -897,7 +907,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     const int nblk = nkp / 32;
-    if (!dyn && attention_stream_supported(N, M) && !getenv("MDGAT_ATTN_NOSTREAM")) return launch_attention_stream(B, N, M, cross, qkv, msg, s);
+    if (!dyn && attention_stream_supported(N, M) && !getenv("MDGAT_ATTN_NOSTREAM")) return launch_attention_stream(B, N, M, cross, qkv, msg, s, mode);
     // one workgroup per (pair, frame, head) loops over its query tiles; split the tiles over more
     // workgroups only when there are too few (pair, frame, head) units to fill the chip twice
     auto go = [&](auto kern, int threads) {
@@ -920,9 +930,12 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
             if (qsplit > 4) qsplit = 4;
             const size_t lds3 = ((size_t)2 * 4 * 512 * 8 + (size_t)64 * 520) * sizeof(_Float16);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel),
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            hipLaunchKernelGGL(attention_topk16_kernel, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            if (mode == 1) hipLaunchKernelGGL(attention_topk16_kernel<true>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+            else hipLaunchKernelGGL(attention_topk16_kernel<false>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
         } else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
         else return launch_attention_topk_wide(a, B, nk_max, s);
     } else {

@@ -48,6 +48,8 @@ __device__ __forceinline__ void for_units(F&& f) { for_each_unit(f, std::make_in
 
 #define SLOT_END() __builtin_amdgcn_sched_barrier(0)
 
+// FAST (mdgat_attention_mode F16): only the hi planes take part - one MFMA per product, no residual planes.
+template <bool FAST>
 __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,6 +80,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         voff = rl8 * a.PP * 2 + swz * 16; pstride = 8 * a.PP * 2; cstride = 128;
     }
     auto dma_chunk = [&](int ch) __attribute__((always_inline)) {
+        if (FAST && wave == 3) return;        // the lo plane of V^T is not read (the vmcnt waits only get stricter)
         const char* s0 = dbase + (size_t)ch * cstride;
         const unsigned d0 = lds0 + (unsigned)(ch & (NSLOT - 1)) * CHUNK_BYTES + (unsigned)wave * BLK_BYTES;
 #pragma unroll
@@ -100,12 +103,12 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     auto kread = [&](int ch, int jb) __attribute__((always_inline)) {
         const char* base = smem + (ch & (NSLOT - 1)) * CHUNK_BYTES + jb * BLK_BYTES;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) kf[i] = *reinterpret_cast<const f16x8_a*>(base + kofs[i]);
+        for (int i = 0; i < (FAST ? 2 : 4); ++i) kf[i] = *reinterpret_cast<const f16x8_a*>(base + kofs[i]);
     };
     auto vread = [&](int ch, int i) __attribute__((always_inline)) {
         const char* base = smem + (ch & (NSLOT - 1)) * CHUNK_BYTES + 2 * BLK_BYTES;
         vh[i & 1] = *reinterpret_cast<const f16x8_a*>(base + vofs[i]);
-        vl[i & 1] = *reinterpret_cast<const f16x8_a*>(base + BLK_BYTES + vofs[i]);
+        if (!FAST) vl[i & 1] = *reinterpret_cast<const f16x8_a*>(base + BLK_BYTES + vofs[i]);
     };
 
     // ---- this lane's query fragments: dims 16 t + 8 hi + j of query l31, planes hi / lo ----
@@ -139,6 +142,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     // QK^T product k of the block whose K fragments are in kf
     auto qk = [&](int k) __attribute__((always_inline)) {
         if (k == 0) A = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qh[0], zero16, 0, 0, 0);
+        else if (FAST) { if (k == 2) A = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qh[1], A, 0, 0, 0); }
         else if (k == 1) X = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], ql[0], zero16, 0, 0, 0);
         else if (k == 2) A = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qh[1], A, 0, 0, 0);
         else if (k == 3) X = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], ql[1], X, 0, 0, 0);
@@ -150,6 +154,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         if (u < 2) {
 #pragma unroll
             for (int r = 8 * u; r < 8 * u + 8; r += 2) {
+                if (FAST) { Sc[jb][r] = A[r]; Sc[jb][r + 1] = A[r + 1]; continue; }
                 const f32x2 v = f32x2{X[r], X[r + 1]} * f32x2{MDGAT_SPLIT_INV, MDGAT_SPLIT_INV} + f32x2{A[r], A[r + 1]};
                 Sc[jb][r] = v[0]; Sc[jb][r + 1] = v[1];
             }
@@ -198,6 +203,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         } else if (u == 4) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) php[pb][j] = (_Float16)pv[j];
+        } else if (FAST) {
         } else if (u == 5 || u == 6) {
             const u32x4 hp = __builtin_bit_cast(u32x4, php[pb]);
 #pragma unroll
@@ -214,6 +220,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     auto pvm = [&](int i, int k) __attribute__((always_inline)) {
         const int pb = i & 1;
         if (k == 0) Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[pb], php[pb], Om, 0, 0, 0);
+        else if (FAST) {}
         else if (k == 1) Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[pb], php[pb], Ox, 0, 0, 0);
         else Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[pb], plp[pb], Om, 0, 0, 0);
     };
@@ -252,7 +259,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         });
         if (!__all(sc == 1.0f)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { Om[r] *= sc; Ox[r] *= sc; }
+            for (int r = 0; r < 16; ++r) { Om[r] *= sc; if (!FAST) Ox[r] *= sc; }
         }
         SLOT_END();
         // step 1 beside P.V of step 0, then the logits of block 0 combined (Sc[0] is free after vs(1, 0))
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = fmaf(Ox[4 * g4 + j], MDGAT_SPLIT_INV, Om[4 * g4 + j]) * inv_l;
+        for (int j = 0; j < 4; ++j) o[j] = (FAST ? Om[4 * g4 + j] : fmaf(Ox[4 * g4 + j], MDGAT_SPLIT_INV, Om[4 * g4 + j])) * inv_l;
         *reinterpret_cast<f32x4_a*>(T + l31 * OROW + 8 * g4 + 4 * hi) = o;
     }
     float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32;
@@ -319,17 +326,18 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
 
 bool attention_stream_supported(int N, int M) { return N % 64 == 0 && M % 64 == 0; }
 
-int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s) {
+int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s, int mode) {
     const int nq_max = N > M ? N : M;
     StreamArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, (nq_max + 127) / 128};
     const size_t lds = (size_t)NSLOT * CHUNK_BYTES;
     static bool attr = false;
     if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_stream_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention LDS attribute"))
-            return rc;
+        for (const void* kern : {reinterpret_cast<const void*>(attention_stream_kernel<false>), reinterpret_cast<const void*>(attention_stream_kernel<true>)})
+            if (int rc = mdgat_check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention LDS attribute"))
+                return rc;
         attr = true;
     }
-    hipLaunchKernelGGL(attention_stream_kernel, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
+    if (mode == 1) hipLaunchKernelGGL(attention_stream_kernel<true>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(attention_stream_kernel<false>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "attention launch");
 }

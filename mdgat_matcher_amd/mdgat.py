@@ -114,6 +114,12 @@ class MDGAT(nn.Module):
         self.triplet_loss_gamma = config['triplet_loss_gamma']
         self.train_step = config['train_step']
         L = self.config['L']
+        # not a reference key: 'fp32' (default, the parity path) or 'f16' (single-f16 attention products, a throughput
+        # mode outside the parity bar - BASELINE.json configs[2]; 'bf16' is accepted as an alias: the operands are f16,
+        # same matrix-core rate, three more mantissa bits)
+        self.attention_dtype = str(self.config.get('attention_dtype', 'fp32'))
+        if self.attention_dtype not in ('fp32', 'f16', 'bf16'):
+            raise ValueError(f"attention_dtype={self.attention_dtype!r}: expected 'fp32' or 'f16'")
         if self.descriptor != 'FPFH':
             raise NotImplementedError(
                 f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
@@ -198,6 +204,7 @@ class MDGAT(nn.Module):
                 cfg.topk[i] = kk
             cfg.extract_mode = self._extract_mode()
             cfg.match_threshold = float(self.config['match_threshold'])
+            cfg.attention_mode = 0 if self.attention_dtype == 'fp32' else 1
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx)
