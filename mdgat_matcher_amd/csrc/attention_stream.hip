@@ -330,13 +330,9 @@ int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, fl
     const int nq_max = N > M ? N : M;
     StreamArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, (nq_max + 127) / 128};
     const size_t lds = (size_t)NSLOT * CHUNK_BYTES;
-    static bool attr = false;
-    if (!attr) {
-        for (const void* kern : {reinterpret_cast<const void*>(attention_stream_kernel<false>), reinterpret_cast<const void*>(attention_stream_kernel<true>)})
-            if (int rc = mdgat_check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention LDS attribute"))
-                return rc;
-        attr = true;
-    }
+    static std::atomic<unsigned long long> optin[2];
+    const void* kern = mode == 1 ? reinterpret_cast<const void*>(attention_stream_kernel<true>) : reinterpret_cast<const void*>(attention_stream_kernel<false>);
+    if (int rc = mdgat_lds_optin(kern, lds, optin[mode == 1], "attention LDS attribute")) return rc;
     if (mode == 1) hipLaunchKernelGGL(attention_stream_kernel<true>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(attention_stream_kernel<false>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "attention launch");

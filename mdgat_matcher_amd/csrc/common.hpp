@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <atomic>
 #include "../../include/mdgat_hip.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -30,6 +31,16 @@ __device__ __forceinline__ constexpr int mfma32_row(int r, int hi) { return (r &
 
 void mdgat_set_error(const char* fmt, ...);
 int mdgat_check_hip(hipError_t e, const char* what);
+// Opt a kernel in to `lds` bytes of dynamic LDS, once per device (`done` = the caller's static bitmap of devices;
+// one process may drive several GPUs from several threads: torch.nn.DataParallel).
+inline int mdgat_lds_optin(const void* kern, size_t lds, std::atomic<unsigned long long>& done, const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 63;       // (bit 63: never cached)
+    if (dev < 63 && ((done.load(std::memory_order_acquire) >> dev) & 1ull)) return MDGAT_OK;
+    if (int rc = mdgat_check_hip(hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), what)) return rc;
+    if (dev < 63) done.fetch_or(1ull << dev, std::memory_order_release);
+    return MDGAT_OK;
+}
 
 // ---- packed-weight blob layout (must match mdgat_matcher_amd/pack.py) --------------------------
 struct BlobLayout {

@@ -237,13 +237,8 @@ int launch_encoder(const EncoderLaunch& p, hipStream_t s) {
     a.k1s = p.es; a.k2s = a.k1s + 64 * 64; a.d0s = a.k2s + 128 * 128; a.d1s = a.d0s + 64 * 96; a.els = a.d1s + 128 * 128;
     a.x = p.x; a.B = p.B; a.N = p.N; a.M = p.M; a.R = p.B * (p.N + p.M);
     const size_t lds = (size_t)OFF_END * sizeof(_Float16) + 672 * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(encoder_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "encoder LDS attribute"))
-            return rc;
-        attr = true;
-    }
+    static std::atomic<unsigned long long> optin;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(encoder_kernel), lds, optin, "encoder LDS attribute")) return rc;
     hipLaunchKernelGGL(encoder_kernel, dim3((a.R + 127) / 128), dim3(256), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "encoder launch");
 }

@@ -625,13 +625,8 @@ int launch_layer_t(const LayerArgs& a, hipStream_t s) {
         + 8 * 256 * 8
 #endif
         ;
-    static bool attr = false;
-    if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3, VW>),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "layer LDS attribute"))
-            return rc;
-        attr = true;
-    }
+    static std::atomic<unsigned long long> optin;        // (one per template instance)
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3, VW>), lds, optin, "layer LDS attribute")) return rc;
     constexpr int TILE_PTS = WPTS * NWAVE;
     hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3, VW>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "layer launch");

@@ -94,13 +94,8 @@ int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float 
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     ScoreArgs a{mdesc, scores, N, M, scale};
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
-    static bool attr = false;
-    if (!attr) {
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(scores_kernel),
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "scores LDS attribute"))
-            return rc;
-        attr = true;
-    }
+    static std::atomic<unsigned long long> optin;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(scores_kernel), lds, optin, "scores LDS attribute")) return rc;
     hipLaunchKernelGGL(scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "scores launch");
 }
