@@ -132,6 +132,11 @@ def main():
         return net._run(*inputs)
 
     with torch.no_grad():
+        # initialisation, not warm-up: the first forwards of a process load the code objects, size the workspace and
+        # meet a one-off runtime stall (one early step of 25-80 ms, usually the 3rd or 4th: tools/step_times.py)
+        for _ in range(8):
+            step()
+        torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
         shard.barrier(world)
