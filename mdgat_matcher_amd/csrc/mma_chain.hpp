@@ -65,51 +65,4 @@ __device__ __forceinline__ void block_mma(const _Float16* buf, int wrow, int hi,
     for (int r = 0; r < 16; ++r) out[r] = fmaf(aca[r] + acb[r], MDGAT_SPLIT_INV, acc[r]);
 }
 
-// Two accumulators per block: m = hi.hi, x = hi.lo + lo.hi (to be scaled by 1/2048 when combined).
-struct SplitAcc { f32x16 m, x; };
-
-// Same product as block_mma, with (a) the W fragments read three k-steps ahead, (b) the two cross products
-// sharing one accumulator, (c) a caller-supplied piece of independent work `inter(slot)` issued behind EACH matrix
-// instruction (slots 3 ks, 3 ks + 1, 3 ks + 2) - units of the PREVIOUS block's epilogue and the copies of the next
-// stage, so that their VALU / LDS / memory instructions run in the shadow of this block's matrix instructions (a
-// 32x32x16 instruction occupies the matrix pipe for 32 cycles = 8 VALU issues of the same wave).
-// ROWH = LDS row pitch in halves.
-template <int NK, bool SWAP, int ROWH, typename Inter>
-__device__ __forceinline__ void block_mma_il(const _Float16* buf, int wrow, int hi, const f16x8* xh, const f16x8* xl,
-                                             SplitAcc& acc, Inter&& inter) {
-    constexpr int K = NK * 16, AHEAD = 3;
-    const _Float16* wp = buf + wrow * ROWH + 8 * hi;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { acc.m[r] = 0.f; acc.x[r] = 0.f; }
-    f16x8 wh[NK], wl[NK];
-#pragma unroll
-    for (int ks = 0; ks < AHEAD; ++ks) {
-        wh[ks] = *reinterpret_cast<const f16x8*>(wp + 16 * ks);
-        wl[ks] = *reinterpret_cast<const f16x8*>(wp + K + 16 * ks);
-    }
-#pragma unroll
-    for (int ks = 0; ks < NK; ++ks) {
-        if (ks + AHEAD < NK) {
-            wh[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + 16 * (ks + AHEAD));
-            wl[ks + AHEAD] = *reinterpret_cast<const f16x8*>(wp + K + 16 * (ks + AHEAD));
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep the reads of k-step ks + AHEAD ahead of the MFMAs of k-step ks
-        acc.x = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xl[ks], acc.x, 0, 0, 0)
-                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(xl[ks], wh[ks], acc.x, 0, 0, 0);
-        inter(3 * ks);
-        __builtin_amdgcn_sched_barrier(0);
-        acc.m = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[ks], xh[ks], acc.m, 0, 0, 0)
-                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wh[ks], acc.m, 0, 0, 0);
-        inter(3 * ks + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        acc.x = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[ks], xh[ks], acc.x, 0, 0, 0)
-                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(xh[ks], wl[ks], acc.x, 0, 0, 0);
-        inter(3 * ks + 2);
-        __builtin_amdgcn_sched_barrier(0);
-#ifdef MMA_TR
-        MMA_TR(ks);
-#endif
-    }
-}
-
 }  // namespace
