@@ -186,6 +186,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     // with whole blocks two more probes are cheaper than the three passes of that finish)
     int state = 0;
     bool hv_est = EXACT && k > 4;                    // chi is still the assumption, not a measured count
+    bool lo_meas = false;                            // lo is a probe (not the row minimum)
     if (chi >= k) { thr = m; state = 1; }            // ties at the maximum (or k == 1)
     if (nk <= k) { thr = -INF; state = 1; }          // this frame has exactly k keys: keep all
     if (state == 0 && k - chi == 1) state = 2;
@@ -209,14 +210,18 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
             if (collapsed) { thr = (EXACT && hv_est && c >= k) ? hv : lo; state = 1; }
             else if (c == k) { thr = t; state = 1; }
             else {
-                if (c > k) { lo = t; clo = c; } else { hv = t; chi = c; hv_est = false; }
+                if (c > k) { lo = t; clo = c; lo_meas = true; } else { hv = t; chi = c; hv_est = false; }
                 if (k - chi == 1) state = 2;
                 else if (!EXACT && clo - k == 1) state = 3;
                 else {
                     const float z = (t - mu) * inv_sd;
                     const float dens = (float)nk * 0.3989422804f * inv_sd * __builtin_amdgcn_exp2f(-0.7213475204f * z * z);
                     const float tn = t + (float)(c - k) * __builtin_amdgcn_rcpf(fmaxf(dens, 1e-3f * (float)nk * inv_sd));
-                    t = ((it & 3) == 3) ? lo : tn;             // every 4th probe: interpolate inside the bracket
+                    // every 4th probe, and whenever both ends of the bracket are probes with few logits between them
+                    // (the normal density says little about 48 logits): interpolate inside the bracket (t = lo does that
+                    // at the top of the loop).  CPU simulation of this search, 16 rows in lockstep: 6.6 -> 5.9 probes
+                    const bool narrow = lo_meas && !hv_est && clo - chi <= 48;
+                    t = (((it & 3) == 3) || narrow) ? lo : tn;
                 }
             }
         }
