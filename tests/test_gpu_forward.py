@@ -258,6 +258,17 @@ def test_f16_attention_mode_configs2():
     assert e16 < 2e-2 and agree >= 0.97
     with pytest.raises(ValueError):
         MDGAT(dict(cfg, attention_dtype='int8'))
+    # shapes no f16 kernel covers ignore the flag: bit-identical to the default path
+    small = synth.make_batch(2, 100, 75, first_pair=9)
+    ds = {k: v.to(DEV) for k, v in small.items()}
+    zs = []
+    for dt in ('fp32', 'f16'):
+        net = MDGAT(dict(synth.default_config(L=2, k=[16, None], sinkhorn_iterations=10), attention_dtype=dt))
+        net.load_state_dict(synth.make_state_dict(L=2, seed=3))
+        net = net.double().eval().to(DEV)
+        zs.append(net.match(ds['keypoints0'], ds['descriptors0'], ds['keypoints1'], ds['descriptors1'],
+                            ds['scores0'], ds['scores1'], return_scores=True)[4])
+    assert torch.equal(zs[0], zs[1])
 
 
 @pytest.mark.parametrize('n,m,L,S,k', [(2048, 2048, 9, 200, None), (1024, 700, 2, 50, [128, None, 64, None]),
