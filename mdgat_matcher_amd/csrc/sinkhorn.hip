@@ -242,12 +242,13 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // K and the absorbed potentials (b: decided on b alone, which is bit-identical in all workgroups of a
 // pair; a: per row, purely local), so any dynamic range the log-domain form handles is handled here.
 //
-// G workgroups (8 waves each, two workgroups per CU) share one pair: workgroup j owns rows [64 j, 64 j + 64),
-// wave w of it 8 of those rows, lane l the columns 8 l .. 8 l + 7: a lane keeps an 8 x 8 block of K (64
-// VGPRs) for all iterations.  Row sums: 8 in-lane FMAs + a DPP wave reduction per row.  Column sums:
-// in-lane over the wave's 8 rows, the 8 waves merged through LDS, the G workgroups through L2 as 8-byte
-// {epoch, value} granules (relaxed agent-scope atomics, the data is the flag, two slot sets alternate by
-// epoch parity; partners sit on one XCD for speed only; bounded spins, a timeout poisons Z with NaN).
+// G workgroups (8 waves each, one per CU) share one pair: workgroup j owns rows [128 j, 128 j + 128), wave w of it
+// 16 of those rows, lane l the columns 8 l .. 8 l + 7: a lane keeps a 16 x 8 block of K (128 VGPRs) for all
+// iterations.  Row sums: 8 in-lane FMAs per row + one transposed wave reduction for the 16 rows (wave_sum16).  Column
+// sums: in-lane over the wave's 16 rows, the 8 waves merged through LDS, the G workgroups through L2 as 8-byte
+// {epoch, value} granules (the data is the flag, two slot sets alternate by epoch parity; relaxed agent-scope atomics,
+// or non-temporal accesses once the partners have agreed that they share an XCD; partners are placed on one XCD for
+// speed only; bounded spins, a timeout poisons Z with NaN).
 struct SksArgs {
     const float* scores;
     const float* alpha_dev;
