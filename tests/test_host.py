@@ -56,6 +56,21 @@ def test_config_contract():
         MDGAT(synth.default_config(L=2, descriptor='pointnet'))
     net = MDGAT(cfg)
     assert net.config['sinkhorn_iterations'] == 100 and net.config['match_threshold'] == 0.2
+    # the one key the reference does not have
+    assert net.attention_dtype == 'fp32' and MDGAT(dict(cfg, attention_dtype='f16')).attention_dtype == 'f16'
+    with pytest.raises(ValueError):
+        MDGAT(dict(cfg, attention_dtype='fp8'))
+
+
+def test_create_rejects_bad_config_before_touching_a_device():
+    lib = _lib.load()
+    for field, value in (('L', 33), ('L', -1), ('attention_mode', 7), ('extract_mode', 4)):
+        c = _lib.MdgatConfig()
+        c.L = 1
+        setattr(c, field, value)
+        h = C.c_void_p()
+        assert lib.mdgat_create(C.byref(c), 0, C.byref(h)) == _lib.ERR_BAD_ARG, field
+        assert not h.value and lib.mdgat_last_error()
 
 
 def test_no_cpu_fallback():
