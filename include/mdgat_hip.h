@@ -81,7 +81,13 @@ typedef struct {
     float* x_layers; /* [2L][B][P][128]    descriptors after every layer (mdgat.py:274) */
     float* mdesc;    /* [B][P][128]        final_proj output (mdgat.py:397) */
     float* scores;   /* [B][N][M]          pre-OT scores (mdgat.py:430-431) */
+    uint32_t* topk_sel; /* [2L][mdgat_topk_sel_words(B, N, M)]  the keys every dynamic layer kept (the index set of
+                           mdgat.py:202 `logits.topk(k)`) as bit masks [B][4 heads][P queries][W words], W = ceil(max(N, M) / 32):
+                           bit j of word w = key 32 w + j of the query's source frame; slices of full-attention layers are
+                           left untouched.  Parity tests feed this selection to the oracle to separate near-tie flips of
+                           the discontinuous top-k from arithmetic error. */
 } mdgat_taps;
+size_t mdgat_topk_sel_words(int B, int N, int M);
 
 /* ---- lifetime ------------------------------------------------------------------------------ */
 
@@ -164,6 +170,10 @@ int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_thr
 int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg,
                     void* workspace, size_t workspace_bytes, void* stream);
 size_t mdgat_attention_workspace_bytes(int B, int N, int M);
+/* The same, also returning the kept keys of a dynamic layer (topk > 0) in sel [mdgat_topk_sel_words(B, N, M)]
+ * (layout as mdgat_taps.topk_sel). */
+int mdgat_attention_sel(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, uint32_t* sel,
+                        void* workspace, size_t workspace_bytes, void* stream);
 
 /* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
  * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */

@@ -38,7 +38,11 @@ class MdgatConfig(C.Structure):
 
 
 class MdgatTaps(C.Structure):
-    _fields_ = [('x_enc', C.c_void_p), ('x_layers', C.c_void_p), ('mdesc', C.c_void_p), ('scores', C.c_void_p)]
+    _fields_ = [('x_enc', C.c_void_p), ('x_layers', C.c_void_p), ('mdesc', C.c_void_p), ('scores', C.c_void_p),
+                ('topk_sel', C.c_void_p)]
+
+
+TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel')
 
 
 # name -> (restype, argtypes); every symbol include/mdgat_hip.h declares
@@ -62,6 +66,9 @@ SIGNATURES = {
     'mdgat_attention': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
     'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'mdgat_attention_sel': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_size_t, C.c_void_p]),
+    'mdgat_topk_sel_words': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_pointwise': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                                   C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     'mdgat_pose': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,

@@ -283,7 +283,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
         const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
-        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s, h->cfg.attention_mode))) return rc;
+        uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
+        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s, h->cfg.attention_mode, sel))) return rc;
         mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1;
@@ -377,6 +378,11 @@ extern "C" size_t mdgat_attention_workspace_bytes(int B, int N, int M) {
 
 extern "C" int mdgat_attention(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, void* workspace,
                                size_t workspace_bytes, void* stream) {
+    return mdgat_attention_sel(B, N, M, cross, topk, qkv, msg, nullptr, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mdgat_attention_sel(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, uint32_t* sel,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
     if (!qkv || !msg || !workspace) { mdgat_set_error("mdgat_attention: null pointer"); return MDGAT_ERR_BAD_ARG; }
     if (topk < 0) { mdgat_set_error("mdgat_attention: topk < 0"); return MDGAT_ERR_BAD_ARG; }
     if (workspace_bytes < mdgat_attention_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
@@ -386,7 +392,7 @@ extern "C" int mdgat_attention(int B, int N, int M, int cross, int topk, const f
     hipStream_t s = static_cast<hipStream_t>(stream);
     const Qkv16 q16 = mdgat_qkv16_carve(static_cast<_Float16*>(workspace), B, N, M);
     if (int rc = launch_qkv_split(B, N, M, qkv, q16, s)) return rc;
-    return launch_attention(B, N, M, cross, topk, q16, msg, s);
+    return launch_attention(B, N, M, cross, topk, q16, msg, s, 0, sel);
 }
 
 extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,

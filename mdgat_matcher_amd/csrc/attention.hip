@@ -38,7 +38,14 @@ struct AttnArgs {
     float* msg;            // [B][P][128]
     int N, M, Npad, PP, cross, topk;
     float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
+    uint32_t* sel;         // TAP kernels only: [B][4][P][selW] bit j of word w = key 32 w + j of the source frame was kept
+    int selW;
 };
+
+// parity tap (mdgat_taps.topk_sel): OR `bits` (NB consecutive keys starting at key0, NB | 32) into the row's mask
+__device__ __forceinline__ void tap_keys(uint32_t* row, int key0, unsigned bits) {
+    if (bits) atomicOr(row + (key0 >> 5), bits << (key0 & 31));
+}
 
 __device__ __forceinline__ float xor32(float v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ int xor32i(int v) { return __shfl_xor(v, 32, 64); }
@@ -62,14 +69,18 @@ __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) 
     for (int j = 0; j < 8; ++j) l[j] = (_Float16)r[j];
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers); the row sum in two packed halves
+// p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers; `kept` counts the logits at or above it); the
+// row sum in two packed halves
 template <bool TOPK>
-__device__ __forceinline__ void softmax8(const float* s, float m11, float thr, float (&p)[8], f32x2& l2) {
+__device__ __forceinline__ void softmax8(const float* s, float m11, float thr, float (&p)[8], f32x2& l2, int& kept) {
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
         const f32x2 d = f32x2{s[j], s[j + 1]} - f32x2{m11, m11};
         f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-        if (TOPK) { e[0] = (s[j] >= thr) ? e[0] : 0.f; e[1] = (s[j + 1] >= thr) ? e[1] : 0.f; }
+        if (TOPK) {
+            e[0] = (s[j] >= thr) ? e[0] : 0.f; e[1] = (s[j + 1] >= thr) ? e[1] : 0.f;
+            kept += (s[j] >= thr); kept += (s[j + 1] >= thr);
+        }
         p[j] = e[0]; p[j + 1] = e[1];
         l2 += e;
     }
@@ -115,6 +126,9 @@ struct QuadComm {
 // the bracket (exact ties at the k-th value: all kept), or when it is one element away from k on either
 // side; those rows are finished by direct order-statistic passes after the loop (max below hv / second
 // smallest at or above lo).  All rows run in lockstep, so the loop ends with its slowest row.
+// More than k logits are >= the returned threshold only when the k-th place falls inside a group of exactly equal
+// logits (fp32 logits closer than one ulp, duplicated keypoints); the kernels count what the softmax pass keeps and
+// call topk_break_ties() for such rows, so that every row keeps exactly k keys like torch.topk.
 template <int NBLK, bool EXACT, typename Comm>
 __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
     const float INF = __builtin_inff();
@@ -192,10 +206,21 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     if (state == 0 && k - chi == 1) state = 2;
     if (!EXACT && state == 0 && clo - k == 1) state = 3;
     float t = mu + zq * sd;
-    for (int it = 0; it < 64; ++it) {
+    // monotone integer image of a float (signed compare order) and back: bisection in this space closes ANY bracket in
+    // at most 32 probes, whatever the distribution of the logits
+    auto ordinal = [](float f) { const int b = __builtin_bit_cast(int, f); return b ^ ((b >> 31) & 0x7fffffff); };
+    for (int it = 0; it < 80; ++it) {
         // (measured at N = 512, k = 128 / 64: 6.9 probes per wave of 16 rows; without this test one more full counting
         // pass ran only to learn that every row had finished)
         if (Comm::LOCAL_VOTE && !comm.any(state == 0)) break;
+        // The density / interpolation steps below converge in ~6 probes on bell-shaped rows but only linearly on
+        // bimodal or heavy-tailed ones: from the 9th probe on every other probe is the ordinal midpoint of the bracket
+        // (36 of them by the end of the loop), so the search always terminates with the exact threshold.
+        if (it >= 9 && (it & 1)) {
+            const int ol = ordinal(lo), oh = ordinal(hv);
+            const int om = ol + (int)(((unsigned)oh - (unsigned)ol) >> 1);
+            t = __builtin_bit_cast(float, om ^ ((om >> 31) & 0x7fffffff));
+        }
         if (!(t > lo && t < hv)) {
             t = lo + (hv - lo) * (((float)(clo - k) + 0.5f) * __builtin_amdgcn_rcpf((float)(clo - chi)));   // (only steers the search)
             if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
@@ -206,7 +231,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         const int c = comm.count_vote(count_local(t), state == 0, any_probing);   // one exchange per probe
         if (!any_probing) break;                       // every row had finished before this probe
         if (state == 0) {
-            // ties at the k-th value: keep them all (k or more of them at the maximum: only those)
+            // ties at the k-th value (k or more of them at the maximum: only those)
             if (collapsed) { thr = (EXACT && hv_est && c >= k) ? hv : lo; state = 1; }
             else if (c == k) { thr = t; state = 1; }
             else {
@@ -226,7 +251,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
             }
         }
     }
-    if (state == 0) { thr = lo; state = 1; }
+    if (state == 0) { thr = lo; state = 1; }         // (probe cap; not reached, see the bisection above)
     if (comm.any(state == 2)) {   // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
         float mx = -INF;
 #pragma unroll
@@ -256,6 +281,47 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     return thr;
 }
 
+// Exactly k keys per row (torch.topk keeps exactly k; which of several EQUAL logits it keeps is unspecified there -
+// here the lowest key indices stay).  Rare path (about one row in 10^5 on real-valued data): the softmax pass counts
+// the keys it keeps (one v_addc per logit, hidden behind the P.V MFMAs); when a row kept more than k, the tied logit
+// with the largest key index is dropped, `surplus` (= kept - k, per row) times: either overwritten with -inf in the
+// registers before the pass is (re)done, or - attention_topk16_kernel - its share is taken out of the written row again.
+// Key index (within the source frame) of S[jb][r] in this lane = lane_off + Layout::koff(jb, r), the second part a
+// compile-time constant.
+struct KeyLayout32 { static __device__ constexpr int koff(int jb, int r) { return jb * 32 + 16 * (r >> 3) + (r & 7); } };       // 32x32 S^T fragments
+struct KeyLayout16 { static __device__ constexpr int koff(int jb, int r) { return 16 * (4 * jb + (r >> 2)) + (r & 3); } };      // 16x16 S^T fragments
+struct NoDropHook { __device__ __forceinline__ void operator()(int, bool) const {} };
+// SWEEP: write -inf over the dropped logits in the registers (the pass is then run on them).  on_drop(key, active) is
+// called once per dropped key and round (`active` = this lane's row drops `key` in this round).
+template <typename Layout, bool SWEEP = true, int NBLK, typename Comm, typename Hook = NoDropHook>
+__device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, int surplus, Comm& comm, int lane_off, Hook on_drop = Hook()) {
+    // lim = smallest key index to drop: the surplus-th largest index among the tied logits, found one at a time (the
+    // registers are only written after the loop: modifying S inside it costs the kernels dozens of spilled registers)
+    int lim = 1 << 20;
+#pragma unroll 1
+    while (comm.any(surplus > 0)) {
+        const int below = lim - lane_off;
+        int cand = -1;                              // largest koff below the limit of a tied logit in this lane
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cand = (S[jb][r] == thr && Layout::koff(jb, r) < below) ? Layout::koff(jb, r) : cand;   // (koff grows with (jb, r))
+        // (key indices are < 4096: exact as floats)
+        const int top = (int)comm.rmax(cand >= 0 ? (float)(cand + lane_off) : -1.0f);
+        if (surplus > 0) lim = top;
+        on_drop(top, surplus > 0);
+        surplus -= 1;
+    }
+    if (SWEEP) {
+        const int from = lim - lane_off;
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (S[jb][r] == thr && Layout::koff(jb, r) >= from) S[jb][r] = -__builtin_inff();
+    }
+}
+
 // NBLK  = 32-key blocks per chunk (16 NBLK row registers); full attention walks the keys chunk by chunk
 //         with an online softmax (running max / sum, the output rescaled between chunks), dynamic
 //         attention needs the whole row at once and therefore a single chunk.
@@ -263,8 +329,9 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
 // LARGE = more than 512 keys (full attention only): LDS holds a window of 512 keys that is re-staged for
 //         every query pass; the online softmax carries across windows.
 // Threads: 512 (two waves per SIMD, <= 256 registers) for NBLK <= 8, else 256 (one wave per SIMD).
-template <bool TOPK, int NBLK, bool EXACT, bool LARGE>
+template <bool TOPK, int NBLK, bool EXACT, bool LARGE, bool TAP = false>
 __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void attention_kernel(AttnArgs a) {
+    static_assert(TOPK || !TAP, "the selection tap belongs to the dynamic layers");
     static_assert(!(TOPK && LARGE), "dynamic attention needs the whole row in one chunk");
     constexpr int NT = NBLK <= 8 ? 512 : 256;
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
@@ -359,6 +426,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+        bool redo = false;                                      // dynamic layers: exact ties at the k-th place
+        int surplus = 0;
+        const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
 
         for (int wb0 = 0; wb0 < nblk; wb0 += wcap) {            // LDS windows (one unless LARGE)
             const int wnb = min(wcap, nblk - wb0);
@@ -411,7 +481,32 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
                 // ---- exact top-k threshold (dynamic layers: the chunk is the whole row) ----
                 float thr = NEG_INF;
-                if (TOPK) { WaveComm comm; thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm); }
+                if (TOPK) {
+                    WaveComm comm;
+                    thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm);
+                    if (TAP) {      // the TAP build counts first, so that the selection it records is final
+                        int c = 0;
+#pragma unroll
+                        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
+                        surplus = comm.rsum(c) - kexp;
+                    }
+                    if (redo || TAP) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, c0 * 32 + 8 * hi);
+                }
+                if (TOPK && TAP && qw + l31 < nq) {
+                    uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
+#pragma unroll
+                    for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const int key0 = (c0 + jb) * 32 + 16 * t + 8 * hi;
+                            unsigned bits = 0;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) bits |= (unsigned)(S[jb][8 * t + j] >= thr && key0 + j < nk) << j;
+                            tap_keys(row, key0, bits);
+                        }
+                }
 
                 if (!TOPK && (wb0 + c0) > 0) {
                     // online softmax: bring the running sum and output to the new maximum
@@ -432,6 +527,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
                 // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
                 const float m11 = m - 11.0f;
+                int kept = 0;
 #pragma unroll
                 for (int jb = 0; jb < NBLK; ++jb) {
                     if (EXACT || c0 + jb < wnb) {
@@ -440,7 +536,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             float p[8], s8[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
-                            softmax8<TOPK>(s8, m11, thr, p, l2);
+                            softmax8<TOPK>(s8, m11, thr, p, l2, kept);
                             f16x8 ph, pl;
                             split8(p, ph, pl);
                             const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
@@ -450,6 +546,19 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
                             Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
                         }
+                    }
+                }
+                if (TOPK) {
+                    // a row kept more than k logits (exact ties at the k-th place): redo the chunk - the whole row -
+                    // once, with the tie-break (topk_break_ties)
+                    surplus = kept + xor32i(kept) - kexp;
+                    if (!redo && __any(surplus > 0)) {
+                        redo = true;
+                        c0 -= NBLK;
+                        m_run = NEG_INF;
+                        l2 = f32x2{0.f, 0.f};
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
                     }
                 }
             }
@@ -477,7 +586,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 // of the workgroup search independently.  K sits in LDS as [plane][dim chunk g][key] 16-byte units (conflict free for
 // this fragment shape), V^T as in the other kernels; P.V pairs two key blocks per k-step.
 // FAST (mdgat_attention_mode F16): hi planes only, one MFMA per product.
-template <bool FAST>
+template <bool FAST, bool TAP = false>
 __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
@@ -547,25 +656,29 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // ---- S^T: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
         const _Float16* kfrag_h = Ks + l15 * 64 + (g ^ (l15 & 7)) * 8;
         const _Float16* kfrag_l = Ks + l15 * 64 + ((4 + g) ^ (l15 & 7)) * 8;
-        f32x16 S[8];
+        // logits of the tile: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r
+        auto logits = [&](f32x16 (&S)[8]) {
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < 8; ++c) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int blk = 4 * c + j;
-                // A operand: key l15 of the block, dims 8 g ..; (key & 7) = (l15 & 7): the swizzle is a per-lane constant
-                const f16x8 kh = *reinterpret_cast<const f16x8*>(kfrag_h + blk * (16 * 64));
-                const f16x8 kl = *reinterpret_cast<const f16x8*>(kfrag_l + blk * (16 * 64));
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
-                if (!FAST) {
-                    acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
-                    acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
+                for (int j = 0; j < 4; ++j) {
+                    const int blk = 4 * c + j;
+                    // A operand: key l15 of the block, dims 8 g ..; (key & 7) = (l15 & 7): the swizzle is a per-lane constant
+                    const f16x8 kh = *reinterpret_cast<const f16x8*>(kfrag_h + blk * (16 * 64));
+                    const f16x8 kl = *reinterpret_cast<const f16x8*>(kfrag_l + blk * (16 * 64));
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
+                    if (!FAST) {
+                        acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, acx, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) S[c][4 * j + r] = FAST ? acc[r] : fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
                 }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) S[c][4 * j + r] = FAST ? acc[r] : fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
             }
-        }
+        };
+        f32x16 S[8];
+        logits(S);
         float m = -__builtin_inff();
 #pragma unroll
         for (int c = 0; c < 8; ++c)
@@ -573,10 +686,32 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[c][r]);
         m = comm.rmax(m);
         const float thr = topk_threshold<8, true>(S, m, a.topk, nk, a.zq, comm);
+        if (TAP) {
+            // the selection the tap records is final: count and break exact ties at the k-th place before the pass
+            int c = 0;
+#pragma unroll
+            for (int jb = 0; jb < 8; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
+            topk_break_ties<KeyLayout16>(S, thr, comm.rsum(c) - a.topk, comm, 4 * g);
+            if (qw + l15 < nq) {
+                uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l15) * a.selW;
+#pragma unroll
+                for (int c2 = 0; c2 < 8; ++c2)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        unsigned bits = 0;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) bits |= (unsigned)(S[c2][4 * j + r] >= thr) << r;
+                        tap_keys(row, 16 * (4 * c2 + j) + 4 * g, bits);
+                    }
+            }
+        }
 
         // ---- P' = 2048 exp2(s - m), masked; O = P' V with two key blocks per k-step ----
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
+        int kept = 0;
         f32x4 Om[2], Ox[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { Om[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ox[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -587,7 +722,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 float p[8], s8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s8[i] = S[c][8 * jj + i];
-                softmax8<true>(s8, m11, thr, p, l2);
+                softmax8<true>(s8, m11, thr, p, l2, kept);
                 f16x8 ph, pl;
                 if (FAST) {
 #pragma unroll
@@ -611,8 +746,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 }
             }
         }
-        const float l = comm.rsum(l2[0] + l2[1]);
-        const float inv_l = 1.0f / l;
+        float l_row = comm.rsum(l2[0] + l2[1]);
+        const float inv_l = 1.0f / l_row;
         // ---- message rows: lane (dim l15 (+16 t), g) holds queries 4 g + r ----
         float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l15;
 #pragma unroll
@@ -624,6 +759,39 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 out[(size_t)q * 128] = fmaf(Ox[0][r], MDGAT_SPLIT_INV, Om[0][r]) * inv;
                 out[(size_t)q * 128 + 16] = fmaf(Ox[1][r], MDGAT_SPLIT_INV, Om[1][r]) * inv;
             }
+        }
+        if (TAP) continue;
+        // ---- exact ties at the k-th place: a row kept more than k logits (topk_break_ties; about one row in 10^5).
+        // A launch waits for its slowest workgroup, so this has to be short and must not burden the code above: the
+        // logits are computed again (they do not survive the pass: there are not enough registers), the tied logits
+        // with the largest key indices are found one at a time and the share of each is taken out of the rows just
+        // written:  o <- (o l - P' v) / (l - P'),  l <- l - P'.  (A second pass instead costs the launch 10 % at B = 64.)
+        const int surplus = comm.rsum(kept) - a.topk;
+        if (comm.any(surplus > 0)) {
+            logits(S);
+            const float e = __builtin_amdgcn_exp2f(thr - m11);                  // P' of a tied logit, as softmax8 computes it
+            const float eh = (float)(_Float16)e;
+            const float el = (float)(_Float16)(e - eh);
+            topk_break_ties<KeyLayout16, false>(S, thr, surplus, comm, 4 * g, [&](int key, bool active) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {       // this lane wrote dims l15, 16 + l15 of the output rows 4 g + r
+                    const int row = 4 * g + r;
+                    const int x = __shfl(key, row, 64);
+                    const float ph = __shfl(eh, row, 64), pl = __shfl(el, row, 64);
+                    const float lr = __shfl(l_row, row, 64), er = __shfl(e, row, 64);
+                    if (__shfl((int)active, row, 64) && qw + row < nq) {
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            const _Float16* vp = Vs + (16 * t + l15) * VSTR + x;
+                            const float vh = (float)vp[0], vl = (float)vp[32 * VSTR];
+                            const float c = FAST ? ph * vh : fmaf(ph * vl, MDGAT_SPLIT_INV, fmaf(pl, vh, ph * vh));
+                            float* o = out + (size_t)(qw + row) * 128 + 16 * t;
+                            *o = (*o * lr - c) / (lr - er);
+                        }
+                    }
+                }
+                if (active) l_row -= e;
+            });
         }
     }
 }
@@ -672,7 +840,7 @@ struct WideComm {
 // Dynamic attention for more than 512 keys per frame (up to 256 NW): NW waves share a 32-query tile, wave
 // kw of the tile keeps the logits of keys [256 kw, 256 kw + 256) in 128 registers.  Nothing is shared between
 // the waves except per-row scalars, so K and V^T fragments come straight from global memory (L2) instead of LDS.
-template <int NW>
+template <int NW, bool TAP = false>
 __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a) {
     constexpr int NBLK = 8;
     constexpr int NG = 8 / NW;                // query tiles per workgroup pass
@@ -713,6 +881,12 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             ql[0] = *reinterpret_cast<const f16x8*>(p + 32);
             ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
         }
+        f32x2 l2;
+        f32x16 Om, Ox;
+        int surplus = 0;
+        const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
+        // (the pass is redone once, with the tie-break, when one of its rows kept more than k logits: topk_break_ties)
+        for (bool redo = false;; redo = true) {
         f32x16 S[NBLK];
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
@@ -753,10 +927,32 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
         m = comm.rmax(m);
         const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
+        if (TAP) {      // the TAP build counts first, so that the selection it records is final
+            int c = 0;
+#pragma unroll
+            for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
+            surplus = comm.rsum(c) - kexp;
+        }
+        if (redo || TAP) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, kw * NBLK * 32 + 8 * hi);
+        if (TAP && qw + l31 < nq) {
+            uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
+#pragma unroll
+            for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int key0 = (kw * NBLK + jb) * 32 + 16 * t + 8 * hi;
+                    unsigned bits = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) bits |= (unsigned)(S[jb][8 * t + j] >= thr && key0 + j < nk) << j;
+                    tap_keys(row, key0, bits);
+                }
+        }
 
         const float m11 = m - 11.0f;
-        f32x2 l2 = {0.f, 0.f};
-        f32x16 Om, Ox;
+        l2 = f32x2{0.f, 0.f};
+        int kept = 0;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
 #pragma unroll
@@ -768,7 +964,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                     float p[8], s8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
-                    softmax8<true>(s8, m11, thr, p, l2);
+                    softmax8<true>(s8, m11, thr, p, l2, kept);
                     f16x8 ph, pl;
                     split8(p, ph, pl);
                     const _Float16* vp = vg + gb * 32 + t * 16;
@@ -779,6 +975,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                     Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
                 }
             }
+        }
+        surplus = comm.rsum(kept) - kexp;
+        if (!comm.any(surplus > 0) || redo) break;  // (any() first: every wave of the workgroup takes part in it)
         }
         float l = l2[0] + l2[1];
         l += xor32(l);
@@ -817,10 +1016,12 @@ static int launch_attention_topk_wide(const AttnArgs& a, int B, int nk_max, hipS
     const size_t lds = (size_t)(1040 + 8 * 17 * 64) * sizeof(float);
     if (nblk <= 32) {
         const int npass = (nk_max + 63) / 64;
-        hipLaunchKernelGGL(attention_topk_wide_kernel<4>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<4, true>), dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(attention_topk_wide_kernel<4>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
     } else {
         const int npass = (nk_max + 31) / 32;
-        hipLaunchKernelGGL(attention_topk_wide_kernel<8>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<8, true>), dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        else hipLaunchKernelGGL(attention_topk_wide_kernel<8>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
     }
     return mdgat_check_hip(hipGetLastError(), "wide dynamic attention launch");
 }
@@ -899,7 +1100,11 @@ static float normal_quantile_upper(double p) {
     return (float)x;
 }
 
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode) {
+extern "C" size_t mdgat_topk_sel_words(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return (size_t)B * 4 * (N + M) * (((N > M ? N : M) + 31) / 32); }
+
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode, uint32_t* sel) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
     if (topk > 0) {
@@ -910,7 +1115,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             return MDGAT_ERR_BAD_ARG;
         }
     }
-    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f};
+    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f, nullptr, (nk_max + 31) / 32};
     if (topk > 0) a.zq = normal_quantile_upper(((double)topk - 0.5) / (double)nk_max);
     const int nkp = ((nk_max + 31) / 32) * 32;
     const int wkeys = nkp > 512 ? 512 : nkp;      // keys the LDS window holds
@@ -918,6 +1123,11 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     // k == number of keys on both sides keeps every key: identical to full attention
     const bool dyn = topk > 0 && !(topk == N && topk == M);
     const int nblk = nkp / 32;
+    if (sel && topk > 0) {
+        // parity tap: the kept keys of every (pair, head, query) as a bit mask; k == number of keys keeps them all
+        if (int rc = mdgat_check_hip(hipMemsetAsync(sel, dyn ? 0 : 0xff, mdgat_topk_sel_words(B, N, M) * sizeof(uint32_t), s), "memset(top-k tap)")) return rc;
+        if (dyn) a.sel = sel;
+    }
     if (!dyn && attention_stream_supported(N, M) && !getenv("MDGAT_ATTN_NOSTREAM")) return launch_attention_stream(B, N, M, cross, qkv, msg, s, mode);
     // one workgroup per (pair, frame, head) loops over its query tiles; split the tiles over more
     // workgroups only when there are too few (pair, frame, head) units to fill the chip twice
@@ -934,7 +1144,11 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     const bool mult32 = (N % 32 == 0) && (M % 32 == 0);
     if (dyn) {
         // the whole row in one chunk
-        if (nblk <= 4) go(attention_kernel<true, 4, false, false>, 512);
+        if (a.sel && !(N == 512 && M == 512) && nblk <= 16) {
+            if (nblk <= 4) go(attention_kernel<true, 4, false, false, true>, 512);
+            else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false, true>, 512); else go(attention_kernel<true, 8, false, false, true>, 512); }
+            else go(attention_kernel<true, 16, false, false, true>, 256);
+        } else if (nblk <= 4) go(attention_kernel<true, 4, false, false>, 512);
         else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false>, 512); else go(attention_kernel<true, 8, false, false>, 512); }
         else if (N == 512 && M == 512) {
             // 512 keys in both frames: one wave = 16 queries, the row in four lanes
@@ -945,7 +1159,12 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (mode == 1) hipLaunchKernelGGL(attention_topk16_kernel<true>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+            if (a.sel) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+                if (mode == 1) hipLaunchKernelGGL((attention_topk16_kernel<true, true>), dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+                else hipLaunchKernelGGL((attention_topk16_kernel<false, true>), dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+            } else if (mode == 1) hipLaunchKernelGGL(attention_topk16_kernel<true>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
             else hipLaunchKernelGGL(attention_topk16_kernel<false>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
         } else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
         else return launch_attention_topk_wide(a, B, nk_max, s);

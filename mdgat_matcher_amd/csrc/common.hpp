@@ -107,7 +107,8 @@ size_t mdgat_qkv16_halves(int B, int N, int M);
 Qkv16 mdgat_qkv16_carve(_Float16* base, int B, int N, int M);
 int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& out, hipStream_t s);
 // mode: mdgat_attention_mode (1 = single-f16 products where implemented)
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0);
+// sel (parity tap, may be NULL): the kept keys of a dynamic layer as bit masks [B][4][P][W], W = ceil(max(N, M) / 32)
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0, uint32_t* sel = nullptr);
 // full attention as a stream of 64-key chunks (attention_stream.hip); frames with key counts that are multiples of 64
 bool attention_stream_supported(int N, int M);
 int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0);

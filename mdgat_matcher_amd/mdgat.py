@@ -293,7 +293,7 @@ class MDGAT(nn.Module):
             tap_struct = None
             if taps is not None:
                 tap_struct = _lib.MdgatTaps()
-                for name in ('x_enc', 'x_layers', 'mdesc', 'scores'):
+                for name in _lib.TAP_NAMES:
                     t = taps.get(name)
                     setattr(tap_struct, name, t.data_ptr() if t is not None else None)
             stream = torch.cuda.current_stream(dev).cuda_stream
@@ -341,7 +341,7 @@ class MDGAT(nn.Module):
             tap_struct = None
             if taps is not None:
                 tap_struct = _lib.MdgatTaps()
-                for name in ('x_enc', 'x_layers', 'mdesc', 'scores'):
+                for name in _lib.TAP_NAMES:
                     t = taps.get(name)
                     setattr(tap_struct, name, t.data_ptr() if t is not None else None)
             rc = lib.mdgat_forward_frames(

@@ -54,8 +54,25 @@ def extract(Z: torch.Tensor, mode: int = _lib.EXTRACT_DUSTBIN, match_threshold: 
     return m0, m1, s0, s1
 
 
-def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0) -> torch.Tensor:
-    """attention / dynamic_attention (mdgat.py:190-210).  qkv [B, N+M, 3, 4, 32] -> message [B, N+M, 128]."""
+def topk_sel_words(B: int, N: int, M: int) -> int:
+    """uint32 words of one layer's slice of the top-k selection tap (``mdgat_taps.topk_sel``)."""
+    return int(_lib.load().mdgat_topk_sel_words(B, N, M))
+
+
+def topk_sel_to_masks(sel: torch.Tensor, B: int, N: int, M: int, cross: bool):
+    """Unpack one layer's selection tap (int32 words [B][4][N+M][W]) into boolean masks
+    ``(mask0 [B, 4, N, keys of frame 0's source], mask1 [B, 4, M, keys of frame 1's source])``: True where the dynamic
+    layer kept the key (the index set of ``logits.topk(k)``, mdgat.py:202)."""
+    W = (max(N, M) + 31) // 32
+    w = sel.reshape(B, 4, N + M, W).to(torch.int64) & 0xFFFFFFFF
+    bits = ((w[..., None] >> torch.arange(32, device=w.device)) & 1).bool().reshape(B, 4, N + M, W * 32)
+    nk0, nk1 = (M, N) if cross else (N, M)
+    return bits[:, :, :N, :nk0], bits[:, :, N:, :nk1]
+
+
+def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0, return_selection: bool = False):
+    """attention / dynamic_attention (mdgat.py:190-210).  qkv [B, N+M, 3, 4, 32] -> message [B, N+M, 128]
+    (with ``return_selection``: also the boolean masks of the keys a dynamic layer kept, see topk_sel_to_masks)."""
     _need_cuda(qkv)
     x = qkv.to(torch.float32).contiguous()
     B, P = x.shape[0], x.shape[1]
@@ -65,8 +82,12 @@ def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0) -> 
     with torch.cuda.device(x.device):
         need = lib.mdgat_attention_workspace_bytes(B, N, M)
         ws = torch.empty(need, dtype=torch.uint8, device=x.device)
-        _lib.check(lib.mdgat_attention(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
-                                       ws.data_ptr(), need, _stream(x)), 'mdgat_attention')
+        sel = torch.empty(topk_sel_words(B, N, M), dtype=torch.int32, device=x.device) if return_selection else None
+        _lib.check(lib.mdgat_attention_sel(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
+                                           sel.data_ptr() if sel is not None else None,
+                                           ws.data_ptr(), need, _stream(x)), 'mdgat_attention')
+    if return_selection:
+        return msg, topk_sel_to_masks(sel, B, N, M, cross)
     return msg
 
 

@@ -83,21 +83,45 @@ def attention(q, k, v):
     return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob
 
 
-def dynamic_attention(q, k, v, topk: int):
+def dynamic_attention(q, k, v, topk: int, forced=None, report=None):
     """mdgat.py:196-210: per (batch, head, query) keep the ``topk`` largest logits, softmax over
-    those, zero probability elsewhere.  ``topk > M`` raises, as ``torch.topk`` does there."""
+    those, zero probability elsewhere.  ``topk > M`` raises, as ``torch.topk`` does there.
+
+    Attribution of top-k flips (test infrastructure, no reference counterpart): ``forced`` is a boolean mask
+    [B, H, N, M] of the keys ANOTHER implementation kept for the same layer; the softmax then runs over that
+    selection instead of this function's own ``topk`` (softmax over a gathered set == masked softmax, 205-209), and
+    ``report`` (a list) receives one dict per call describing every row where the two selections differ:
+    ``rows`` = number of such rows, ``max_gap`` = largest |logit - k-th largest logit| over the keys in the symmetric
+    difference (how far from a tie the disagreement is, in the units of the logits), ``bad_count`` = rows whose forced
+    selection does not hold exactly ``topk`` keys."""
     dh = q.shape[1]
     m = k.shape[3]
     if topk > m:
         raise RuntimeError(f'selected index k out of range: k={topk} > {m} keys')
     logits = torch.einsum('bdhn,bdhm->bhnm', q, k) / dh ** 0.5
     top = logits.topk(topk, dim=3, largest=True, sorted=True)
-    prob = torch.zeros_like(logits)
-    prob.scatter_(3, top.indices, torch.softmax(top.values, dim=-1))
+    if forced is None:
+        prob = torch.zeros_like(logits)
+        prob.scatter_(3, top.indices, torch.softmax(top.values, dim=-1))
+        if report is not None:      # this function's own selection, in the mask form `forced` takes
+            report.append({'own': torch.zeros_like(logits, dtype=torch.bool).scatter_(3, top.indices, True)})
+    else:
+        forced = forced.to(torch.bool)
+        assert forced.shape == logits.shape, (forced.shape, logits.shape)
+        prob = torch.softmax(logits.masked_fill(~forced, -math.inf), dim=-1)
+        if report is not None:
+            own = torch.zeros_like(forced)
+            own.scatter_(3, top.indices, True)
+            diff = own ^ forced
+            kth = top.values[..., -1:]
+            gap = torch.where(diff, (logits - kth).abs(), torch.zeros_like(logits))
+            report.append({'rows': int(diff.any(-1).sum()), 'total_rows': diff[..., 0].numel(),
+                           'max_gap': float(gap.max()), 'bad_count': int((forced.sum(-1) != topk).sum()),
+                           'row_gaps': gap.amax(-1)[diff.any(-1)]})
     return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob
 
 
-def multi_head_attention(sd, prefix, x, source, topk: Optional[int]):
+def multi_head_attention(sd, prefix, x, source, topk: Optional[int], forced=None, report=None):
     """MultiHeadedAttention.forward (mdgat.py:223-237).  The ``view(B, dh, H, -1)`` at 227/231
     sends channel c to (d = c // H, h = c % H)."""
     b, d_model, _ = x.shape
@@ -108,14 +132,14 @@ def multi_head_attention(sd, prefix, x, source, topk: Optional[int]):
     if topk is None:
         msg, _ = attention(q, k, v)
     else:
-        msg, _ = dynamic_attention(q, k, v, topk)
+        msg, _ = dynamic_attention(q, k, v, topk, forced, report)
     msg = msg.contiguous().view(b, d_model, -1)
     return _pointwise(sd[f'{prefix}.merge.weight'], sd[f'{prefix}.merge.bias'], msg)
 
 
-def attentional_propagation(sd, prefix, x, source, topk):
+def attentional_propagation(sd, prefix, x, source, topk, forced=None, report=None):
     """AttentionalPropagation.forward (mdgat.py:246-248): MLP([x ; message])."""
-    message = multi_head_attention(sd, f'{prefix}.attn', x, source, topk)
+    message = multi_head_attention(sd, f'{prefix}.attn', x, source, topk, forced, report)
     return mlp(sd, f'{prefix}.mlp', torch.cat([x, message], dim=1), 2)
 
 
@@ -131,16 +155,26 @@ def layer_topk_schedule(L: int, k_list: List[Optional[int]]) -> List[Optional[in
     return sched
 
 
-def attentional_gnn(sd, desc0, desc1, k_list, L, capture=None):
+def attentional_gnn(sd, desc0, desc1, k_list, L, capture=None, forced_topk=None):
     """AttentionalGNN.forward (mdgat.py:259-276): alternating self/cross layers (352-353); both
-    frames use the same layer weights and the pre-update descriptors (270 before 274)."""
+    frames use the same layer weights and the pre-update descriptors (270 before 274).
+
+    ``forced_topk`` (test infrastructure): {layer index: (mask0, mask1)} selections for dynamic_attention, see there;
+    the per-layer reports land in ``capture['topk_report'][layer] = [frame-0 report, frame-1 report]`` (an empty dict
+    makes every dynamic layer report its own selection)."""
     sched = layer_topk_schedule(L, k_list)
     for i in range(2 * L):
         cross = (i % 2 == 1)
         src0, src1 = (desc1, desc0) if cross else (desc0, desc1)
         p = f'gnn.layers.{i}'
-        delta0 = attentional_propagation(sd, p, desc0, src0, sched[i])
-        delta1 = attentional_propagation(sd, p, desc1, src1, sched[i])
+        f0 = f1 = rep = None
+        if forced_topk is not None and sched[i] is not None:
+            f0, f1 = forced_topk.get(i, (None, None))
+            rep = [] if capture is not None else None
+        delta0 = attentional_propagation(sd, p, desc0, src0, sched[i], f0, rep)
+        delta1 = attentional_propagation(sd, p, desc1, src1, sched[i], f1, rep)
+        if rep is not None:
+            capture.setdefault('topk_report', {})[i] = rep
         desc0, desc1 = desc0 + delta0, desc1 + delta1
         if capture is not None:
             capture[f'layer{i}_desc0'] = desc0
@@ -337,10 +371,12 @@ def gt_matches(kp0, kp1, T0=None, T1=None, threshold=0.5, mutual=False):
 
 
 # ----------------------------------------------------------------------------- whole forward
-def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture: Optional[dict] = None):
+def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture: Optional[dict] = None,
+                  forced_topk: Optional[dict] = None):
     """MDGAT.forward for ``descriptor == 'FPFH'`` (mdgat.py:369-483, 596-603), loss excluded.
 
-    ``capture`` (optional dict) receives the stage tensors the golden fixtures hold."""
+    ``capture`` (optional dict) receives the stage tensors the golden fixtures hold; ``forced_topk`` replaces the
+    top-k selections of the dynamic layers (see attentional_gnn / dynamic_attention)."""
     dtype = sd['bin_score'].dtype
     kpts0, kpts1 = data['keypoints0'].to(dtype), data['keypoints1'].to(dtype)
     if kpts0.shape[1] == 0 or kpts1.shape[1] == 0:          # mdgat.py:374-382
@@ -358,7 +394,7 @@ def mdgat_forward(sd: Dict[str, torch.Tensor], config: dict, data: dict, capture
     desc1 = encode(sd, kpts1, data['scores1'].to(dtype), data['descriptors1'].to(dtype))
     if capture is not None:
         capture['enc0'], capture['enc1'] = desc0, desc1
-    desc0, desc1 = attentional_gnn(sd, desc0, desc1, config['k'], L, capture)
+    desc0, desc1 = attentional_gnn(sd, desc0, desc1, config['k'], L, capture, forced_topk)
     mdesc0 = _pointwise(sd['final_proj.weight'], sd['final_proj.bias'], desc0)       # mdgat.py:397
     mdesc1 = _pointwise(sd['final_proj.weight'], sd['final_proj.bias'], desc1)
     scores = torch.einsum('bdn,bdm->bnm', mdesc0, mdesc1) / d_model ** 0.5           # mdgat.py:430-431

@@ -11,16 +11,14 @@ pytestmark = pytest.mark.gpu
 from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
 
+from parity_util import assert_attributed, attributed_parity  # noqa: E402
+
 DEV = 'cuda:0'
-Z_TOL = 1e-4        # north star: soft-assignment matrix within 1e-4 (fp32 kernels vs fp64 reference)
-# Dynamic (top-k) layers are discontinuous in their logits: when the k-th and (k+1)-th largest logit of a
-# row differ by less than the fp32 round-off of the pipeline (~2e-6), fp32 and the fp64 reference keep a
-# different key and that ONE keypoint's descriptor moves by ~p_k |v_a - v_b| (~5e-4).  At the bench shape
-# (2 x 512 rows x 4 heads x 4 dynamic layers per pair) about one such near-tie per pair is expected
-# (DESIGN.md section 6), so the big-shape tests bound the FRACTION of entries outside 1e-4 and the worst
-# case, while every fixture without such a near-tie (all the small ones) is held to 1e-4 everywhere.
-FLIP_FRAC = 0.02    # at most 2 % of Z entries (a few rows/columns) may exceed Z_TOL at N=512
-FLIP_MAX = 2e-2
+Z_TOL = 1e-4        # north star: soft-assignment matrix within 1e-4 (fp32-class kernels vs fp64 reference)
+# Dynamic (top-k) layers are discontinuous in their logits.  Configurations that have them are held to the bar in the
+# two-statement form of tests/parity_util.py: Z within 1e-4 everywhere and identical matches against the fp64 oracle
+# run with the HIP path's own top-k selections, and every selection that differs from the oracle's is a near-tie
+# below GAP_EPS.  Where no selection differs, the plain comparison with the reference's golden output is asserted too.
 
 
 def _g(golden_dir, name):
@@ -96,24 +94,30 @@ def test_forward_dict_contract_and_variants(golden_dir, name):
 
 @pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100'])
 def test_config_shapes_golden(golden_dir, name):
+    """BASELINE configs[0] / configs[1] shapes with the default dynamic schedule, against the REFERENCE's own fp64
+    output (tests/golden/cfg_*.npz) and against the oracle with the HIP selections forced."""
     g = _g(golden_dir, name)
-    net, data, (B, n, m, L) = _build(g)
-    m0, m1, s0, s1, Z = net.match(data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'],
-                                  data['scores0'], data['scores1'], return_scores=True)
+    net, _, (B, n, m, L) = _build(g)
+    seed, first_pair = int(g['meta'][5]), int(g['meta'][6])
+    k = [None if x < 0 else int(x) for x in g['k']]
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=int(g['meta'][4]))
+    sd = synth.make_state_dict(L=L, seed=seed, bin_score=float(g['bin_score']) if 'bin_score' in g else 1.0)
+    res = attributed_parity(net, cfg, sd, synth.make_batch(B, n, m, first_pair=first_pair), DEV)
+    assert_attributed(res, name)
+    m0, m1, s0, s1, Z = res['out']
+    # column marginals are exact by construction and independent of the top-k selections
+    assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
     Zc = Z.cpu().double().numpy()
     errs = np.concatenate([np.abs(Zc[:, ::8, ::8] - g['Z_sub']).ravel(), np.abs(Zc[:, -1, :] - g['Z_lastrow']).ravel(),
                            np.abs(Zc[:, :, -1] - g['Z_lastcol']).ravel()])
-    print(name, 'max|dZ|', errs.max(), 'frac > 1e-4:', (errs > Z_TOL).mean(), 'median', np.median(errs))
-    assert np.median(errs) < 1e-5
-    assert (errs > Z_TOL).mean() < FLIP_FRAC and errs.max() < FLIP_MAX      # see the note on near-ties above
-    # column marginals are exact by construction and independent of top-k near-ties
-    assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
-    mm0 = (m0.cpu().numpy() != g['default_matches0']).mean()
-    mm1 = (m1.cpu().numpy() != g['default_matches1']).mean()
-    print(name, 'match mismatch fraction', mm0, mm1)
-    assert mm0 < 0.005 and mm1 < 0.005
-    agree = m0.cpu().numpy() == g['default_matches0']
-    assert np.abs(s0.cpu().double().numpy() - g['default_mscores0'])[agree].max() < 5e-3
+    mm = (m0.cpu().numpy() != g['default_matches0']).sum() + (m1.cpu().numpy() != g['default_matches1']).sum()
+    print(f'[parity] {name} vs the reference golden: max|dZ| {errs.max():.3e}, entries > 1e-4: {(errs > Z_TOL).mean():.2e}, '
+          f'matches differing {mm}')
+    if res['flip_rows'] == 0:       # same selections as the reference: the plain bar applies
+        assert errs.max() < Z_TOL
+        np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+        np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+        assert np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max() < Z_TOL
 
 
 def test_dataparallel_dropin_like_test_py(golden_dir):
@@ -200,13 +204,13 @@ def test_bench_shape_properties():
     argsp = (args[0][:2], args[1][:2], args[2][:2, perm], args[3][:2, perm], args[4][:2], args[5][:2, perm])
     m0p, m1p, s0p, s1p, Zp = net.match(*argsp, return_scores=True)
     assert (Zp[:, :, :n] - Z[:2][:, :, perm]).abs().max() < 1e-3
-    # (6) a pinned oracle run of two pairs of the same batch agrees within the north-star tolerance
-    cap = {}
+    # (6) two pairs of the same batch against the fp64 oracle, north-star bar in the attributed form (parity_util.py);
+    #     by (2) the result of a pair does not depend on the batch it is in
     sd = synth.make_state_dict(L=L, seed=0)
     cpu = {k: v[:2].cpu().double() for k, v in data.items()}
-    O.mdgat_forward(sd, synth.default_config(L=L), cpu, cap)
-    err = (cap['Z'] - Z[:2].cpu().double()).abs()
-    assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC and err.max() < FLIP_MAX
+    res = attributed_parity(net, synth.default_config(L=L), sd, cpu, DEV)
+    assert_attributed(res, 'bench shape, pairs 0-1')
+    assert torch.equal(res['out'][4], Z[:2])
 
 
 @pytest.mark.parametrize('n,L,S', [(256, 4, 20), (512, 9, 100)])
@@ -275,27 +279,26 @@ def test_f16_attention_mode_configs2():
                                        (600, 1300, 2, 30, [])])
 def test_large_frames(n, m, L, S, k):
     """More than 512 keypoints per frame (BASELINE.json configs[4]: N=2048, L=9, 200 iterations): windowed full
-    attention, the wide dynamic-attention kernel and the streaming Sinkhorn.  Against the fp64 oracle on the same
-    inputs; dynamic layers may flip a near-tied top-k member (see FLIP_FRAC), full-attention configs may not."""
+    attention, the wide dynamic-attention kernel and the tiled Sinkhorn.  Against the fp64 oracle on the same
+    inputs: 1e-4 on Z and identical matches, for dynamic configurations in the attributed form of parity_util.py."""
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=0)
     net = MDGAT(cfg)
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     data = synth.make_batch(1, n, m, first_pair=1)
-    cap = {}
-    ref = O.mdgat_forward(sd, cfg, data, cap)
-    d = {kk: v.to(DEV) for kk, v in data.items()}
-    m0, m1, s0, s1, Z = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
-                                  d['scores0'], d['scores1'], return_scores=True)
-    err = (Z.cpu().double() - cap['Z']).abs()
-    print('large', n, m, L, S, 'max|dZ|', err.max().item(), 'median', err.median().item())
     if k == []:
+        cap = {}
+        ref = O.mdgat_forward(sd, cfg, data, cap)
+        d = {kk: v.to(DEV) for kk, v in data.items()}
+        m0, m1, s0, s1, Z = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
+                                      d['scores0'], d['scores1'], return_scores=True)
+        err = (Z.cpu().double() - cap['Z']).abs()
+        print('large', n, m, L, S, 'max|dZ|', err.max().item(), 'median', err.median().item())
         assert err.max() < Z_TOL
         assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
     else:
-        assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC and err.max() < FLIP_MAX
-        assert (m0.cpu() != ref['matches0']).double().mean() < FLIP_FRAC
+        assert_attributed(attributed_parity(net, cfg, sd, data, DEV), f'large {n}x{m} L={L} S={S}')
 
 
 @pytest.mark.parametrize('B,n,m,k', [(3, 37, 53, []), (2, 130, 75, []), (5, 20, 44, [8, None]), (1, 1, 9, []), (2, 128, 256, [])])
@@ -310,17 +313,17 @@ def test_ragged_shapes_vs_oracle(B, n, m, k):
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     data = synth.make_batch(B, n, m, first_pair=2)
+    if k != []:
+        assert_attributed(attributed_parity(net, cfg, sd, data, DEV), f'ragged {B}x{n}x{m}')
+        return
     cap = {}
     ref = O.mdgat_forward(sd, cfg, data, cap)
     d = {kk: v.to(DEV) for kk, v in data.items()}
     m0, m1, s0, s1, Z = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
                                   d['scores0'], d['scores1'], return_scores=True)
     err = (Z.cpu().double() - cap['Z']).abs()
-    if k == []:
-        assert err.max() < Z_TOL, err.max()
-        assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
-    else:
-        assert err.median() < 1e-5 and (err > Z_TOL).double().mean() < FLIP_FRAC
+    assert err.max() < Z_TOL, err.max()
+    assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
 
 
 def test_repeatable_bitwise():

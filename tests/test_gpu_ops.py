@@ -127,15 +127,99 @@ def test_attention_topk_golden_and_errors(golden_dir):
         ops.attention(torch.zeros(1, 4200, 3, 4, 32, device=DEV), 2100, 2100, False, topk=8)   # > 2048 keys: dynamic unsupported
 
 
-def test_attention_topk_with_ties():
-    # duplicated keys produce exact ties at the threshold: all tied entries are kept (documented deviation:
-    # torch.topk keeps an arbitrary subset); rows without ties must still match the oracle
-    rs = np.random.RandomState(5)
-    N = M = 64
+@pytest.mark.parametrize('N,k,dups', [(64, 16, 2), (512, 64, 3), (512, 128, 2), (256, 128, 5), (1024, 128, 4), (2048, 64, 3), (100, 30, 2)])
+def test_attention_topk_with_ties(N, k, dups):
+    """Duplicated keys give exactly equal logits.  Where such a group straddles the k-th place `torch.topk` keeps an
+    unspecified subset of it; the kernel keeps EXACTLY k keys too and breaks the tie towards the lowest key indices.
+    Checked through the selection tap: every row holds k keys, the kept members of a tied group are its first ones,
+    and with that selection forced the oracle agrees to 1e-5 on every row (rows whose selection the tie does not touch
+    are the oracle's own)."""
+    rs = np.random.RandomState(5 + N + k)
+    M = N
     qkv = torch.from_numpy(rs.standard_normal((1, N + M, 3, 4, 32)))
-    qkv[:, 10] = qkv[:, 11]   # keys 10 and 11 of frame 0 identical
-    out = ops.attention(qkv.to(DEV), N, M, False, topk=16).cpu().double()
+    group = [10 + 7 * i for i in range(dups)]                 # keys 10, 17, 24, ... of frame 0 identical
+    for g in group[1:]:
+        qkv[:, g, 1:] = qkv[:, group[0], 1:]
+    out, (sel0, sel1) = ops.attention(qkv.to(DEV), N, M, False, topk=k, return_selection=True)
+    # the kernels without the tap find the surplus after the softmax pass and take the dropped key out again (or redo
+    # the pass): the same result as the tap build up to the rounding of that correction
+    assert (out - ops.attention(qkv.to(DEV), N, M, False, topk=k)).abs().max() < 1e-6
+    out = out.cpu().double()
+    sel0, sel1 = sel0.cpu(), sel1.cpu()
     assert torch.isfinite(out).all()
+    assert (sel1.sum(-1) == k).all() and (sel0.sum(-1) == k).all()      # exactly k everywhere
+    kept = sel0[..., group].long()                                       # [1, 4, N, dups]
+    assert (kept[..., :-1] >= kept[..., 1:]).all()                       # a kept member never follows a dropped one
+    partial = (kept.sum(-1) > 0) & (kept.sum(-1) < dups)
+    assert partial.any()                                                 # the straddling case is exercised
+    q = qkv[:, :N, 0].permute(0, 3, 2, 1)
+    kk = qkv[:, :N, 1].permute(0, 3, 2, 1)
+    v = qkv[:, :N, 2].permute(0, 3, 2, 1)
+    rep = []
+    ref, _ = O.dynamic_attention(q, kk, v, k, forced=sel0, report=rep)
+    assert (out[:, :N] - _ref_msg_to_lib(ref)).abs().max() < 1e-5
+    assert rep[0]['bad_count'] == 0 and rep[0]['max_gap'] < 5e-6
+    ref_own, _ = O.dynamic_attention(q, kk, v, k)
+    err = (out[:, :N] - _ref_msg_to_lib(ref_own)).abs().reshape(1, N, 4, 32).amax(3)       # [1, N, H]
+    assert err[(~partial).permute(0, 2, 1)].max() < 1e-5
+
+
+def test_attention_topk_all_keys_equal():
+    """Every logit of a row equal (identical keys): k or more ties AT THE MAXIMUM - the first k keys stay."""
+    rs = np.random.RandomState(2)
+    for N, k in ((64, 16), (512, 64), (1024, 128)):
+        qkv = torch.from_numpy(rs.standard_normal((1, 2 * N, 3, 4, 32)))
+        qkv[:, :, 1] = qkv[:, :1, 1]
+        out, (sel0, sel1) = ops.attention(qkv.to(DEV), N, N, False, topk=k, return_selection=True)
+        assert (out - ops.attention(qkv.to(DEV), N, N, False, topk=k)).abs().max() < 1e-6
+        for sel in (sel0.cpu(), sel1.cpu()):
+            assert (sel.sum(-1) == k).all()
+            assert sel[..., :k].all() and not sel[..., k:].any()
+        v = qkv[:, :N, 2].permute(0, 3, 2, 1)
+        ref = v[..., :k].mean(-1, keepdim=True).expand(-1, -1, -1, N)          # uniform softmax over the first k values
+        assert (out[:, :N].cpu().double() - _ref_msg_to_lib(ref)).abs().max() < 1e-5
+
+
+@pytest.mark.parametrize('n,k', [(512, 64), (512, 128), (2048, 64), (1024, 128), (256, 128), (100, 30)])
+@pytest.mark.parametrize('dist', ['bimodal', 'outliers', 'lognormal', 'cauchy', 'two_clusters_at_k'])
+def test_attention_topk_count_on_hard_distributions(n, k, dist):
+    """The threshold search must end with EXACTLY k kept keys whatever the shape of a logit row (no ties here): sharply
+    bimodal rows, a few huge outliers, heavy tails.  Its density / interpolation steps converge only linearly on such
+    rows; the interleaved ordinal bisection bounds the search (without it the probe cap was hit and nearly
+    all keys were kept).  Checked through the selection tap; the message is compared with the oracle as well."""
+    rs = np.random.RandomState(n + k + len(dist))
+    B = 1
+    if dist == 'bimodal':            # 10 % of the keys near 8 +- 1, the rest near -2 +- 0.05
+        x = np.where(rs.uniform(size=(B, 2 * n)) < 0.1, 8 + rs.standard_normal((B, 2 * n)), -2 + 0.05 * rs.standard_normal((B, 2 * n)))
+    elif dist == 'outliers':
+        x = 0.01 * rs.standard_normal((B, 2 * n))
+        x[:, rs.choice(2 * n, 12, replace=False)] = rs.uniform(-300, 300, 12)
+    elif dist == 'lognormal':
+        x = np.exp(1.5 * rs.standard_normal((B, 2 * n)))
+    elif dist == 'cauchy':
+        x = np.clip(rs.standard_cauchy((B, 2 * n)), -500, 500)
+    else:                            # the k-th place falls inside a tight cluster far from the mean
+        x = np.where(np.arange(2 * n)[None] % n < k - 3, 20 + rs.standard_normal((B, 2 * n)), 1e-3 * rs.standard_normal((B, 2 * n)))
+    qkv = np.zeros((B, 2 * n, 3, 4, 32))
+    qkv[:, :, 2] = rs.standard_normal((B, 2 * n, 4, 32))
+    qkv[:, :, 1, :, 0] = x[:, :, None]                               # key component = the prescribed distribution
+    qkv[:, :, 1, :, 1] = 0.3 * rs.standard_normal((B, 2 * n, 4))      # + a second component so that rows differ
+    qkv[:, :, 0, :, 0] = np.sqrt(32) * rs.uniform(0.5, 2.0, (B, 2 * n, 4)) * np.where(rs.uniform(size=(B, 2 * n, 4)) < 0.2, -1, 1)
+    qkv[:, :, 0, :, 1] = np.sqrt(32) * rs.uniform(-1, 1, (B, 2 * n, 4))
+    qkv = torch.from_numpy(qkv)
+    out, (sel0, sel1) = ops.attention(qkv.to(DEV), n, n, False, topk=k, return_selection=True)
+    cnt = torch.cat([sel0.sum(-1), sel1.sum(-1)], dim=2).cpu()
+    assert (cnt == k).all(), (dist, int(cnt.min()), int(cnt.max()))
+    out = out.cpu().double()
+    for lo, hi, sel in ((0, n, sel0), (n, 2 * n, sel1)):
+        q = qkv[:, lo:hi, 0].permute(0, 3, 2, 1)
+        kk = qkv[:, lo:hi, 1].permute(0, 3, 2, 1)
+        v = qkv[:, lo:hi, 2].permute(0, 3, 2, 1)
+        rep = []
+        ref, _ = O.dynamic_attention(q, kk, v, k, forced=sel.cpu(), report=rep)
+        scale = max(1.0, float(np.abs(x).max()) * 2.5 / 10.0)               # logits up to ~1000 here: fp32 resolution 6e-5
+        assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < 2e-5 * scale
+        assert rep[0]['max_gap'] < 5e-6 * scale and rep[0]['rows'] <= 4, rep[0]
 
 
 @pytest.mark.parametrize('n', [256, 512, 1024])

@@ -1,0 +1,76 @@
+"""Parity numbers at the BASELINE configs with the default dynamic schedule (GPU box):
+    python tools/parity_report.py [pairs_c0 pairs_c1 pairs_c4] > profiles/parity_rN.txt
+
+Per configuration and pair: max|dZ| of the HIP path against the fp64 oracle run with the HIP top-k selections forced,
+whether the matches are identical, the number of dynamic-attention rows whose selection differs from the oracle's own
+top-k and the largest distance of a disagreeing key from the k-th logit (tests/parity_util.py states the bar), then
+the same pair against the PLAIN fp64 oracle (what a flip costs), and - as a yardstick for the arithmetic - the flips
+a plain fp32 PyTorch run of the oracle makes against fp64 on the same pairs."""
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
+from oracle import mdgat_oracle as O  # noqa: E402
+from parity_util import attributed_parity  # noqa: E402
+
+
+def fp32_flips(sd, cfg, data, own64):
+    """selection differences of a plain fp32 PyTorch run (free-running, own trajectory) against the fp64 oracle's"""
+    sd32 = {k: (v.float() if v.is_floating_point() else v) for k, v in sd.items()}
+    d32 = {k: v.float() for k, v in data.items()}
+    cap = {}
+    O.mdgat_forward(sd32, cfg, d32, cap, forced_topk={})
+    rows = 0
+    for i, reps in cap['topk_report'].items():
+        for side in range(2):
+            rows += int((reps[side]['own'] ^ own64[i][side]).any(-1).sum())
+    return rows, cap['Z'].double()
+
+
+def main():
+    torch.set_num_threads(synth.effective_cpu_count())
+    counts = [int(x) for x in sys.argv[1:4]] + [8, 8, 1][len(sys.argv[1:4]):]
+    configs = [('configs[0] N=256 L=4 S=20', 256, 4, 20, counts[0]), ('configs[1] N=512 L=9 S=100', 512, 9, 100, counts[1]),
+               ('configs[4] N=2048 L=9 S=200', 2048, 9, 200, counts[2])]
+    print('# tools/parity_report.py: HIP path vs fp64 oracle, default k schedule [128, None, 128, None, 64, None, 64, None], weights seed 0')
+    for name, n, L, S, pairs in configs:
+        cfg = synth.default_config(L=L, sinkhorn_iterations=S)
+        sd = synth.make_state_dict(L=L, seed=0)
+        net = MDGAT(cfg)
+        net.load_state_dict(sd)
+        net = net.double().eval().to('cuda:0')
+        tot_rows = tot_flip = tot_flip32 = 0
+        worst = worst_gap = worst_plain = worst32 = 0.0
+        all_equal = True
+        t0 = time.time()
+        for p in range(pairs):
+            data = synth.make_batch(1, n, n, first_pair=100 + p)
+            r = attributed_parity(net, cfg, sd, data)
+            cap = {}
+            ref = O.mdgat_forward(sd, cfg, data, cap, forced_topk={})
+            own64 = {i: (rep[0]['own'], rep[1]['own']) for i, rep in cap['topk_report'].items()}
+            plain = (r['out'][4].cpu().double() - cap['Z']).abs().max().item()
+            mm = int((r['out'][0].cpu() != ref['matches0']).sum() + (r['out'][1].cpu() != ref['matches1']).sum())
+            f32rows, Z32 = fp32_flips(sd, cfg, data, own64) if n <= 512 else (-1, None)
+            e32 = (Z32 - cap['Z']).abs().max().item() if Z32 is not None else float('nan')
+            print(f'{name} pair {100 + p}: forced-selection max|dZ| {r["errZ"]:.2e} matches identical {r["matches_equal"]} | '
+                  f'rows differing {r["flip_rows"]}/{r["topk_rows"]} max gap {r["max_gap"]:.2e} kept!=k {r["bad_count"]} | '
+                  f'vs plain fp64 oracle: max|dZ| {plain:.2e}, matches differing {mm} | fp32 PyTorch: rows differing {f32rows}, max|dZ| {e32:.2e}')
+            tot_rows += r['topk_rows']; tot_flip += r['flip_rows']; tot_flip32 += max(f32rows, 0)
+            worst = max(worst, r['errZ']); worst_gap = max(worst_gap, r['max_gap']); worst_plain = max(worst_plain, plain)
+            worst32 = max(worst32, e32 if e32 == e32 else 0.0)
+            all_equal &= r['matches_equal']
+            sys.stdout.flush()
+        print(f'== {name}: {pairs} pairs, {time.time() - t0:.0f} s: worst forced-selection max|dZ| {worst:.2e} (bar 1e-4), matches identical: {all_equal}, '
+              f'top-k rows differing {tot_flip} of {tot_rows} ({tot_flip / max(tot_rows, 1):.2e}), worst gap {worst_gap:.2e}; '
+              f'plain fp64 comparison worst max|dZ| {worst_plain:.2e}; fp32 PyTorch rows differing {tot_flip32}, worst max|dZ| {worst32:.2e}')
+
+
+if __name__ == '__main__':
+    main()
