@@ -60,6 +60,7 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
+    unsigned* host_error; // host-mapped word the Sinkhorn kernel sets when a partner workgroup never arrived (checked on the next call)
     // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream
     bool prof_on;
     std::vector<hipEvent_t> prof_ev;
@@ -96,6 +97,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights = nullptr;
     h->wsplit = nullptr;
     h->loaded = false;
+    h->host_error = nullptr;
     h->prof_on = false;
     for (int c = 0; c < MDGAT_PROF_CLASSES; ++c) { h->prof_ms[c] = 0.0; h->prof_launches[c] = 0; }
     int prev = 0;
@@ -104,8 +106,16 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMalloc(split weights)");
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMemset(split weights)");
+    if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(error word)");
+    if (!rc) *h->host_error = 0;
     (void)hipSetDevice(prev);
-    if (rc) { if (h->weights) (void)hipFree(h->weights); delete h; return rc; }
+    if (rc) {
+        if (h->weights) (void)hipFree(h->weights);
+        if (h->wsplit) (void)hipFree(h->wsplit);
+        if (h->host_error) (void)hipHostFree(h->host_error);
+        delete h;
+        return rc;
+    }
     *out = h;
     return MDGAT_OK;
 }
@@ -156,6 +166,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (!h) return;
     if (h->weights) (void)hipFree(h->weights);
     if (h->wsplit) (void)hipFree(h->wsplit);
+    if (h->host_error) (void)hipHostFree(h->host_error);
     for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
     delete h;
 }
@@ -210,6 +221,13 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
                         const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
+    if (*static_cast<volatile unsigned*>(h->host_error)) {
+        // the forward is asynchronous: a failure inside an earlier launch surfaces here (that call's outputs were poisoned:
+        // no matches, NaN scores / NaN in Z)
+        *h->host_error = 0;
+        mdgat_set_error("mdgat_forward: a previous call on this handle failed on the device (Sinkhorn: a partner workgroup never arrived); its outputs are invalid");
+        return MDGAT_ERR_HIP;
+    }
     if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
     const bool arrays = kpts0 && sigma0 && fpfh0 && kpts1 && sigma1 && fpfh1;
     if ((!arrays && !(rec0 && rec1)) || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
@@ -307,10 +325,12 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
 
     // ---- optimal transport (mdgat.py:434-436) and match extraction (441-483) ----
     // (Z is only materialised when the caller asks for it or the streaming Sinkhorn needs it for the extraction)
-    const bool fused = ws.sk_bytes != 0;   // N, M <= 512: the cluster kernel, arg-maxes fused
+    const bool fused = ws.sk_bytes != 0;   // N, M <= 2048: the cluster kernel, arg-maxes fused
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
     const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1};
-    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s))) return rc;
+    unsigned* host_error_dev = nullptr;
+    if ((rc = mdgat_check_hip(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_error_dev), h->host_error, 0), "hipHostGetDevicePointer"))) return rc;
+    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, host_error_dev))) return rc;
     mark(MDGAT_PROF_SINKHORN);
     if (h->prof_on && prof_n > 1) {
         if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;

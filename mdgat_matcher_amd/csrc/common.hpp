@@ -133,8 +133,9 @@ struct SkExtract {   // match extraction to run after (or fused into) the Sinkho
     int64_t *m0, *m1;
     float *s0, *s1;
 };
+// host_error (optional, host-mapped memory): set to 1 when a workgroup of the cluster kernel lost a partner (bounded spin)
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s);
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* host_error = nullptr);
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,

@@ -1,5 +1,5 @@
-// Register-resident GEMM chain on the f16 matrix cores (layer.hip, encoder.hip): split-f16 operands, a wave owns
-// 32 keypoints, products computed "swapped" so that the output fragment is the next product's B operand.
+// Register-resident GEMM chain on the f16 matrix cores (layer.hip: a wave owns 16 keypoints, 16x16x32 MFMAs;
+// encoder.hip: 32 keypoints, 32x32x16): split-f16 operands, products computed "swapped" so that the output fragment is the next product's B operand.
 #pragma once
 #include "common.hpp"
 

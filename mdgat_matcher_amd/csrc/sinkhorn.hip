@@ -256,6 +256,7 @@ struct SksArgs {
     float* Z;
     unsigned long long* slots;   // per group: column slots [2][GC][GR][SLOT_STRIDE], then row slots [2][GR][GC][ROW_STRIDE]; zeroed per launch
     unsigned* error_word;
+    unsigned* host_error;        // optional, host-mapped: set together with error_word so that the owner of a handle learns of it
     int B, N, M, iters, ngroups, GR, GC;
     // fused arg-max of the match extraction (mdgat.py:441-483): per row over this workgroup's columns, per column over
     // its rows (merged later); ext_mode < 0: off.  Z may be NULL when only the matches are wanted.
@@ -631,8 +632,9 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
-        const float poison = (P > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-                                 ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
+        const bool partner_lost = P > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const float poison = partner_lost ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
+        if (partner_lost && a.host_error && tid == 0) __hip_atomic_store(a.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
         const float VM = ran ? v0M + lg2(bM) + poison : 0.f;
         const float Ur = (ran && my_row_valid) ? u0r + lg2(ar) : 0.f;    // lane r: potential of row r
@@ -732,7 +734,7 @@ struct ExArgs {
     float thr;
     int64_t* m0; int64_t* m1;
     float* s0; float* s1;
-    int* valid_count;   // global count of valid frame-0 rows (dustbin modes; mdgat.py:465 quirk)
+    const unsigned* sk_error;   // optional: error word of the Sinkhorn kernel that produced the arg-maxes (a lost partner)
     // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
     // per row slab [B][GR][M])
     const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int GR, GC;
@@ -747,11 +749,17 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     int* idx1 = idx0 + N;                       // [M]
     float* val0 = reinterpret_cast<float*>(idx1 + M);   // [N]
     float* val1 = val0 + N;                     // [M]
-    int* nvalid = reinterpret_cast<int*>(val1 + M);
     const bool inner = a.mode >= MDGAT_EXTRACT_THRESHOLD;   // arg-max over the inner N x M block only
     const int ncol = inner ? M : M + 1;   // columns scanned per row
     const int nrow = inner ? N : N + 1;   // rows scanned per column
-    if (tid == 0) *nvalid = 0;
+    if (a.sk_error && *a.sk_error) {
+        // the Sinkhorn kernel lost a partner workgroup (bounded spin ran out): its potentials are garbage.  Z is poisoned
+        // with NaN there; without Z the failure must be just as loud: no matches, NaN scores (and the handle reports
+        // MDGAT_ERR_HIP on its next call)
+        for (int i = tid; i < N; i += 1024) { a.m0[(size_t)blockIdx.x * N + i] = -1; a.s0[(size_t)blockIdx.x * N + i] = __builtin_nanf(""); }
+        for (int j = tid; j < M; j += 1024) { a.m1[(size_t)blockIdx.x * M + j] = -1; a.s1[(size_t)blockIdx.x * M + j] = __builtin_nanf(""); }
+        return;
+    }
 
     if (!a.Z) {
         for (int i = tid; i < N; i += 1024) {
@@ -812,14 +820,12 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
 
     if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
         const bool mutual = a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL;
-        int local = 0;
         for (int i = tid; i < N; i += 1024) {
             const int j = idx0[i];
             const bool valid = j < M;
             const bool keep = valid && (!mutual || idx1[j] == i);
             m0[i] = valid ? j : -1;
             s0[i] = keep ? expf(val0[i]) : 0.f;
-            local += valid ? 1 : 0;
         }
         for (int j = tid; j < M; j += 1024) {
             const int i = idx1[j];
@@ -828,9 +834,6 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             m1[j] = valid ? i : -1;
             s1[j] = keep ? expf(val1[j]) : 0.f;
         }
-        if (local) atomicAdd(nvalid, local);
-        __syncthreads();
-        if (tid == 0 && *nvalid) atomicAdd(a.valid_count, *nvalid);
     } else if (a.mode == MDGAT_EXTRACT_THRESHOLD) {
         for (int i = tid; i < N; i += 1024) {
             const float e = expf(val0[i]);
@@ -865,13 +868,16 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     }
 }
 
-// mdgat.py:465-467: when NO frame-0 keypoint of the whole batch is matched, both score vectors are zeros
-__global__ void extract_alldust_fixup(const int* valid_count, float* s1, size_t n) {
-    if (*valid_count != 0) return;
-    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s1[i] = 0.f;
+// mdgat.py:465-467: when NO frame-0 keypoint of the whole batch is matched (valid0.sum() == 0), both score vectors are
+// zeros.  matches0 >= 0 <=> valid0 in both dustbin modes, so the written matches are scanned (no counter shared between
+// launches): every workgroup stops at the first chunk that holds a match - the first one on real data.
+__global__ __launch_bounds__(256) void extract_alldust_fixup(const int64_t* m0, size_t n0, float* s1, size_t n1) {
+    for (size_t base = 0; base < n0; base += 256) {
+        const size_t i = base + threadIdx.x;
+        if (__syncthreads_or(i < n0 && m0[i] >= 0)) return;
+    }
+    for (size_t i = blockIdx.x * (size_t)256 + threadIdx.x; i < n1; i += (size_t)gridDim.x * 256) s1[i] = 0.f;
 }
-
-int* g_valid_count[16] = {nullptr};
 
 template <int NC, int NW>
 int launch_sk(const SkArgs& a, int B, hipStream_t s) {
@@ -910,7 +916,7 @@ size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
 static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s);
 
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
-                          float* Z, void* ws, int num_cu, const SkExtract* ex, hipStream_t s) {
+                          float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* host_error, hipStream_t s) {
     constexpr int RPW = 16;
     int GR, GC;
     sk_tiling(N, M, GR, GC);
@@ -923,7 +929,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
     if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), B, N, M, iters, ngroups, GR, GC, -1, nullptr, nullptr, nullptr, nullptr};
+              static_cast<unsigned*>(ws), host_error, B, N, M, iters, ngroups, GR, GC, -1, nullptr, nullptr, nullptr, nullptr};
     if (ex) {
         char* p = static_cast<char*>(ws) + slots_bytes(N, M);
         a.ext_mode = ex->mode;
@@ -940,7 +946,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     hipError_t e = hipLaunchCooperativeKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
     if (ex) {
-        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr,
+        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, a.error_word,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s);
     }
@@ -952,7 +958,7 @@ size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_clust
 // ex != NULL: also extract the matches.  With the cluster kernel the arg-maxes are fused into its epilogue and Z may
 // be NULL; otherwise Z must be given and is scanned by the extraction kernel.
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s) {
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* host_error) {
     if (B <= 0) return MDGAT_OK;
     if (!Z && !ex) { mdgat_set_error("sinkhorn: nothing to compute (no Z, no extraction)"); return MDGAT_ERR_BAD_ARG; }
     if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("sinkhorn: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
@@ -961,7 +967,7 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, s);
+        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, host_error, s);
     }
     if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
     // streaming kernel: any shape up to M = 2048, no workspace
@@ -983,21 +989,13 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
 
 static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s) {
     if (a.mode < 0 || a.mode > 3) { mdgat_set_error("extract: bad mode %d", a.mode); return MDGAT_ERR_BAD_ARG; }
-    int dev = 0;
-    if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
-    if (dev >= 16) { mdgat_set_error("extract: device index %d >= 16", dev); return MDGAT_ERR_UNSUPPORTED; }
-    if (!g_valid_count[dev]) {
-        if (int rc = mdgat_check_hip(hipMalloc(&g_valid_count[dev], sizeof(int)), "hipMalloc(valid_count)")) return rc;
-    }
-    if (int rc = mdgat_check_hip(hipMemsetAsync(g_valid_count[dev], 0, sizeof(int), s), "memset(valid_count)")) return rc;
-    a.valid_count = g_valid_count[dev];
     const size_t lds = (size_t)(2 * (N + M) + 4) * sizeof(float);
     hipLaunchKernelGGL(extract_kernel, dim3(B), dim3(1024), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "extract launch")) return rc;
     if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
         const size_t n = (size_t)B * M;
-        hipLaunchKernelGGL(extract_alldust_fixup, dim3((unsigned)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024)), dim3(256), 0, s,
-                           g_valid_count[dev], a.s1, n);
+        hipLaunchKernelGGL(extract_alldust_fixup, dim3((unsigned)((n + 255) / 256 < 16 ? (n + 255) / 256 : 16)), dim3(256), 0, s,
+                           a.m0, (size_t)B * N, a.s1, n);
         return mdgat_check_hip(hipGetLastError(), "extract fixup launch");
     }
     return MDGAT_OK;

@@ -136,8 +136,15 @@ class MDGAT(nn.Module):
         self.register_parameter('bin_score', nn.Parameter(torch.tensor(1.)))
         # shared (by reference) with DataParallel replicas: device index -> _DeviceState
         self._states: Dict[int, _DeviceState] = {}
-        self._states_lock = threading.Lock()
-        self._sig_holder = [None]
+        self._states_lock = threading.RLock()
+        # Also shared with the replicas (lists, so that a replica's shallow __dict__ copy sees later updates):
+        # [0] the packed fp32 host blob of the owner's parameters.  torch.nn.parallel.replicate() strips the parameters
+        #     off the replicas (they become plain attributes; state_dict() of a replica holds only buffers), so a
+        #     replica cannot pack - the owner packs in _replicate_for_data_parallel(), before the replicas run;
+        # [1] True while a blob installed by load_packed() (e.g. received by an RCCL broadcast) stands in for this
+        #     module's own parameters: casts / moves of the module must not throw it away.
+        self._blob_holder = [None, False]
+        self._sig_holder = [self._signature()]
         # replicas never run __init__, so only the original module owns (and finally frees) the handles
         weakref.finalize(self, _close_states, self._states)
 
@@ -147,6 +154,8 @@ class MDGAT(nn.Module):
             for st in self._states.values():
                 st.close()
             self._states.clear()
+            self._blob_holder[0] = None
+            self._blob_holder[1] = False
 
     def _signature(self):
         ts = list(self.parameters()) + list(self.buffers())
@@ -158,6 +167,10 @@ class MDGAT(nn.Module):
         sig = self._signature()
         if sig != self._sig_holder[0]:
             self._sig_holder[0] = sig
+            if self._blob_holder[1]:
+                # the weights in use were installed by load_packed(): this module's own parameters (random init on
+                # every rank but the broadcasting one) are not what runs, so moving / casting them changes nothing
+                return
             self._invalidate()
 
     def _apply(self, fn, *a, **k):
@@ -168,12 +181,21 @@ class MDGAT(nn.Module):
 
     def load_state_dict(self, state_dict, *a, **k):
         out = super().load_state_dict(state_dict, *a, **k)
-        self._invalidate_if_changed()
+        self._sig_holder[0] = self._signature()
+        self._invalidate()          # new parameters: they replace whatever ran before, a load_packed() blob included
         return out
 
     def repack(self):
-        """Call after modifying parameters in place (nothing else tracks in-place edits)."""
+        """Call after modifying parameters in place (nothing else tracks in-place edits); also ends the reign of a
+        blob installed by load_packed()."""
         self._invalidate()
+
+    def _replicate_for_data_parallel(self):
+        # torch.nn.DataParallel (test.py:158) calls this on the owner, in the caller's thread, before every forward
+        # with more than one device: pack here, where the parameters still are parameters
+        if not self._blob_holder[1]:
+            self._host_blob()
+        return super()._replicate_for_data_parallel()
 
     # ------------------------------------------------------------------ library state
     def _extract_mode(self):
@@ -187,6 +209,16 @@ class MDGAT(nn.Module):
     def packed_weights(self):
         """fp32 blob (numpy) of the current parameters in the library's layout."""
         return pack.pack_state_dict(self.state_dict(), self.config['L'])
+
+    def _host_blob(self):
+        """The packed blob, made once per set of parameters and shared with DataParallel replicas."""
+        with self._states_lock:
+            if self._blob_holder[0] is None:
+                if 'bin_score' not in self._parameters:
+                    raise RuntimeError('this MDGAT is a DataParallel replica without packed weights: the owner module '
+                                       'packs them in _replicate_for_data_parallel() - was replicate() bypassed?')
+                self._blob_holder[0] = self.packed_weights()
+            return self._blob_holder[0]
 
     def _state_for(self, device: torch.device, blob_device_tensor: Optional[torch.Tensor] = None) -> _DeviceState:
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -214,7 +246,7 @@ class MDGAT(nn.Module):
                     _lib.check(lib.mdgat_load_weights(handle, C.c_void_p(blob_device_tensor.data_ptr()), n, 1),
                                'mdgat_load_weights')
                 else:
-                    blob = self.packed_weights()
+                    blob = self._host_blob()
                     assert blob.size == lib.mdgat_blob_floats(L), (blob.size, lib.mdgat_blob_floats(L))
                     _lib.check(lib.mdgat_load_weights(handle, blob.ctypes.data_as(C.c_void_p), blob.size, 0),
                                'mdgat_load_weights')
@@ -231,9 +263,12 @@ class MDGAT(nn.Module):
         idx = blob.device.index
         with self._states_lock:
             old = self._states.pop(idx, None)
-        if old is not None:
-            old.close()
-        return self._state_for(blob.device, blob)
+            if old is not None:
+                old.close()
+            self._blob_holder[0] = None
+            self._blob_holder[1] = True     # stands until load_state_dict() / repack(): see _invalidate_if_changed
+            self._sig_holder[0] = self._signature()
+            return self._state_for(blob.device, blob)
 
     # ------------------------------------------------------------------ forward
     def forward(self, data):

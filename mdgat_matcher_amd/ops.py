@@ -24,8 +24,8 @@ def _need_cuda(*ts):
 def sinkhorn(scores: torch.Tensor, bin_score: float, iters: int, streaming: bool = False) -> torch.Tensor:
     """log_optimal_transport (mdgat.py:288-308): scores [B, N, M] -> Z [B, N+1, M+1] (fp32).
 
-    N, M <= 512 run on the register-resident cluster kernel (needs a small workspace, allocated here);
-    larger shapes, or ``streaming=True``, use the one-workgroup-per-pair streaming kernel."""
+    N, M <= 2048 run on the register-resident cluster kernel (128 x 512 tiles per workgroup; needs a small workspace,
+    allocated here); ``streaming=True`` selects the one-workgroup-per-pair streaming kernel."""
     _need_cuda(scores)
     s = scores.to(torch.float32).contiguous()
     B, N, M = s.shape

@@ -9,6 +9,8 @@ Parity pin: the reference publishes no tests or golden vectors for this path (SU
 so the oracle is pinned against *outputs of the reference itself*: ``tools/make_goldens.py``
 imports ``/root/reference/models/mdgat.py`` in the build container, runs it in fp64 on seeded
 synthetic weights/inputs and commits the stage tensors under ``tests/golden/``;
+``tools/make_goldens_aux.py`` does the same for the steps either side of the matcher
+(``utils/utils_test.py``: solve_icp / calculate_error; ``load_data.py``: SparseDataset.__getitem__).
 ``tests/test_oracle_golden.py`` checks every function below against those fixtures.
 
 Every function cites the reference lines it restates.  The state dict uses the reference's
@@ -337,6 +339,17 @@ def pose_from_matches(kpts0, kpts1, matches0, T_gt=None, inlier_dist=1.0):
         with np.errstate(invalid='ignore'):
             re = float(np.arccos((E[0, 0] + E[1, 1] + E[2, 2] - 1) * 0.5))
     return T, int(valid.sum()), inl, inl / max(int(valid.sum()), 1), te, re
+
+
+def frame_transforms(pose0, pose1, T_cam0_velo):
+    """load_data.py:231-239 for one pair of frames: the sensor->world transform of each frame (pose . T_cam0_velo, the
+    einsum at 238-239) and T_gt = inv(T_cam0_velo) inv(pose0) pose1 T_cam0_velo (235), which maps frame-1 points onto
+    frame 0.  poses are the 4x4 camera-0 poses of KITTI/poses/NN.txt, T_cam0_velo the `Tr` row of calib.txt.
+    Returns (T0, T1, T_gt) as float64 arrays."""
+    import numpy as np
+    p0, p1, tcv = (np.asarray(x, dtype=np.float64) for x in (pose0, pose1, T_cam0_velo))
+    T_gt = np.linalg.inv(tcv) @ np.linalg.inv(p0) @ p1 @ tcv
+    return p0 @ tcv, p1 @ tcv, T_gt
 
 
 def gt_matches(kp0, kp1, T0=None, T1=None, threshold=0.5, mutual=False):

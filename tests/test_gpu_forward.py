@@ -370,3 +370,69 @@ def test_match_frames_raw_records():
     # and the array entry point agrees with the record entry point on pre-decoded inputs
     m0b = net.match(k0.to(DEV), d0.to(DEV), k1.to(DEV), d1.to(DEV), s0.to(DEV), s1.to(DEV))[0]
     assert torch.equal(m0b, m0)
+
+
+def test_match_frames_vs_reference_loader_outputs(golden_dir):
+    """The record decode fused into the encoder kernel against the REFERENCE loader's outputs (tests/golden/aux_loader.npz:
+    SparseDataset.__getitem__, load_data.py:146-169 and 290-295): matching the raw 37-float records must give the same
+    result as matching the keypoints / saliency / normalised descriptors the reference's loader made of them."""
+    g = np.load(os.path.join(golden_dir, 'aux_loader.npz'))
+    L = 2
+    cfg = synth.default_config(L=L, k=[32, None, 16, None], sinkhorn_iterations=20)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=L, seed=4))
+    net = net.double().eval().to(DEV)
+    for j in range(int(g['n_items'])):
+        r0 = torch.from_numpy(g[f'item{j}_rec0']).to(DEV)
+        r1 = torch.from_numpy(g[f'item{j}_rec1']).to(DEV)
+        a = net.match_frames(r0, r1, return_scores=True)
+        t = {k: torch.from_numpy(g[f'item{j}_{k}']).to(DEV) for k in ('keypoints0', 'keypoints1', 'descriptors0', 'descriptors1',
+                                                                         'scores0', 'scores1')}
+        b = net.match(t['keypoints0'], t['descriptors0'], t['keypoints1'], t['descriptors1'], t['scores0'], t['scores1'],
+                      return_scores=True)
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        assert (a[4] - b[4]).abs().max() < 1e-5      # (the kernel normalises in fp32 with its own summation order)
+
+
+def test_replicas_made_by_torch_replicate(golden_dir):
+    """torch.nn.parallel.replicate() - what DataParallel.forward runs whenever it has more than one device (test.py:158,
+    train.py:192-196) - strips the parameters off the replicas; the replica must run on the blob its owner packed."""
+    g = _g(golden_dir, 'fwd_n64_L4_S20')
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    net = MDGAT(synth.default_config(L=L, k=k, sinkhorn_iterations=S))
+    net.load_state_dict(synth.make_state_dict(L=L, seed=seed))
+    net = net.double().eval().to(DEV)
+    data = synth.make_batch(B, n, m, first_pair=first_pair, device=DEV)
+    for _ in range(2):                                  # DataParallel replicates before every forward
+        replica = torch.nn.parallel.replicate(net, [0])[0]
+        assert 'bin_score' not in replica._parameters
+        with torch.no_grad():
+            out = replica(data)
+        np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g['default_matches0'])
+        np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g['default_matches1'])
+    assert len(net._states) == 1                        # one handle per device, shared by owner and replicas
+
+
+def test_load_packed_blob_on_device():
+    """The multi-rank weight path (shard.broadcast_weights -> load_packed -> mdgat_load_weights(on_device=1)): a rank
+    whose own parameters are random init runs the broadcast blob, bit-identically to the rank that packed it, also
+    after the net.double().eval() of test.py:193."""
+    L = 3
+    cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=30)
+    src = MDGAT(cfg)
+    src.load_state_dict(synth.make_state_dict(L=L, seed=7))
+    src = src.eval().to(DEV)
+    d = synth.make_batch(3, 200, 256, device=DEV, dtype=torch.float32)
+    args = (d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1'])
+    ref = src.match(*args, return_scores=True)
+    blob = torch.from_numpy(src.packed_weights()).to(DEV)
+    other = MDGAT(cfg).eval().to(DEV)                   # random init: NOT the weights that must run
+    other.load_packed(blob)
+    for cast in (lambda x: x, lambda x: x.double().eval(), lambda x: x.float(), lambda x: x.to(DEV)):
+        other = cast(other)
+        out = other.match(*args, return_scores=True)
+        for a, b in zip(ref, out):
+            assert torch.equal(a, b)
+    other.repack()                                      # back to its own (random) parameters
+    assert not torch.equal(other.match(*args, return_scores=True)[4], ref[4])

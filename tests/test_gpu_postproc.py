@@ -1,5 +1,8 @@
-"""GPU parity of the steps either side of the matcher against the oracle's restatement of
-utils/utils_test.py (pose from matches) and load_data.py (ground-truth matches).  fp64 on both sides."""
+"""GPU parity of the steps either side of the matcher: against OUTPUTS OF THE REFERENCE
+(tests/golden/aux_*.npz, produced by tools/make_goldens_aux.py from utils/utils_test.py and load_data.py) and, at more
+shapes, against the oracle's restatement, which test_oracle_golden.py pins to the same fixtures.  fp64 on both sides."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -85,3 +88,46 @@ def test_gt_matches(N, M, mutual):
     g0, g1, rep = ops.gt_matches(torch.from_numpy(k0).to(DEV), torch.from_numpy(k1).to(DEV), threshold=5.0, mutual=mutual)
     r0, r1, rr = O.gt_matches(k0[0], k1[0], None, None, 5.0, mutual)
     np.testing.assert_array_equal(g0[0].cpu().numpy(), r0)
+
+
+
+def _aux(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+def test_pose_vs_reference_outputs(golden_dir):
+    """solve_icp + calculate_error of the reference (utils_test.py:41-110) on its own outputs.  The rank-deficient sets
+    ('three', 'planar': the sign of the null singular vector is the SVD routine's choice) are checked for what is
+    defined there - T maps the matched points onto each other - and the others entry by entry."""
+    g = _aux(golden_dir, 'aux_pose')
+    for name in g['names']:
+        mk0, mk1, T_gt, st = g[f'{name}_mkpts0'], g[f'{name}_mkpts1'], g[f'{name}_T_gt'], g[f'{name}_stats']
+        n = len(mk0)
+        T, out = ops.pose_from_matches(torch.from_numpy(mk0[None]).to(DEV), torch.from_numpy(mk1[None]).to(DEV),
+                                       torch.arange(n, device=DEV)[None], T_gt=torch.from_numpy(T_gt[None]).to(DEV))
+        T, out = T[0].cpu().numpy(), out[0].cpu().numpy()
+        assert out[0] == st[0]
+        if name in ('three', 'planar'):
+            res = (T[:3, :3] @ mk1.T).T + T[:3, 3] - mk0
+            ref = (g[f'{name}_T'][:3, :3] @ mk1.T).T + g[f'{name}_T'][:3, 3] - mk0
+            assert np.abs(res).max() <= np.abs(ref).max() + 1e-5, name
+            continue
+        assert np.abs(T - g[f'{name}_T']).max() < 1e-9, name
+        assert out[1] == st[1] and abs(out[2] - st[2]) < 1e-12, name
+        assert abs(out[3] - st[3]) < 1e-9 and abs(out[4] - st[4]) < 1e-7, name
+
+
+@pytest.mark.parametrize('mutual', [False, True])
+def test_gt_matches_vs_reference_outputs(golden_dir, mutual):
+    """The loader's ground-truth matcher (load_data.py:238-285) on the reference's own outputs."""
+    g = _aux(golden_dir, 'aux_loader')
+    for j in range(int(g['n_items'])):
+        tag = f'item{j}_' + ('mutual_' if mutual else '')
+        T0, T1, _ = O.frame_transforms(g[f'item{j}_pose0'], g[f'item{j}_pose1'], g['T_cam0_velo'])
+        k0 = torch.from_numpy(g[tag + 'keypoints0'][None]).to(DEV)
+        k1 = torch.from_numpy(g[tag + 'keypoints1'][None]).to(DEV)
+        g0, g1, rep = ops.gt_matches(k0, k1, torch.from_numpy(T0[None]).to(DEV), torch.from_numpy(T1[None]).to(DEV),
+                                     threshold=float(g['threshold']), mutual=mutual)
+        np.testing.assert_array_equal(g0[0].cpu().numpy(), g[tag + 'gt_matches0'].astype(np.int64))
+        np.testing.assert_array_equal(g1[0].cpu().numpy(), g[tag + 'gt_matches1'].astype(np.int64))
+        assert int(rep[0]) == int(g[tag + 'rep'])

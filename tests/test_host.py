@@ -185,3 +185,78 @@ def test_oracle_postproc_restatements():
     for mutual in (False, True):
         m0, m1, rep = O.gt_matches(P, P[perm], threshold=0.5, mutual=mutual)
         assert rep == 40 and (P[perm][m0] == P).all() and (m1 == perm).all()
+
+
+def _emulate_replicate(net):
+    """What torch.nn.parallel.replicate() does to a module tree, minus the device broadcast (which needs GPUs): every
+    module is shallow-copied by _replicate_for_data_parallel(), the copies are re-wired, and parameters become plain
+    tensor attributes of the copies (replicate.py: 'parameters in replicas are no longer leaves')."""
+    mods = list(net.modules())
+    idx = {m: i for i, m in enumerate(mods)}
+    copies = [m._replicate_for_data_parallel() for m in mods]
+    for m, c in zip(mods, copies):
+        for key, child in m._modules.items():
+            c._modules[key] = None if child is None else copies[idx[child]]
+        for key, param in m._parameters.items():
+            if param is not None:
+                setattr(c, key, param.detach().clone())
+    return copies[0]
+
+
+def test_dataparallel_replica_uses_the_owners_packed_weights():
+    """DataParallel with more than one device replicates the module; replicas have no parameters
+    (state_dict() holds buffers only), so a replica must not pack - the owner packs when it is replicated and the
+    replicas share that blob."""
+    L = 2
+    net = MDGAT(synth.default_config(L=L, k=[]))
+    net.load_state_dict(synth.make_state_dict(L=L, seed=3))
+    net = net.double().eval()
+    ref = net.packed_weights()
+    rep = _emulate_replicate(net)
+    assert 'bin_score' not in rep._parameters and len(rep.state_dict()) < len(net.state_dict())
+    with pytest.raises(KeyError):
+        rep.packed_weights()                       # what the round-1 code did on the replica
+    np.testing.assert_array_equal(rep._host_blob(), ref)
+    assert rep._states is net._states and rep._blob_holder is net._blob_holder
+    # new parameters on the owner invalidate the shared blob; the next replication packs the new ones
+    net.load_state_dict(synth.make_state_dict(L=L, seed=4))
+    assert net._blob_holder[0] is None
+    rep2 = _emulate_replicate(net)
+    np.testing.assert_array_equal(rep2._host_blob(), net.packed_weights())
+    assert not np.array_equal(rep2._host_blob(), ref)
+    # a replica made behind the owner's back says what is wrong instead of a KeyError from the packer
+    net._invalidate()
+    orphan = MDGAT._replicate_for_data_parallel.__wrapped__(net) if hasattr(MDGAT._replicate_for_data_parallel, '__wrapped__') \
+        else torch.nn.Module._replicate_for_data_parallel(net)
+    orphan._parameters = {}
+    with pytest.raises(RuntimeError, match='replica'):
+        orphan._host_blob()
+
+
+def test_load_packed_state_survives_casts():
+    """a device state installed by load_packed() (weights received by the RCCL broadcast) must
+    survive net.double() / .to() / .float() - test.py:193 calls net.double().eval() before every forward - and end
+    with load_state_dict() or repack()."""
+    class _State:
+        closed = False
+        def close(self):
+            self.closed = True
+    L = 1
+    net = MDGAT(synth.default_config(L=L, k=[]))
+    st = _State()
+    net._states[0] = st
+    net._blob_holder[1] = True                    # what load_packed() records
+    net.double()
+    net.float()
+    net.double().eval()
+    assert net._states.get(0) is st and not st.closed
+    net.load_state_dict(synth.make_state_dict(L=L, seed=1))
+    assert st.closed and not net._states and net._blob_holder[1] is False
+    # without load_packed a real change of the parameters does invalidate, a no-op cast does not
+    st2 = _State()
+    net._states[0] = st2
+    net.double()
+    net.double().eval()
+    assert net._states.get(0) is st2 and not st2.closed
+    net.float()
+    assert st2.closed and not net._states

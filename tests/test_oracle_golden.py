@@ -156,3 +156,40 @@ def test_edge_cases(golden_dir):
     np.testing.assert_array_equal(out['matches1'].numpy(), g['alldust_matches1'])
     assert (out['matches0'] == -1).all()
     np.testing.assert_array_equal(out['matching_scores0'].numpy(), g['alldust_mscores0'])
+
+
+# ---------------------------------------------------------------- steps either side of the matcher
+# fixtures: tools/make_goldens_aux.py (the reference's utils/utils_test.py and load_data.py, imported unmodified)
+def test_pose_from_matches_vs_reference(golden_dir):
+    g = _load(golden_dir, 'aux_pose')
+    for name in g['names']:
+        mk0, mk1, T_gt = g[f'{name}_mkpts0'], g[f'{name}_mkpts1'], g[f'{name}_T_gt']
+        T = O.solve_icp(mk1, mk0)                                   # utils_test.py:73-110
+        np.testing.assert_allclose(T, g[f'{name}_T'], atol=1e-12, err_msg=str(name))
+        n = len(mk0)
+        # calculate_error (utils_test.py:41-71) through the (kpts, matches) form test.py:213-216 feeds it
+        Tr, cnt, inl, ratio, te, re = O.pose_from_matches(mk0, mk1, np.arange(n), T_gt, inlier_dist=1.0)
+        st = g[f'{name}_stats']
+        np.testing.assert_allclose(Tr, g[f'{name}_T'], atol=1e-12)
+        assert cnt == st[0] and inl == st[1] and abs(ratio - st[2]) < 1e-15, name
+        assert abs(te - st[3]) < 1e-9 * max(1.0, st[3]), name
+        assert (np.isnan(re) and np.isnan(st[4])) or abs(re - st[4]) < 1e-9, name
+    assert np.linalg.det(g['reflection_T'][:3, :3]) < 0             # the reference has no det(R) fix: mirrored
+
+
+@pytest.mark.parametrize('mutual', [False, True])
+def test_loader_vs_reference(golden_dir, mutual):
+    g = _load(golden_dir, 'aux_loader')
+    for j in range(int(g['n_items'])):
+        tag = f'item{j}_' + ('mutual_' if mutual else '')
+        for side in (0, 1):
+            kp, score, desc = O.decode_frames(g[f'item{j}_rec{side}'][None])       # load_data.py:146-169, 290-295
+            np.testing.assert_array_equal(kp[0].numpy(), g[tag + f'keypoints{side}'])
+            np.testing.assert_array_equal(score[0].numpy(), g[tag + f'scores{side}'])
+            np.testing.assert_array_equal(desc[0].numpy(), g[tag + f'descriptors{side}'])
+        T0, T1, T_gt = O.frame_transforms(g[f'item{j}_pose0'], g[f'item{j}_pose1'], g['T_cam0_velo'])
+        np.testing.assert_allclose(T_gt, g[tag + 'T_gt'], atol=1e-9)
+        m0, m1, rep = O.gt_matches(g[tag + 'keypoints0'], g[tag + 'keypoints1'], T0, T1, float(g['threshold']), mutual)
+        np.testing.assert_array_equal(m0, g[tag + 'gt_matches0'].astype(np.int64))         # load_data.py:257-285
+        np.testing.assert_array_equal(m1, g[tag + 'gt_matches1'].astype(np.int64))
+        assert rep == int(g[tag + 'rep']) and rep > 10
