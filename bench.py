@@ -10,10 +10,15 @@ over one batch of synthetic frame pairs already resident in HBM.  Workload at ev
 configs[1] per GPU (batch=64 pairs, 512 keypoints per frame, L=9, 100 Sinkhorn iterations, fp32); with
 --gpus N every rank owns its own 64 pairs (weak scaling; pairs are independent, no data-path collective -
 the only collective is the one-time RCCL broadcast of the packed weights from rank 0).
+`--config {0,2,3,4}` runs another BASELINE.json configuration instead (never the headline; configs[3] = the
+8-way sharded 4096 pairs is `--gpus 8 --config 3`, 512 pairs per GPU).
 
 Rank 0 prints ONE JSON line: metric keypoint-pairs/sec (whole job), plus
-  roofline     - the dominant kernel class of the step against the f16 MFMA roofline, its average launch
-                 duration measured live with HIP events on the launch stream (mdgat_profile);
+  roofline     - the dominant kernel class of the step against the f16 MFMA roofline (or HBM for Sinkhorn), its
+                 average launch duration measured live with HIP events on the launch stream (mdgat_profile);
+  roofline_qk  - the Q K^T contraction of full attention (the north star's "QK^T roofline"): the phase in isolation
+                 (same kernel, softmax and P.V knocked out; mdgat_attention_qk_probe) timed with HIP events on the
+                 launch stream, as executed and as useful fraction of the dense f16 MFMA peak;
   cpu_baseline - the CPU oracle (fp64 PyTorch restatement of the reference, "port") timed on this box's
                  host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -23,47 +28,51 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-from mdgat_matcher_amd import MDGAT, shard, synth  # noqa: E402
+from mdgat_matcher_amd import MDGAT, ops, shard, synth  # noqa: E402
 
-N_KPTS = 512
-L_LAYERS = 9
-S_ITERS = 100
-BATCH = 64
+# BASELINE.json configs: pairs per GPU, keypoints per frame, L, Sinkhorn iterations, attention dtype
+CONFIGS = {
+    0: dict(B=1, n=256, L=4, S=20, att='fp32', name='configs[0]: one frame pair, 256 keypoints, L=4, 20 Sinkhorn iterations'),
+    1: dict(B=64, n=512, L=9, S=100, att='fp32', name='configs[1]'),
+    2: dict(B=512, n=512, L=9, S=100, att='f16', name='configs[2]: f16 attention / fp32 Sinkhorn'),
+    3: dict(B=512, n=512, L=9, S=100, att='fp32', name='configs[3]: 4096 pairs sharded 8-way = 512 per GPU'),
+    4: dict(B=8, n=2048, L=9, S=200, att='fp32', name='configs[4]: 2048 dense keypoints, 200 Sinkhorn iterations'),
+}
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 SPLIT_FACTOR = 3.0               # f16 MFMAs executed per fp32-equivalent product (hi.hi, hi.lo, lo.hi)
 PEAK_HBM_GBS = 8000.0
-# HBM traffic per launch from rocprofv3 PMC passes of this same command (profiles/r1j_pmc_fetch_write_kb.txt):
-# 2 x FETCH_SIZE (gfx950 under-reports wide streaming reads by 2x, MI355X_MICROARCH.md) + WRITE_SIZE, bytes.
-# Algorithmic bytes of a layer launch at B=64: read x + msg 67.1 MB, write x + q/k/v 134.2 MB.
-PMC_TRAFFIC_BYTES = {'layer': (2 * 37847.0 + 131072.0) * 1024, 'attention_full': (2 * 49212.6 + 32768.0) * 1024,
-                     'attention_topk': (2 * 49326.5 + 32768.0) * 1024, 'sinkhorn': (2 * 74001.8 + 108986.3) * 1024}
+# HBM traffic per launch is not measurable from inside the process: it comes from the rocprofv3 PMC passes of this same
+# command committed under profiles/ (tools/profile_round.sh; 2 x FETCH_SIZE - gfx950 under-reports wide streaming reads
+# by 2x, MI355X_MICROARCH.md - + WRITE_SIZE).  profiles/pmc_traffic.json: {config: {kernel class: [bytes, source file]}}
+PMC_TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
 
 
 # Algorithmic work of one launch of each kernel class: MACs x 2, fp32-equivalent.
 # Every product runs as three f16 MFMAs (split operands), so the matrix cores execute 3x these FLOPs.
-def class_work(B, n, L, S, sched):
+def class_work(B, n, L, S):
     R = B * 2 * n
-    per = {
+    att = B * 2 * 4 * (2 * 2.0 * n * n * 32)
+    return {
         'encoder': {'flops': 2.0 * R * (32 * 64 + 64 * 128 + 64 * 128 + 256 * 128 + 4 * 32 + 33 * 64)},
-        'layer': {'flops': 2.0 * R * (256 * 256 + 256 * 128 + 128 * 384)},
-        'attention_full': {'flops': B * 2 * 4 * (2 * 2.0 * n * n * 32)},
-        'attention_topk': {'flops': B * 2 * 4 * (2 * 2.0 * n * n * 32)},
+        'layer_first': {'flops': 2.0 * R * (128 * 384)},                                # q|k|v projection of layer 0 only
+        'layer': {'flops': 2.0 * R * (256 * 256 + 256 * 128 + 128 * 384)},              # mlp + residual + next q|k|v
+        'layer_last': {'flops': 2.0 * R * (256 * 256 + 256 * 128 + 128 * 128)},         # mlp + residual + final_proj
+        'attention_full': {'flops': att},
+        'attention_topk': {'flops': att},
         'scores': {'flops': B * 2.0 * n * n * 128},
         # log-domain Sinkhorn: 2 x S element visits of the (n+1)^2 matrix, 4 bytes each if it were streamed
         'sinkhorn': {'bytes': B * 4.0 * (2.0 * S * (n + 1) * (n + 1))},
         'extract': {'bytes': B * 4.0 * (n + 1) * (n + 1)},
     }
-    return per
 
 
-def kernel_breakdown(net, dev, inputs, B, n, L, S, sched, steps=5):
+def kernel_breakdown(net, dev, inputs, B, n, L, S, steps=5):
     """Average launch duration of every kernel class, measured live with HIP events on the launch stream
     inside the library (mdgat_profile), over `steps` extra forwards after the timed region."""
     net.profile(dev, True)
@@ -71,7 +80,7 @@ def kernel_breakdown(net, dev, inputs, B, n, L, S, sched, steps=5):
         for _ in range(steps):
             net._run(*inputs)
     prof = net.profile(dev, False)
-    work = class_work(B, n, L, S, sched)
+    work = class_work(B, n, L, S)
     rows = []
     for name, (ms, launches) in prof.items():
         if launches == 0:
@@ -79,6 +88,31 @@ def kernel_breakdown(net, dev, inputs, B, n, L, S, sched, steps=5):
         rows.append({'kernel': name, 'launches_per_step': launches // steps, 'ms': ms / launches,
                      'step_ms': ms / steps, **work[name]})
     return rows
+
+
+def qk_roofline(dev, B, n, reps=20):
+    """The Q K^T phase of the streamed full-attention kernel in isolation, HIP events on the launch stream."""
+    g = torch.Generator(dev).manual_seed(0)
+    qkv = torch.randn(B, 2 * n, 3, 4, 32, device=dev, generator=g) * 1.3
+    probe = ops.QkProbe(qkv, n, n)
+    for _ in range(3):
+        probe.run()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        probe.run()
+    b.record()
+    torch.cuda.synchronize()
+    ms = a.elapsed_time(b) / reps
+    flops = B * 2 * 4 * (2.0 * n * n * 32)            # Q K^T only: half of an attention launch
+    useful = flops / (ms * 1e-3) / 1e12
+    return {'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
+            'avg_launch_ms': ms, 'algorithmic_flops_per_launch': flops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+            'achieved': SPLIT_FACTOR * useful, 'frac': SPLIT_FACTOR * useful / PEAK_F16_MFMA_TFLOPS,
+            'useful_tflops': useful, 'frac_useful': useful / PEAK_F16_MFMA_TFLOPS,
+            'note': 'achieved/frac = f16 MFMA FLOP/s executed (3 MFMAs per fp32-class product: no term can be dropped at the '
+                    '1e-4 bar, profiles/precision_ablation_r2.txt); useful = fp32-equivalent'}
 
 
 def cpu_baseline(n, L, S, budget_s=15.0, max_pairs=64):
@@ -100,32 +134,47 @@ def cpu_baseline(n, L, S, budget_s=15.0, max_pairs=64):
                       f'{torch.get_num_threads()} threads, {dt:.1f} s'}
 
 
+def pmc_traffic(config, kernel):
+    try:
+        with open(PMC_TRAFFIC_FILE) as f:
+            entry = json.load(f).get(str(config), {}).get(kernel)
+        return (float(entry[0]), entry[1]) if entry else (None, None)
+    except (OSError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=BATCH, help='pairs per GPU per step (BASELINE config: 64)')
-    ap.add_argument('--attention-dtype', default='fp32', choices=['fp32', 'f16'],
+    ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS),
+                    help='BASELINE.json configs index (default 1 = the headline workload)')
+    ap.add_argument('--batch', type=int, default=None, help='pairs per GPU per step (default: the configuration\'s)')
+    ap.add_argument('--attention-dtype', default=None, choices=['fp32', 'f16'],
                     help="'f16': single-f16 attention products (BASELINE configs[2]; outside the parity bar, not the headline)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     args = ap.parse_args()
 
+    c = CONFIGS[args.config]
+    B = args.batch if args.batch is not None else c['B']
+    n, L, S = c['n'], c['L'], c['S']
+    att = args.attention_dtype or c['att']
+
     rank, world, local = shard.init_distributed(args.gpus)
     dev = torch.device('cuda', local)
     torch.cuda.set_device(dev)
 
-    cfg = synth.default_config(L=L_LAYERS, sinkhorn_iterations=S_ITERS)
-    cfg['attention_dtype'] = args.attention_dtype
+    cfg = synth.default_config(L=L, sinkhorn_iterations=S)
+    cfg['attention_dtype'] = att
     net = MDGAT(cfg).eval()
     if rank == 0:
-        net.load_state_dict(synth.make_state_dict(L=L_LAYERS, seed=0, dtype=torch.float32))
+        net.load_state_dict(synth.make_state_dict(L=L, seed=0, dtype=torch.float32))
     shard.broadcast_weights(net, dev, rank, world)      # RCCL broadcast of the packed blob (no-op at world 1)
 
-    B = args.batch
     first, count = shard.partition(B * world, rank, world)
-    data = synth.make_batch(count, N_KPTS, N_KPTS, first_pair=first, dtype=torch.float32, device=dev)
+    data = synth.make_batch(count, n, n, first_pair=first, dtype=torch.float32, device=dev)
     inputs = (data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'], data['descriptors1'])
 
     def step():
@@ -151,6 +200,7 @@ def main():
 
     if rank == 0:
         pairs = B * world * args.steps
+        parity = att == 'fp32'
         out = {
             'metric': 'keypoint-pairs/sec',
             'value': pairs / dt,
@@ -163,40 +213,45 @@ def main():
             'higher_is_better': True,
             'scaling': 'weak',
             'vs_baseline': None,
-            'dtype': 'f32 (products as 3 split-f16 MFMAs, fp32 accumulate)' if args.attention_dtype == 'fp32' else
+            'dtype': 'f32 (products as 3 split-f16 MFMAs, fp32 accumulate)' if parity else
                      'f16 attention products (single f16 operands, fp32 accumulate), f32 elsewhere: NOT the parity path',
             'data': 'synthetic',
-            'config': {'workload': f'batch={B} synthetic pairs per GPU, N=M={N_KPTS} keypoints, 33-D FPFH, L={L_LAYERS}, '
-                                   f'{S_ITERS} Sinkhorn iterations, ' + ('fp32 (BASELINE.json configs[1])' if args.attention_dtype == 'fp32' else 'f16 attention / fp32 Sinkhorn (BASELINE.json configs[2] at this batch)'),
-                       'pairs_per_gpu': B, 'keypoints': N_KPTS, 'L': L_LAYERS, 'sinkhorn_iterations': S_ITERS,
+            'config': {'workload': f'batch={B} synthetic pairs per GPU, N=M={n} keypoints, 33-D FPFH, L={L}, '
+                                   f'{S} Sinkhorn iterations, ' + ('fp32' if parity else 'f16 attention / fp32 Sinkhorn') +
+                                   f' (BASELINE.json {c["name"]}' + ('' if B == c['B'] else f' at batch {B}') + ')',
+                       'baseline_config': args.config, 'pairs_per_gpu': B, 'keypoints': n, 'L': L, 'sinkhorn_iterations': S,
                        'parallelism': f'pairs sharded {world}-way, no data-path collective'},
         }
         if not args.no_breakdown:
-            sched = net._topk_schedule()
-            rows = kernel_breakdown(net, dev, inputs, B, N_KPTS, L_LAYERS, S_ITERS, sched)
+            rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
             dom = max(rows, key=lambda r: r['step_ms'])
+            traffic, source = pmc_traffic(args.config if B == c['B'] and att == c['att'] else -1, dom['kernel'])
             if 'flops' in dom:
                 alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-                ach = SPLIT_FACTOR * alg
+                ach = (SPLIT_FACTOR if parity or not dom['kernel'].startswith('attention') else 1.0) * alg
                 roof = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F16_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_MFMA_TFLOPS,
-                        'traffic': PMC_TRAFFIC_BYTES.get(dom['kernel']) if B == BATCH else None,
+                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
                         'avg_launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
-                        'algorithmic_tflops': alg,
+                        'algorithmic_tflops': alg, 'frac_useful': alg / PEAK_F16_MFMA_TFLOPS,
                         'note': 'achieved = f16 MFMA FLOP/s executed = 3 x the fp32-equivalent algorithmic rate '
-                                '(every product is hi.hi + hi.lo + lo.hi on the f16 matrix cores)'}
+                                '(every product is hi.hi + hi.lo + lo.hi on the f16 matrix cores); frac_useful = the '
+                                'fp32-equivalent rate over the same peak; traffic = HBM bytes per launch from the PMC '
+                                'passes of this command named in traffic_source (not measured in this run)'}
             else:
                 ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
                 roof = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'avg_launch_ms': dom['ms'],
-                        'bytes_per_launch': dom['bytes']}
+                        'frac': ach / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': dom['ms'],
+                        'bytes_per_launch': dom['bytes'],
+                        'note': 'bytes = the streamed-form algorithmic traffic 2 S (n+1)^2 4 B per pair (SURVEY 8d)'}
             out['roofline'] = roof
+            if n % 64 == 0 and att == 'fp32':
+                out['roofline_qk'] = qk_roofline(dev, B, n)
             out['kernels'] = [{'kernel': r['kernel'], 'launches_per_step': r['launches_per_step'], 'avg_ms': round(r['ms'], 4),
                                'step_ms': round(r['step_ms'], 3),
                                'algorithmic_tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if 'flops' in r else None}
                               for r in rows]
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(N_KPTS, L_LAYERS, S_ITERS)
+            out['cpu_baseline'] = cpu_baseline(n, L, S, max_pairs=64 if n <= 512 else 4)
         print(json.dumps(out), flush=True)
     shard.finalize(world)
 

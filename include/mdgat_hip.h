@@ -146,7 +146,9 @@ enum {
     MDGAT_PROF_SCORES = 4,         /* score matrix */
     MDGAT_PROF_SINKHORN = 5,
     MDGAT_PROF_EXTRACT = 6,
-    MDGAT_PROF_CLASSES = 7
+    MDGAT_PROF_LAYER_FIRST = 7,    /* the launch before layer 0: q/k/v projection only (a third of a layer launch's work) */
+    MDGAT_PROF_LAYER_LAST = 8,     /* the launch after the last layer: mlp + residual + final_proj */
+    MDGAT_PROF_CLASSES = 9
 };
 int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
 
@@ -174,6 +176,13 @@ size_t mdgat_attention_workspace_bytes(int B, int N, int M);
  * (layout as mdgat_taps.topk_sel). */
 int mdgat_attention_sel(int B, int N, int M, int cross, int topk, const float* qkv, float* msg, uint32_t* sel,
                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Measurement only (bench.py, roofline_qk): the Q K^T contraction of the streamed full-attention kernel in isolation -
+ * the same chunk ring, LDS reads and split-f16 MFMA sequence as mdgat_attention, without V^T traffic, softmax and P.V.
+ * msg [B][P][128]: element [p][head * 32] receives the row maximum of the base-2 logits, the rest is left alone.
+ * N and M must be multiples of 64.  Not part of the matching path (mdgat.py:192 is its subject). */
+int mdgat_attention_qk_probe(int B, int N, int M, int cross, const float* qkv, float* msg,
+                             void* workspace, size_t workspace_bytes, void* stream);
 
 /* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
  * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */

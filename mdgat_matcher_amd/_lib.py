@@ -17,7 +17,7 @@ EXTRACT_DUSTBIN_MUTUAL = 1
 EXTRACT_THRESHOLD = 2
 EXTRACT_THRESHOLD_MUTUAL = 3
 
-PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores', 'sinkhorn', 'extract')
+PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores', 'sinkhorn', 'extract', 'layer_first', 'layer_last')
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -66,6 +66,7 @@ SIGNATURES = {
     'mdgat_attention': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_size_t, C.c_void_p]),
     'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    'mdgat_attention_qk_probe': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_attention_sel': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
     'mdgat_topk_sel_words': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -295,7 +295,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
-        mark(MDGAT_PROF_LAYER);
+        mark(MDGAT_PROF_LAYER_FIRST);
     }
     for (int i = 0; i < L2; ++i) {
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
@@ -310,7 +310,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
-        mark(MDGAT_PROF_LAYER);
+        mark(i + 1 < L2 ? MDGAT_PROF_LAYER : MDGAT_PROF_LAYER_LAST);
         if (taps && taps->x_layers)
             if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_layers + (size_t)i * R * 128, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_layers"))) return rc;
     }
@@ -413,6 +413,21 @@ extern "C" int mdgat_attention_sel(int B, int N, int M, int cross, int topk, con
     const Qkv16 q16 = mdgat_qkv16_carve(static_cast<_Float16*>(workspace), B, N, M);
     if (int rc = launch_qkv_split(B, N, M, qkv, q16, s)) return rc;
     return launch_attention(B, N, M, cross, topk, q16, msg, s, 0, sel);
+}
+
+extern "C" int mdgat_attention_qk_probe(int B, int N, int M, int cross, const float* qkv, float* msg, void* workspace,
+                                        size_t workspace_bytes, void* stream) {
+    if (!qkv || !msg || !workspace) { mdgat_set_error("mdgat_attention_qk_probe: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (workspace_bytes < mdgat_attention_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        mdgat_set_error("mdgat_attention_qk_probe: workspace too small or not 16-byte aligned");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Qkv16 q16 = mdgat_qkv16_carve(static_cast<_Float16*>(workspace), B, N, M);
+    // (qkv == workspace: the operands are already there in the library's split layout - bench.py times only the probe)
+    if (static_cast<const void*>(qkv) != workspace)
+        if (int rc = launch_qkv_split(B, N, M, qkv, q16, s)) return rc;
+    return launch_attention_qk_probe(B, N, M, cross, q16, msg, s);
 }
 
 extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,

@@ -49,7 +49,10 @@ __device__ __forceinline__ void for_units(F&& f) { for_each_unit(f, std::make_in
 #define SLOT_END() __builtin_amdgcn_sched_barrier(0)
 
 // FAST (mdgat_attention_mode F16): only the hi planes take part - one MFMA per product, no residual planes.
-template <bool FAST>
+// QK_ONLY (bench.py's roofline_qk leg, mdgat_attention_qk_probe): the Q K^T phase in isolation - the same chunk ring,
+// K fragment reads, MFMA sequence and logit combine, but no V^T copies, no softmax and no P.V; the running row maximum
+// is what leaves the kernel (so that nothing is dead code).
+template <bool FAST, bool QK_ONLY = false>
 __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     }
     auto dma_chunk = [&](int ch) __attribute__((always_inline)) {
         if (FAST && wave == 3) return;        // the lo plane of V^T is not read (the vmcnt waits only get stricter)
+        if (QK_ONLY && wave >= 2) return;
         const char* s0 = dbase + (size_t)ch * cstride;
         const unsigned d0 = lds0 + (unsigned)(ch & (NSLOT - 1)) * CHUNK_BYTES + (unsigned)wave * BLK_BYTES;
 #pragma unroll
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         for (int i = 0; i < (FAST ? 2 : 4); ++i) kf[i] = *reinterpret_cast<const f16x8_a*>(base + kofs[i]);
     };
     auto vread = [&](int ch, int i) __attribute__((always_inline)) {
+        if (QK_ONLY) return;
         const char* base = smem + (ch & (NSLOT - 1)) * CHUNK_BYTES + 2 * BLK_BYTES;
         vh[i & 1] = *reinterpret_cast<const f16x8_a*>(base + vofs[i]);
         if (!FAST) vl[i & 1] = *reinterpret_cast<const f16x8_a*>(base + BLK_BYTES + vofs[i]);
@@ -187,6 +192,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     float m11 = 0.f;
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     auto vs = [&](int i, int u) __attribute__((always_inline)) {
+        if (QK_ONLY) return;
         const int jb = i >> 1, r0 = 8 * (i & 1), pb = i & 1;
         if (u == 0) {
 #pragma unroll
@@ -218,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     };
     // P.V product k of step i: O^T += V^T P^T (p' = hi + lo unscaled; the lo plane of V carries the factor 2048)
     auto pvm = [&](int i, int k) __attribute__((always_inline)) {
+        if (QK_ONLY) return;
         const int pb = i & 1;
         if (k == 0) Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[pb], php[pb], Om, 0, 0, 0);
         else if (FAST) {}
@@ -299,6 +306,10 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     for (int c = 0; c + 1 < NCH; ++c) chunk_body(c, std::true_type{});
     chunk_body(NCH - 1, std::false_type{});
     for_units<3>([&](int k) __attribute__((always_inline)) { pvm(3, k); });
+    if (QK_ONLY) {
+        if (hi == 0 && qw + l31 < nq) a.msg[((size_t)b * P + q_off + qw + l31) * 128 + head * 32] = m_run;
+        return;
+    }
 
     // ---- message rows through a wave-private tile in two slots nobody touches any more ----
     float l = l2[0] + l2[1];
@@ -336,4 +347,15 @@ int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, fl
     if (mode == 1) hipLaunchKernelGGL(attention_stream_kernel<true>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     else hipLaunchKernelGGL(attention_stream_kernel<false>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "attention launch");
+}
+
+int launch_attention_qk_probe(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s) {
+    if (!attention_stream_supported(N, M)) { mdgat_set_error("qk probe: key counts must be multiples of 64"); return MDGAT_ERR_UNSUPPORTED; }
+    const int nq_max = N > M ? N : M;
+    StreamArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, (nq_max + 127) / 128};
+    const size_t lds = (size_t)NSLOT * CHUNK_BYTES;
+    static std::atomic<unsigned long long> optin;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(attention_stream_kernel<false, true>), lds, optin, "qk probe LDS attribute")) return rc;
+    hipLaunchKernelGGL((attention_stream_kernel<false, true>), dim3(B * 8 * a.QT), dim3(256), lds, s, a);
+    return mdgat_check_hip(hipGetLastError(), "qk probe launch");
 }

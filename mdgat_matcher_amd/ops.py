@@ -91,6 +91,32 @@ def attention(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0, ret
     return msg
 
 
+class QkProbe:
+    """Measurement only (bench.py ``roofline_qk``): the Q K^T phase of the streamed full-attention kernel in isolation
+    (``mdgat_attention_qk_probe``).  ``QkProbe(qkv, N, M)`` converts fp32 q/k/v [B, N+M, 3, 4, 32] to the library's split
+    layout once; ``run(cross)`` launches only the probe kernel on the current stream."""
+
+    def __init__(self, qkv: torch.Tensor, N: int, M: int):
+        _need_cuda(qkv)
+        x = qkv.to(torch.float32).contiguous()
+        self.B, self.N, self.M = x.shape[0], N, M
+        assert x.shape[1] == N + M and tuple(x.shape[2:]) == (3, 4, 32)
+        self.lib = _lib.load()
+        with torch.cuda.device(x.device):
+            self.need = self.lib.mdgat_attention_workspace_bytes(self.B, N, M)
+            self.ws = torch.empty(self.need, dtype=torch.uint8, device=x.device)
+            self.msg = torch.zeros((self.B, N + M, 128), dtype=torch.float32, device=x.device)
+            _lib.check(self.lib.mdgat_attention_qk_probe(self.B, N, M, 0, x.data_ptr(), self.msg.data_ptr(), self.ws.data_ptr(),
+                                                         self.need, _stream(x)), 'mdgat_attention_qk_probe')
+
+    def run(self, cross: bool = False):
+        with torch.cuda.device(self.ws.device):
+            _lib.check(self.lib.mdgat_attention_qk_probe(self.B, self.N, self.M, int(bool(cross)), self.ws.data_ptr(),
+                                                         self.msg.data_ptr(), self.ws.data_ptr(), self.need, _stream(self.ws)),
+                       'mdgat_attention_qk_probe')
+        return self.msg
+
+
 def pointwise(A: torch.Tensor, W: torch.Tensor, bias=None, relu=False, residual=None) -> torch.Tensor:
     """Conv1d(k=1) over points: A [rows, K] x W [Cout, K]^T (+bias, ReLU, +residual) -> [rows, Cout]."""
     _need_cuda(A, W)

@@ -6,8 +6,14 @@ format and compares Z with the fp64 oracle.  Schemes:
   f16x3    a = hi + lo/2048 with hi, lo fp16; a.b ~ hi.hi + (hi.lo + lo.hi)/2048   (3 fp16 MFMAs)
   bf16x3   a = hi + lo with hi, lo bf16;      a.b ~ hi.hi + hi.lo + lo.hi          (3 bf16 MFMAs)
   f16      single fp16 operands
+Per-operand ablation of f16x3 (which of the cross terms does a product need for the 1e-4 bar?): a.b = hi.hi + a_hi.b_lo + a_lo.b_hi
+  f16x2a   a single f16 (drops a_lo.b_hi), b split     - for P.V: probabilities as ONE f16, V split
+  f16x2ac  the same with the row sum taken over the ROUNDED a (P.V only: softmax weights still sum to one)
+  f16x2b   a split, b single f16 (drops a_hi.b_lo)
+(a = weights / q / probabilities, b = activations / k / v in the three product classes lin / qk / pv)
 Products of two half-precision values are exact in fp32, so only the accumulation order differs from
-the hardware.  Usage: python tools/precision_probe.py [N] [L] [S]"""
+the hardware.  Dynamic layers run with the fp64 run's top-k selections forced (arithmetic error only, no near-tie
+flips).  Usage: [ABLATE=1] python tools/precision_probe.py [N] [L] [S]"""
 import os
 import sys
 
@@ -40,10 +46,17 @@ def make_mm(scheme):
             ah, al = split_f16(a)
             bh, bl = split_f16(b)
             return ah @ bh + (ah @ bl + al @ bh) * (1.0 / 2048.0)
-        if scheme == 'f16x2w':   # activations single fp16?  no: weights/b split, a single
+        if scheme in ('f16x2a', 'f16x2ac'):
             ah = a.half().float()
             bh, bl = split_f16(b)
-            return ah @ bh + (ah @ bl) * (1.0 / 2048.0)
+            out = ah @ bh + (ah @ bl) * (1.0 / 2048.0)
+            if scheme == 'f16x2ac':      # rows of a are softmax weights (sum 1 before rounding): renormalise by the rounded sum
+                out = out / ah.sum(-1, keepdim=True)
+            return out
+        if scheme == 'f16x2b':
+            ah, al = split_f16(a)
+            bh = b.half().float()
+            return ah @ bh + (al @ bh) * (1.0 / 2048.0)
         if scheme == 'bf16x3':
             ah, al = split_bf16(a)
             bh, bl = split_bf16(b)
@@ -52,7 +65,7 @@ def make_mm(scheme):
     return mm
 
 
-def run(scheme_lin, scheme_qk, scheme_pv, sd32, cfg, data):
+def run(scheme_lin, scheme_qk, scheme_pv, sd32, cfg, data, forced=None):
     mm_lin, mm_qk, mm_pv = make_mm(scheme_lin), make_mm(scheme_qk), make_mm(scheme_pv)
     saved = (O._pointwise, O.attention, O.dynamic_attention, torch.einsum)
 
@@ -71,11 +84,14 @@ def run(scheme_lin, scheme_qk, scheme_pv, sd32, cfg, data):
         prob = torch.softmax(logits_of(q, k), dim=-1)
         return pv(prob, v), prob
 
-    def dynamic_attention(q, k, v, topk):
+    def dynamic_attention(q, k, v, topk, forced=None, report=None):
         logits = logits_of(q, k)
-        top = logits.topk(topk, dim=3)
-        prob = torch.zeros_like(logits)
-        prob.scatter_(3, top.indices, torch.softmax(top.values, dim=-1))
+        if forced is not None:       # the fp64 run's selection: arithmetic error only, no near-tie flips
+            prob = torch.softmax(logits.masked_fill(~forced, float('-inf')), dim=-1)
+        else:
+            top = logits.topk(topk, dim=3)
+            prob = torch.zeros_like(logits)
+            prob.scatter_(3, top.indices, torch.softmax(top.values, dim=-1))
         return pv(prob, v), prob
 
     def einsum(eq, *ops):
@@ -86,7 +102,7 @@ def run(scheme_lin, scheme_qk, scheme_pv, sd32, cfg, data):
     O._pointwise, O.attention, O.dynamic_attention, torch.einsum = pointwise, attention, dynamic_attention, einsum
     try:
         cap = {}
-        out = O.mdgat_forward(sd32, cfg, data, cap)
+        out = O.mdgat_forward(sd32, cfg, data, cap, forced_topk=forced)
     finally:
         O._pointwise, O.attention, O.dynamic_attention, torch.einsum = saved
     return out, cap
@@ -105,12 +121,19 @@ def main():
         d32 = {kk: (v.float() if v.dtype == torch.float64 else v) for kk, v in data.items()}
         with torch.no_grad():
             cap64 = {}
-            ref = O.mdgat_forward(sd, cfg, data, cap64)
+            ref = O.mdgat_forward(sd, cfg, data, cap64, forced_topk={})
+            forced = {i: (r[0]['own'], r[1]['own']) for i, r in cap64.get('topk_report', {}).items()} or None
             print(f'--- N={n} L={L} S={S} k={"default" if k is None else "none"}')
-            for lin, qk, pvs in (('f32', 'f32', 'f32'), ('f16x3', 'f16x3', 'f16x3'), ('bf16x3', 'bf16x3', 'bf16x3'),
-                                 ('f16x3', 'f16x3', 'f16'), ('f16x3', 'f32', 'f32'), ('f32', 'f16x3', 'f32'),
-                                 ('f32', 'f32', 'f16x3'), ('f32', 'f32', 'f16')):
-                out, cap = run(lin, qk, pvs, sd32, cfg, d32)
+            combos = (('f32', 'f32', 'f32'), ('f16x3', 'f16x3', 'f16x3'), ('bf16x3', 'bf16x3', 'bf16x3'),
+                      ('f16x3', 'f16x3', 'f16'), ('f16x3', 'f32', 'f32'), ('f32', 'f16x3', 'f32'),
+                      ('f32', 'f32', 'f16x3'), ('f32', 'f32', 'f16'))
+            if os.environ.get('ABLATE'):
+                combos = (('f16x3', 'f16x3', 'f16x3'),
+                          ('f16x3', 'f16x3', 'f16x2a'), ('f16x3', 'f16x3', 'f16x2ac'), ('f16x3', 'f16x3', 'f16x2b'),
+                          ('f16x3', 'f16x2a', 'f16x3'), ('f16x3', 'f16x2b', 'f16x3'),
+                          ('f16x2a', 'f16x3', 'f16x3'), ('f16x2b', 'f16x3', 'f16x3'))
+            for lin, qk, pvs in combos:
+                out, cap = run(lin, qk, pvs, sd32, cfg, d32, forced)
                 dz = (cap['Z'].double() - cap64['Z']).abs()
                 ds = (cap['scores'].double() - cap64['scores']).abs().max().item()
                 mm0 = (out['matches0'] != ref['matches0']).sum().item() + (out['matches1'] != ref['matches1']).sum().item()
