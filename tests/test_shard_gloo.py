@@ -55,6 +55,96 @@ def test_two_rank_gloo():
     np.testing.assert_array_equal(res[0][4][:, 0], np.arange(12))
 
 
+def _install_worker(rank, world, port, q):
+    """The per-rank control flow of bench.py (init -> rank 0 loads the checkpoint -> broadcast of the packed blob ->
+    load_packed -> net.double().eval() -> forward on the rank's shard) with the HIP library replaced at the _lib
+    boundary by a recorder, and 'is on the GPU' answered with yes: what is exercised is the host logic that decides
+    WHICH weights reach mdgat_load_weights on a rank that never loaded a checkpoint."""
+    import contextlib
+    import ctypes as C
+    from unittest import mock
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from mdgat_matcher_amd import MDGAT, _lib, pack, shard, synth
+
+    class FakeLib:
+        def __init__(self):
+            self.calls, self.loaded = [], None
+        def mdgat_create(self, cfg, idx, handle):
+            self.calls.append(('create', idx))
+            handle._obj.value = 4242                      # (handle is ctypes.byref(c_void_p()))
+            return 0
+        def mdgat_blob_floats(self, L):
+            return pack.blob_layout(L)['total']
+        def mdgat_load_weights(self, handle, ptr, n, on_device):
+            addr = ptr.value if hasattr(ptr, 'value') else C.cast(ptr, C.c_void_p).value
+            self.loaded = np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_float)), shape=(n,)).copy()
+            self.calls.append(('load', int(n), int(on_device)))
+            return 0
+        def mdgat_workspace_bytes(self, handle, B, N, M):
+            return 256
+        def mdgat_forward(self, *a):
+            self.calls.append(('forward', a[1], a[2], a[3]))
+            return 0
+        def mdgat_destroy(self, handle):
+            self.calls.append(('destroy',))
+        def mdgat_last_error(self):
+            return b''
+
+    fake = FakeLib()
+    stream = mock.Mock(cuda_stream=0)
+    r, w, _ = shard.init_distributed(world, backend='gloo')
+    L = 2
+    torch.manual_seed(100 + r)                       # every rank starts from its own random init
+    net = MDGAT(synth.default_config(L=L, k=[16, None])).eval()
+    if r == 0:
+        net.load_state_dict(synth.make_state_dict(L=L, seed=5, dtype=torch.float32))
+    blob = shard.broadcast_weights(net, 'cpu', r, w)  # gloo broadcast of rank 0's packed blob (a CPU tensor: not installed)
+    first, count = shard.partition(6, r, w)
+    d = synth.make_batch(count, 40, 48, first_pair=first)
+    # from here on the tensors pose as device memory (only around the calls under test: gloo must not see it)
+    with mock.patch.object(_lib, 'load', lambda: fake), \
+            mock.patch.object(torch.Tensor, 'is_cuda', new=property(lambda self: True)), \
+            mock.patch.object(torch.cuda, 'current_device', lambda: 0), \
+            mock.patch.object(torch.cuda, 'device', lambda d: contextlib.nullcontext()), \
+            mock.patch.object(torch.cuda, 'current_stream', lambda d=None: stream):
+        net.load_packed(blob)                            # what broadcast_weights does with a blob on the GPU
+        net.double().eval()                              # test.py:193, before every forward
+        net._run(d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'])
+        net.double().eval()
+        net._run(d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'])
+        net._invalidate()                                # the recorder's handle must not reach the real mdgat_destroy
+    shard.barrier(w)
+    q.put((r, fake.calls, fake.loaded))
+    shard.finalize(w)
+
+
+def test_two_rank_weight_install_with_stubbed_library():
+    world, port = 2, 29411 + (os.getpid() % 200)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_install_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from mdgat_matcher_amd import MDGAT, pack, synth
+    ref_net = MDGAT(synth.default_config(L=2, k=[16, None]))
+    ref_net.load_state_dict(synth.make_state_dict(L=2, seed=5, dtype=torch.float32))
+    expect = ref_net.packed_weights()
+    n = pack.blob_layout(2)['total']
+    for r, calls, loaded in res:
+        # exactly one handle and ONE weight install per rank - the broadcast blob, handed over as device memory - and
+        # the casts before the forwards neither re-pack the rank's own (random) parameters nor rebuild the handle
+        assert [c for c in calls if c[0] in ('create', 'load', 'destroy')] == [('create', 0), ('load', n, 1), ('destroy',)], (r, calls)
+        assert [c for c in calls if c[0] == 'forward'] == [('forward', 3, 40, 48)] * 2
+        np.testing.assert_array_equal(loaded, expect)
+
+
 def test_partition_properties():
     sys.path.insert(0, ROOT)
     from mdgat_matcher_amd import shard
