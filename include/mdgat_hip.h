@@ -191,10 +191,14 @@ int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W
                     void* stream);
 
 /* knn() / get_graph_feature() (mdgat.py:8-32; dead code there, named by the north star):
- * x [B][N][C], src [B][M][C] (point-major) -> idx int64 [B][N][k] in topk order (nearest first),
- * and, if adj != NULL, the dense 0/1 int64 adjacency [B][N][M]. */
+ * x [B][N][C], src [B][M][C] (point-major) -> idx int64 [B][N][k] in topk order (nearest first; exact ties in the
+ * order of their indices), and, if adj != NULL, the dense 0/1 int64 adjacency [B][N][M].  Any M; k <= 1024.
+ * C == 128 (feature space) runs the inner products on the matrix cores when `workspace` holds
+ * mdgat_knn_workspace_bytes(B, C, N, M) bytes (16-byte aligned; the N x M matrix of 2 x.s - |s|^2); other channel
+ * counts - or workspace == NULL - compute -sum (x - s)^2 inside the selection kernel and need none. */
 int mdgat_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx,
-              int64_t* adj, void* stream);
+              int64_t* adj, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdgat_knn_workspace_bytes(int B, int C, int N, int M);
 
 /* ---- the steps either side of the matcher, fp64 like the reference's numpy ---------- */
 

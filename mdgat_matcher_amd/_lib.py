@@ -77,7 +77,8 @@ SIGNATURES = {
     'mdgat_gt_matches': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mdgat_knn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                            C.c_void_p]),
+                            C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_knn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int, C.c_int]),
 }
 
 _lib = None

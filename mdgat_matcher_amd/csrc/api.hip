@@ -438,10 +438,12 @@ extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, con
     return launch_gemm(g, static_cast<hipStream_t>(stream));
 }
 
+extern "C" size_t mdgat_knn_workspace_bytes(int B, int C, int N, int M) { return mdgat_knn_ws_bytes_impl(B, C, N, M); }
+
 extern "C" int mdgat_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
-                         void* stream) {
+                         void* workspace, size_t workspace_bytes, void* stream) {
     if (!x || !src || !idx) { mdgat_set_error("mdgat_knn: null pointer"); return MDGAT_ERR_BAD_ARG; }
-    return launch_knn(B, C, N, M, k, x, src, idx, adj, static_cast<hipStream_t>(stream));
+    return launch_knn(B, C, N, M, k, x, src, idx, adj, workspace, workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int mdgat_pose(int B, int N, int M, const float* kpts0, const float* kpts1, const int64_t* matches0,

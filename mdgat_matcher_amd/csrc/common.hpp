@@ -148,5 +148,9 @@ int launch_pose(int B, int N, int M, const float* kpts0, const float* kpts1, con
 int launch_gt_match(int B, int N, int M, const float* kpts0, const float* kpts1, const double* T0, const double* T1,
                     double threshold, int mutual, int64_t* gt0, int64_t* gt1, int64_t* rep, hipStream_t s);
 
+// out[b][i][j] = scale <A[b][i], Bm[b][j]> - col_bias[b][j] over 128 channels, split-f16 products (scores.hip)
+int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
+                const float* col_bias, hipStream_t s);
 int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
-               hipStream_t s);
+               void* ws, size_t ws_bytes, hipStream_t s);
+size_t mdgat_knn_ws_bytes_impl(int B, int C, int N, int M);

@@ -11,10 +11,13 @@ namespace {
 constexpr int SROW = 264;     // LDS row (halves): 128 hi | 128 lo | 8 pad (528 B: conflict-free ds_read_b128 fragments)
 
 struct ScoreArgs {
-    const float* mdesc;       // [B][N + M][128]
-    float* scores;            // [B][N][M]
+    const float* A;           // [B] x [N][128] rows, batch stride sA floats
+    const float* Bm;          // [B] x [M][128] rows, batch stride sB floats
+    size_t sA, sB;
+    float* scores;            // [B][N][M] = scale <A_i, B_j> - col_bias[b][j]
     int N, M;
     float scale;
+    const float* col_bias;    // [B][M] or NULL (the kNN helper: |s_j|^2, pointops.hip)
 };
 
 __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
@@ -26,9 +29,8 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int b = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const int P = a.N + a.M;
-    const float* A = a.mdesc + (size_t)b * P * 128;
-    const float* Bm = A + (size_t)a.N * 128;
+    const float* A = a.A + (size_t)b * a.sA;
+    const float* Bm = a.Bm + (size_t)b * a.sB;
 
     // ---- both operand tiles: fp32 rows -> (hi | lo) halves in LDS; 8 x 16-byte loads per thread and operand ----
     auto stage = [&](const float* src, int r0, int nrows, _Float16* dst) {
@@ -78,24 +80,31 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const int j = j0 + 32 * wc + l31;
     if (j < a.M) {
         float* out = a.scores + ((size_t)b * a.N) * a.M + j;
+        const float bias = a.col_bias ? a.col_bias[(size_t)b * a.M + j] : 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + 64 * wr + 32 * t + mfma32_row(r, hi);
-                if (i < a.N) out[(size_t)i * a.M] = fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale;
+                if (i < a.N) out[(size_t)i * a.M] = fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale - bias;
             }
     }
 }
 
 }  // namespace
 
-int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s) {
+int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
+                const float* col_bias, hipStream_t s) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
-    ScoreArgs a{mdesc, scores, N, M, scale};
+    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias};
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
     static std::atomic<unsigned long long> optin;
     if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(scores_kernel), lds, optin, "scores LDS attribute")) return rc;
     hipLaunchKernelGGL(scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "scores launch");
+}
+
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s) {
+    const size_t P = (size_t)(N + M) * 128;
+    return launch_dots(B, N, M, mdesc, P, mdesc + (size_t)N * 128, P, scores, scale, nullptr, s);
 }

@@ -136,8 +136,9 @@ def pointwise(A: torch.Tensor, W: torch.Tensor, bias=None, relu=False, residual=
     return out
 
 
-def knn(x: torch.Tensor, src: torch.Tensor, k: int, adjacency: bool = False):
-    """knn / get_graph_feature (mdgat.py:8-32).  Channel-major inputs like the reference: x [B, C, N], src [B, C, M]."""
+def knn(x: torch.Tensor, src: torch.Tensor, k: int, adjacency: bool = False, mfma: bool = True):
+    """knn / get_graph_feature (mdgat.py:8-32).  Channel-major inputs like the reference: x [B, C, N], src [B, C, M].
+    ``mfma=False`` keeps C = 128 off the matrix cores (distances computed inside the selection kernel)."""
     _need_cuda(x, src)
     xp = x.to(torch.float32).transpose(1, 2).contiguous()
     sp = src.to(torch.float32).transpose(1, 2).contiguous()
@@ -145,9 +146,13 @@ def knn(x: torch.Tensor, src: torch.Tensor, k: int, adjacency: bool = False):
     M = sp.shape[1]
     idx = torch.empty((B, N, k), dtype=torch.int64, device=x.device)
     adj = torch.empty((B, N, M), dtype=torch.int64, device=x.device) if adjacency else None
+    lib = _lib.load()
     with torch.cuda.device(x.device):
-        _lib.check(_lib.load().mdgat_knn(B, Cc, N, M, int(k), xp.data_ptr(), sp.data_ptr(), idx.data_ptr(),
-                                         adj.data_ptr() if adj is not None else None, _stream(x)), 'mdgat_knn')
+        need = lib.mdgat_knn_workspace_bytes(B, Cc, N, M) if mfma else 0      # C == 128: inner products on the matrix cores
+        ws = torch.empty(need, dtype=torch.uint8, device=x.device) if need else None
+        _lib.check(lib.mdgat_knn(B, Cc, N, M, int(k), xp.data_ptr(), sp.data_ptr(), idx.data_ptr(),
+                                 adj.data_ptr() if adj is not None else None,
+                                 ws.data_ptr() if ws is not None else None, need, _stream(x)), 'mdgat_knn')
     return (idx, adj) if adjacency else idx
 
 

@@ -344,3 +344,57 @@ def test_knn_golden(golden_dir):
         np.testing.assert_array_equal(adj.cpu().numpy(), g[f'knn{Cc}_adj'])
     with pytest.raises(RuntimeError):
         ops.knn(x.to(DEV), s.to(DEV), 71)
+
+
+def _knn_check(x, s, k, eps, **kw):
+    """GPU kNN against the fp64 oracle: index lists identical on every row whose k + 1 nearest neighbours are separated
+    by more than eps in the oracle's fp64 distances (closer than fp32-class arithmetic resolves: either order is right)."""
+    idx, adj = ops.knn(x.to(DEV), s.to(DEV), k, adjacency=True, **kw)
+    ref = O.knn(x, s, k)
+    inner = -2.0 * torch.matmul(x.transpose(2, 1), s)
+    nd = -(x ** 2).sum(1, keepdim=True).transpose(2, 1) - inner - (s ** 2).sum(1, keepdim=True)
+    top = nd.topk(min(k + 1, nd.shape[-1]), dim=-1).values
+    # (fp32 resolution grows with the magnitude of the distances: eps is meant at |d^2| <= 100)
+    tol = eps * torch.clamp(top[..., 1:].abs() / 100.0, min=1.0)
+    clear = ((top[..., :-1] - top[..., 1:]) > tol).all(-1) if top.shape[-1] > 1 else torch.ones(top.shape[:2], dtype=torch.bool)
+    frac = 1.0 - clear.double().mean().item()
+    assert torch.equal(idx.cpu()[clear], ref[clear]), 'neighbour lists differ on rows without near-ties'
+    # every row: the same SET up to near-ties is implied above; the adjacency is the scatter of the returned indices
+    assert torch.equal(adj.cpu(), O.knn_adjacency(x, s, k, idx=idx.cpu()))
+    assert (adj.sum(-1) == k).all()
+    return frac
+
+
+@pytest.mark.parametrize('C,N,M,k,eps', [(3, 2048, 2048, 9, 1e-4), (3, 2048, 2048, 64, 1e-4), (128, 2048, 2048, 9, 2e-4),
+                                         (128, 2048, 2048, 64, 2e-4), (3, 300, 5000, 16, 1e-4), (128, 130, 9000, 40, 2e-4),
+                                         (3, 100, 4097, 1, 1e-4), (7, 257, 600, 600, 1e-4), (3, 64, 1500, 1024, 1e-4),
+                                         (128, 512, 512, 128, 2e-4)])
+def test_knn_large(C, N, M, k, eps):
+    """BASELINE configs[4] size (N = M = 2048; coordinates C = 3 and feature space C = 128 on the matrix cores), rows
+    longer than one LDS segment (M > 4096: merged best-k lists), k = M, k = 1, the largest k."""
+    rs = np.random.RandomState(C + N + M + k)
+    scale = 20.0 if C == 3 else 1.0
+    x = torch.from_numpy(scale * rs.standard_normal((2 if N <= 512 else 1, C, N)))
+    s = torch.from_numpy(scale * rs.standard_normal((x.shape[0], C, M)))
+    frac = _knn_check(x, s, k, eps)
+    print(f'knn C={C} N={N} M={M} k={k}: rows excluded as near-ties {frac:.3%}')
+    assert frac <= min(1.0, 0.05 + 0.004 * k)           # (k adjacent gaps per row can be a near-tie)
+    if C == 128:        # the same rows through the path without the matrix-core workspace
+        _knn_check(x[:, :, :64], s, k, eps, mfma=False)
+
+
+def test_knn_exact_ties_lowest_index_first():
+    """Duplicated source points: equal distances - neighbours in the order of their indices, k exactly."""
+    rs = np.random.RandomState(1)
+    x = torch.from_numpy(rs.standard_normal((1, 3, 40)))
+    s = torch.from_numpy(rs.standard_normal((1, 3, 200)))
+    s[:, :, 150:] = s[:, :, :50]                       # points 150.. duplicate points 0..49
+    idx = ops.knn(x.to(DEV), s.to(DEV), 7).cpu()
+    srcf = s.float()
+    d = ((x.float()[:, :, :, None] - srcf[:, :, None, :]) ** 2).sum(1)            # [1, 40, 200], the kernel's fp32 form
+    got = d.gather(2, idx)
+    assert (got[..., 1:] >= got[..., :-1]).all()                                   # nearest first
+    same = got[..., 1:] == got[..., :-1]
+    assert same.any() and (idx[..., 1:][same] > idx[..., :-1][same]).all()          # ties: ascending index
+    kth = got[..., -1:]
+    assert ((d < kth).sum(-1) <= 7).all() and ((d <= kth).sum(-1) >= 7).all()

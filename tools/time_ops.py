@@ -43,6 +43,17 @@ def main():
         m0 = torch.randint(-1, n, (B, n), device=dev, generator=g)
         print(f'pose_from_matches: {t_ms(lambda: ops.pose_from_matches(k0, k1, m0)):.4f} ms')
         print(f'gt_matches: {t_ms(lambda: ops.gt_matches(k0, k1)):.4f} ms')
+    if not only or 'knn' in only:
+        # kNN graph helper (mdgat.py:8-32) at the frame size: C = 3 (coordinates) and C = 128 (feature space, matrix cores)
+        for C, k in ((3, 9), (3, 64), (128, 9), (128, 64)):
+            x = torch.randn(B, C, n, device=dev, generator=g) * (20 if C == 3 else 1)
+            s = torch.randn(B, C, n, device=dev, generator=g) * (20 if C == 3 else 1)
+            ms = t_ms(lambda: ops.knn(x, s, k))
+            # algorithmic bytes: (N + M) C 4 + N k 8; the C = 128 path also writes and reads the N x M matrix once
+            alg = B * ((2 * n) * C * 4 + n * k * 8)
+            mat = B * 2 * n * n * 4 if C == 128 else 0
+            print(f'knn C={C} k={k}: {ms:.4f} ms  (algorithmic {alg / ms / 1e6:.1f} GB/s; with the distance matrix {(alg + mat) / ms / 1e6:.1f} GB/s; '
+                  f'{B * n / ms / 1e3:.2f} M queries/s)')
     if only and 'sinkhorn' not in only:
         return
     scores = torch.randn(B, n, n, device=dev, generator=g) * 3
