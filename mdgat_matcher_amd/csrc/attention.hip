@@ -881,12 +881,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             ql[0] = *reinterpret_cast<const f16x8*>(p + 32);
             ql[1] = *reinterpret_cast<const f16x8*>(p + 48);
         }
-        f32x2 l2;
-        f32x16 Om, Ox;
-        int surplus = 0;
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
-        // (the pass is redone once, with the tie-break, when one of its rows kept more than k logits: topk_break_ties)
-        for (bool redo = false;; redo = true) {
         f32x16 S[NBLK];
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
@@ -927,15 +922,16 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
         m = comm.rmax(m);
         const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
-        if (TAP) {      // the TAP build counts first, so that the selection it records is final
+        {
+            // exact ties at the k-th place (topk_break_ties): this kernel counts what the threshold keeps BEFORE its pass
+            // (a pass redone after the fact costs it 40 spilled registers, and a probe here is a workgroup exchange anyway)
             int c = 0;
 #pragma unroll
             for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
-            surplus = comm.rsum(c) - kexp;
+            topk_break_ties<KeyLayout32>(S, thr, comm.rsum(c) - kexp, comm, kw * NBLK * 32 + 8 * hi);
         }
-        if (redo || TAP) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, kw * NBLK * 32 + 8 * hi);
         if (TAP && qw + l31 < nq) {
             uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
 #pragma unroll
@@ -951,8 +947,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         }
 
         const float m11 = m - 11.0f;
-        l2 = f32x2{0.f, 0.f};
+        f32x2 l2 = {0.f, 0.f};
         int kept = 0;
+        f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
 #pragma unroll
@@ -976,9 +973,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 }
             }
         }
-        surplus = comm.rsum(kept) - kexp;
-        if (!comm.any(surplus > 0) || redo) break;  // (any() first: every wave of the workgroup takes part in it)
-        }
+        (void)kept;
         float l = l2[0] + l2[1];
         l += xor32(l);
         float* ob = obuf + wave * 17 * 64;
