@@ -146,8 +146,8 @@ def pmc_traffic(config, kernel):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', type=int, default=1, choices=sorted(CONFIGS),
                     help='BASELINE.json configs index (default 1 = the headline workload)')
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU per step (default: the configuration\'s)')

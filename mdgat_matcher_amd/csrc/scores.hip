@@ -20,6 +20,8 @@ struct ScoreArgs {
     const float* col_bias;    // [B][M] or NULL (the kNN helper: |s_j|^2, pointops.hip)
 };
 
+// BIAS: subtract col_bias[b][j] (the kNN helper; kept out of the score-matrix instance, whose epilogue is store-bound)
+template <bool BIAS>
 __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // As[128][SROW] | Bs[128][SROW]
     _Float16* As = smem;
@@ -80,13 +82,14 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const int j = j0 + 32 * wc + l31;
     if (j < a.M) {
         float* out = a.scores + ((size_t)b * a.N) * a.M + j;
-        const float bias = a.col_bias ? a.col_bias[(size_t)b * a.M + j] : 0.f;
+        const float bias = BIAS ? a.col_bias[(size_t)b * a.M + j] : 0.f;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int i = i0 + 64 * wr + 32 * t + mfma32_row(r, hi);
-                if (i < a.N) out[(size_t)i * a.M] = fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale - bias;
+                if (i < a.N) out[(size_t)i * a.M] = BIAS ? fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale - bias
+                                                        : fmaf(acx[t][r], MDGAT_SPLIT_INV, acc[t][r]) * a.scale;
             }
     }
 }
@@ -98,9 +101,11 @@ int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias};
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
-    static std::atomic<unsigned long long> optin;
-    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(scores_kernel), lds, optin, "scores LDS attribute")) return rc;
-    hipLaunchKernelGGL(scores_kernel, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
+    static std::atomic<unsigned long long> optin[2];
+    const void* kern = col_bias ? reinterpret_cast<const void*>(scores_kernel<true>) : reinterpret_cast<const void*>(scores_kernel<false>);
+    if (int rc = mdgat_lds_optin(kern, lds, optin[col_bias != nullptr], "scores LDS attribute")) return rc;
+    if (col_bias) hipLaunchKernelGGL(scores_kernel<true>, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(scores_kernel<false>, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "scores launch");
 }
 

@@ -16,6 +16,7 @@
 // per-wave column partials are merged through LDS -> v_j.  Everything is kept in the base-2 log domain
 // (potentials carry a factor log2(e)) so each element costs v_exp_f32 without a pre-multiply.
 #include "common.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -248,7 +249,8 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // sums: in-lane over the wave's 16 rows, the 8 waves merged through LDS, the G workgroups through L2 as 8-byte
 // {epoch, value} granules (the data is the flag, two slot sets alternate by epoch parity; relaxed agent-scope atomics,
 // or non-temporal accesses once the partners have agreed that they share an XCD; partners are placed on one XCD for
-// speed only; bounded spins, a timeout poisons Z with NaN).
+// speed only; bounded spins, a timeout poisons the outputs with NaN and is reported by the handle's next call).  The
+// launch is a plain one when every workgroup has a CU of its own (launch_scaling), cooperative otherwise.
 struct SksArgs {
     const float* scores;
     const float* alpha_dev;
@@ -641,6 +643,13 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         float V[8];
 #pragma unroll
         for (int c = 0; c < 8; ++c) V[c] = (ran && gcol0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
+        // Z (base-2) = s + U + V with s = lg2(K) - u0 - v0 from the register block: the scores are not read a second time
+        // (67 MB per launch at B = 64).  K = exp2(s + u0 + v0) <= 1 carries s to ~1e-7; an entry that underflowed to 0
+        // (more than 126 octaves below its row maximum) is re-read.
+        const float dUr = Ur - u0r;                   // lane r
+        float dV[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) dV[c] = V[c] - v0[c];
         const bool ext = a.ext_mode >= 0;
         const bool inner = a.ext_mode >= MDGAT_EXTRACT_THRESHOLD;   // arg-max over the inner N x M block only
         const bool last_c = jc == GC - 1, last_r = jr == GR - 1;
@@ -653,11 +662,20 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             const int i = row0 + r;
             if (i < N) {
                 const float U = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, Ur), r));
+                const float dU = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dUr), r));
                 const float* row = S + (size_t)i * M;
                 float z[8];
+                bool under = false;
 #pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    z[c] = (gcol0 + c < M) ? (row[min(gcol0 + c, M - 1)] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm : -__builtin_inff();
+                for (int c = 0; c < 8; ++c) {
+                    under |= (gcol0 + c < M) && !(K[r][c] > 0.f);
+                    z[c] = (gcol0 + c < M) ? (lg2(K[r][c]) + dU + dV[c]) * MDGAT_LN2 - norm : -__builtin_inff();
+                }
+                if (__any(under)) {
+#pragma unroll
+                    for (int c = 0; c < 8; ++c)
+                        if ((gcol0 + c < M) && !(K[r][c] > 0.f)) z[c] = (row[gcol0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
+                }
                 const float zM = (alpha + U + VM) * MDGAT_LN2 - norm;
                 if (Zp) {
                     float* zr = Zp + (size_t)i * (M + 1);
@@ -939,11 +957,20 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
         a.cbest_val = reinterpret_cast<float*>(p);
     }
     void* args[] = {&a};
-    // cooperative launch: the runtime checks that all ngroups * P workgroups can be co-resident
     const void* kern = GC > 1 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, true, 16>)
                      : GR > 4 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 16>)
                               : reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 4>);
-    hipError_t e = hipLaunchCooperativeKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
+    // The workgroups of a pair wait for each other, so all of them must become resident.  A workgroup takes a whole CU
+    // (512 threads x 256 registers), and ngroups * P <= num_cu by construction: every workgroup gets a CU as soon as the
+    // stragglers of earlier launches leave - whatever else runs on the device is finite, and resident workgroups spinning on
+    // their partners do not keep others from being dispatched.  A plain launch therefore suffices, and it starts 20-30 us
+    // sooner than hipLaunchCooperativeKernel (measured at B = 64: 430 -> 397 us for launch + 100 iterations).  The bounded
+    // spins stay as the safety net (a partner that never arrives poisons the outputs and is reported on the next call);
+    // MDGAT_SK_COOPERATIVE=1 selects the cooperative launch, which makes the runtime check co-residency.
+    hipError_t e;
+    static const bool cooperative = getenv("MDGAT_SK_COOPERATIVE") != nullptr;
+    if (cooperative || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
+    else e = hipLaunchKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
     if (ex) {
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, a.error_word,
