@@ -591,8 +591,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g = lane >> 4;
+        const int l15 = lane & 15, g = lane >> 4;
     const int head = blockIdx.y;
     const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
     const int P = a.N + a.M;
@@ -639,12 +638,22 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             }
         }
     }
+    // The 16-query tiles of this workgroup are handed out dynamically (a counter in LDS): the threshold search of a tile
+    // takes 5 to 9 probes, and with a fixed four tiles per wave the workgroup would wait for its unluckiest wave.
+    int* next_tile = reinterpret_cast<int*>(Vs + 2 * 32 * VSTR);
+    if (tid == 0) *next_tile = 0;
     __syncthreads();
 
     QuadComm comm;
-    for (int q0 = blockIdx.x * 128; q0 < nq; q0 += gridDim.x * 128) {
-        const int qw = q0 + wave * 16;
-        if (qw >= nq) continue;             // wave-uniform; no barrier inside the loop
+    const int tiles_all = (nq + 15) >> 4;
+    const int tiles_wg = (tiles_all + gridDim.x - 1) / gridDim.x;      // this workgroup: tiles [blockIdx.x tiles_wg, ...)
+    for (;;) {
+        int t = 0;
+        if (lane == 0) t = atomicAdd(next_tile, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= tiles_wg) break;
+        const int qw = (blockIdx.x * tiles_wg + t) * 16;
+        if (qw >= nq) break;                // wave-uniform; no barrier inside the loop
         // query fragment: dims 8 g .. 8 g + 7 of query l15 (B operand), planes hi / lo
         f16x8 qh, ql;
         {
@@ -1149,7 +1158,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             // 512 keys in both frames: one wave = 16 queries, the row in four lanes
             int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
             if (qsplit > 4) qsplit = 4;
-            const size_t lds3 = ((size_t)2 * 4 * 512 * 8 + (size_t)64 * 520) * sizeof(_Float16);
+            const size_t lds3 = ((size_t)2 * 4 * 512 * 8 + (size_t)64 * 520) * sizeof(_Float16) + 16;    // + the tile counter
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<false>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true>),
