@@ -645,7 +645,10 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         for (int c = 0; c < 8; ++c) V[c] = (ran && gcol0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
         // Z (base-2) = s + U + V with s = lg2(K) - u0 - v0 from the register block: the scores are not read a second time
         // (67 MB per launch at B = 64).  K = exp2(s + u0 + v0) <= 1 carries s to ~1e-7; an entry that underflowed to 0
-        // (more than 126 octaves below its row maximum) is re-read.
+        // (more than 126 octaves below its row maximum) is re-read.  Only where the block's registers have room for it:
+        // in the kernels for more than 512 keypoints the longer live range of K costs 12 more spilled registers inside
+        // the iteration loop (N = 2048: 7.5 -> 9.1 us per iteration), so they read the scores again instead.
+        constexpr bool FROM_K = !TWO_D && GMAX == 4;
         const float dUr = Ur - u0r;                   // lane r
         float dV[8];
 #pragma unroll
@@ -665,16 +668,22 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 const float dU = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, dUr), r));
                 const float* row = S + (size_t)i * M;
                 float z[8];
-                bool under = false;
+                if (FROM_K) {
+                    bool under = false;
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                    under |= (gcol0 + c < M) && !(K[r][c] > 0.f);
-                    z[c] = (gcol0 + c < M) ? (lg2(K[r][c]) + dU + dV[c]) * MDGAT_LN2 - norm : -__builtin_inff();
-                }
-                if (__any(under)) {
+                    for (int c = 0; c < 8; ++c) {
+                        under |= (gcol0 + c < M) && !(K[r][c] > 0.f);
+                        z[c] = (gcol0 + c < M) ? (lg2(K[r][c]) + dU + dV[c]) * MDGAT_LN2 - norm : -__builtin_inff();
+                    }
+                    if (__any(under)) {
+#pragma unroll
+                        for (int c = 0; c < 8; ++c)
+                            if ((gcol0 + c < M) && !(K[r][c] > 0.f)) z[c] = (row[gcol0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
+                    }
+                } else {
 #pragma unroll
                     for (int c = 0; c < 8; ++c)
-                        if ((gcol0 + c < M) && !(K[r][c] > 0.f)) z[c] = (row[gcol0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
+                        z[c] = (gcol0 + c < M) ? (row[min(gcol0 + c, M - 1)] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm : -__builtin_inff();
                 }
                 const float zM = (alpha + U + VM) * MDGAT_LN2 - norm;
                 if (Zp) {
