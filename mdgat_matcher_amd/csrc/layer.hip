@@ -42,8 +42,8 @@ extern "C" int mdgat_debug_read(long long* out, int n) { return (int)hipMemcpyFr
 #define TRACE_OFF (5 * 17 * 1024 + (768 + 8 * 2112) * 4)
 __device__ __forceinline__ void trace_point(int slot) {
     extern __shared__ __attribute__((aligned(16))) char tsm[];
-    if ((threadIdx.x & 63) == 0) {
-        long long* tl = reinterpret_cast<long long*>(tsm + TRACE_OFF) + (threadIdx.x >> 6) * 256;
+    if ((threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) {     // waves 0 and 3 only (LDS is nearly full)
+        long long* tl = reinterpret_cast<long long*>(tsm + TRACE_OFF) + ((threadIdx.x >> 6) == 3) * 256;
         const int c = (int)tl[255];
         tl[c] = ((long long)slot << 48) | (__builtin_amdgcn_s_memtime() & 0xffffffffffffLL);
         tl[255] = c + 1;
@@ -129,8 +129,12 @@ __device__ __forceinline__ void for_units(F&& f) { for_each_unit(f, std::make_in
 // "at most YOUNGER outstanding" says exactly that (stores issued in between only make the wait stricter).
 template <int YOUNGER>
 __device__ __forceinline__ void stage_wait() {
+#ifndef KO_NOVM
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
+#endif
+#ifndef KO_NOBAR
     __syncthreads();
+#endif
 }
 // end of a PAIR of stages (last stage h1) that share one barrier: stages h1 + 1 and h1 + 2 must have landed, the copy of
 // stage h1 + 3 (issued during h1) may be in flight.  Needs NSLOT >= 5: stage h + 3 and h + 4 land in the slots of the pair before.
@@ -237,8 +241,8 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
 #ifdef LAYER_TRACE
     const bool trace_on = (blockIdx.x == 3 || blockIdx.x == gridDim.x - 2) && (wave == 0 || wave == 3) && DO_MLP == TRACE_MLP && MODE3 == 1;
     const int tbase = ((blockIdx.x != 3) * 2 + (wave == 3)) * 256;
-    long long* tlds = reinterpret_cast<long long*>(reinterpret_cast<char*>(smem) + TRACE_OFF) + wave * 256;
-    if (lane == 0) tlds[255] = 0;
+    long long* tlds = reinterpret_cast<long long*>(reinterpret_cast<char*>(smem) + TRACE_OFF) + (wave == 3) * 256;
+    if (lane == 0 && (wave == 0 || wave == 3)) tlds[255] = 0;
 #endif
     // stages of the tile: 16 row blocks of W1, 8 of W2, then the units of W3
     constexpr int NSTAGE = (DO_MLP ? 24 : 0) + NB3;
@@ -265,7 +269,11 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int gp = min(wave_pt0 + 2 * i + hi, a.R - 1);
+#ifdef KO_NOPRO
+            t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(gp & 15) * 128 + l31 * 4);
+#else
             t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gp * 128 + l31 * 4);
+#endif
         }
     };
     auto rows_to_tile = [&](const f32x4 (&t)[8]) __attribute__((always_inline)) {
@@ -622,7 +630,7 @@ template <int DO_MLP, int MODE3, int VW>
 int launch_layer_t(const LayerArgs& a, hipStream_t s) {
     const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + NWAVE * TILE_FLOATS) * sizeof(float)
 #ifdef LAYER_TRACE
-        + 8 * 256 * 8
+        + 2 * 256 * 8
 #endif
         ;
     static std::atomic<unsigned long long> optin;        // (one per template instance)
