@@ -55,41 +55,80 @@ __device__ __forceinline__ int xor32i(int v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)p[j];
-    // residual p - (float)h straight from the packed halves: one v_fma_mix_f32 per value instead of a conversion
-    // back and a subtraction (the kernels that use this are bound by their vector instruction count)
+    // residual p - (float)h straight from the packed halves and straight into the packed halves of l: one
+    // v_fma_mixlo/mixhi_f16 per value (the kernels that use this are bound by their vector instruction count)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 hp = __builtin_bit_cast(u32x4, h);
-    float r[8];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r[2 * j]) : "v"(p[2 * j]), "v"(hp[j]));
-        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[2 * j + 1]) : "v"(p[2 * j + 1]), "v"(hp[j]));
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) l[j] = (_Float16)r[j];
+    u32x4 lp;
+    // One block, fenced by wait states: the compiler's hazard recogniser does not look into inline asm, and both a
+    // 16-bit destination write and a transcendental result (the exponentials feed this directly) need a wait state
+    // before the register is used again.  (As eight separate asm statements this produced wrong residuals in some
+    // instances of the kernels - whichever the scheduler happened to interleave badly - and correct ones in others.)
+    asm("s_nop 0\n\t"
+        "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
+        "s_nop 0"
+        : "=&v"(lp[0]), "=&v"(lp[1]), "=&v"(lp[2]), "=&v"(lp[3])
+        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
+          "v"(hp[0]), "v"(hp[1]), "v"(hp[2]), "v"(hp[3]));
+    l = __builtin_bit_cast(f16x8, lp);
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers; `kept` counts the logits at or above it); the
-// row sum in two packed halves
-template <bool TOPK>
-__device__ __forceinline__ void softmax8(const float* s, float m11, float thr, float (&p)[8], f32x2& l2, int& kept) {
+// "s >= t" for two logits per instruction, as a number: clamp((s - t') 2^100) = 1 or 0, with t' the float just below
+// t (the product is exact inside the FMA, so every s >= t gives at least ulp 2^100 >= 1 and every s <= t' at most 0).
+// Compare / select / add-carry cost two instructions per logit and a lane mask in scalar registers each (the pass over a
+// row ran out of them and spilled); the indicator costs half an instruction, and counting it another half (v_pk_add).
+// ge_const(t) is the addend of the FMA.  Logits closer than 2^-90 to each other AND to zero count as tied (t' is kept
+// 2^-90 away from t); -inf pads give 0; t = -inf keeps every finite logit.
+#define MDGAT_GE_BIG 1.2676506002282294e30f      // 2^100
+__device__ __forceinline__ float ge_const(float t) {
+    const int b = __builtin_bit_cast(int, t);
+    const int bp = t > 0.f ? b - 1 : (b | (int)0x80000000) + 1;
+    const float tp = fminf(__builtin_bit_cast(float, bp), t - 0x1p-90f);
+    return t == -__builtin_inff() ? 3.0e38f : -tp * MDGAT_GE_BIG;
+}
+__device__ __forceinline__ f32x2 ge_ind(f32x2 s, float c) {
+    f32x2 d;
+    const f32x2 c2 = {c, c};
+    const unsigned long long big = 0x7180000071800000ull;       // {2^100, 2^100} in a scalar register pair
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0] clamp" : "=v"(d) : "v"(s), "s"(big), "v"(c2));
+    return d;
+}
+// p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers; gc = ge_const(threshold), `kept` counts the logits
+// at or above it in two packed halves); the row sum in two packed halves
+// PK = false (attention_topk_wide_kernel, which has no register to spare for the packed form): gc is the threshold
+// itself, compare and select; nothing is counted.
+template <bool TOPK, bool PK = true>
+__device__ __forceinline__ void softmax8(const float* s, float m11, float gc, float (&p)[8], f32x2& l2, f32x2& kept) {
 #pragma unroll
     for (int j = 0; j < 8; j += 2) {
-        const f32x2 d = f32x2{s[j], s[j + 1]} - f32x2{m11, m11};
+        const f32x2 s2 = {s[j], s[j + 1]};
+        const f32x2 d = s2 - f32x2{m11, m11};
         f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
-        if (TOPK) {
-            e[0] = (s[j] >= thr) ? e[0] : 0.f; e[1] = (s[j + 1] >= thr) ? e[1] : 0.f;
-            kept += (s[j] >= thr); kept += (s[j + 1] >= thr);
+        if (TOPK && !PK) {
+            e[0] = (s[j] >= gc) ? e[0] : 0.f; e[1] = (s[j + 1] >= gc) ? e[1] : 0.f;
+        } else if (TOPK) {
+            const f32x2 ind = ge_ind(s2, gc);
+            e *= ind;
+            kept += ind;
         }
         p[j] = e[0]; p[j + 1] = e[1];
         l2 += e;
     }
 }
+__device__ __forceinline__ int kept_count(f32x2 kept) { return (int)(kept[0] + kept[1] + 0.5f); }
 
 // How the two lanes of a row (and, in the split-key kernel, the two waves of a row) combine per-row
 // partial results.  WaveComm: the row lives in one wave (lanes l, l ^ 32).
 struct WaveComm {
     static constexpr bool LOCAL_VOTE = true;     // any() is one wave-level ballot
+    static constexpr bool PACKED_COUNT = true;   // topk_threshold counts with ge_ind()
     __device__ __forceinline__ float rsum(float v) { return v + xor32(v); }
     __device__ __forceinline__ int rsum(int v) { return v + xor32i(v); }
     __device__ __forceinline__ float rmin(float v) { return fminf(v, xor32(v)); }
@@ -107,6 +146,7 @@ struct WaveComm {
 // QuadComm: the row lives in four lanes of one wave (l & 15 = query; 16x16 MFMA fragments).
 struct QuadComm {
     static constexpr bool LOCAL_VOTE = true;
+    static constexpr bool PACKED_COUNT = true;
     __device__ __forceinline__ float rsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
     __device__ __forceinline__ int rsum(int v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
     __device__ __forceinline__ float rmin(float v) { v = fminf(v, __shfl_xor(v, 16, 64)); return fminf(v, __shfl_xor(v, 32, 64)); }
@@ -166,29 +206,44 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
     }
     const float inv_sd = 1.0f / sd;
-    // count(s >= t) without the VCC-serialised compare/add-carry chain: the sign bits of s - t are shifted into
-    // four independent accumulators (v_alignbit) and counted 32 at a time (v_bcnt)
+    // count(s >= t): the indicator of ge_ind() summed in four independent packed accumulators, one instruction per
+    // logit in all (was two: v_sub + a sign bit shifted into a register by v_alignbit)
     auto count_local = [&](float t) {
-        int below = 0;
-        unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+        if (!Comm::PACKED_COUNT) {
+            // sign bits of s - t shifted into four accumulators (v_alignbit), counted 32 at a time: two instructions
+            // per logit, but fewer live registers than the packed form below
+            int below = 0;
+            unsigned acc0 = 0, acc1 = 0, acc2 = 0, acc3 = 0;
+#pragma unroll
+            for (int jb = 0; jb < NBLK; ++jb) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 4) {
+                    const float d0 = S[jb][r + 0] - t, d1 = S[jb][r + 1] - t, d2 = S[jb][r + 2] - t, d3 = S[jb][r + 3] - t;
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc0) : "v"(d0));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc1) : "v"(d1));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc2) : "v"(d2));
+                    asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc3) : "v"(d3));
+                }
+                if ((jb & 7) == 7 || jb == NBLK - 1) {
+                    below += __builtin_popcount(acc0) + __builtin_popcount(acc1) + __builtin_popcount(acc2) + __builtin_popcount(acc3);
+                    acc0 = acc1 = acc2 = acc3 = 0;
+                }
+            }
+            return 16 * NBLK - below;
+        }
+        const float gc = ge_const(t);
+        f32x2 a0 = {0.f, 0.f}, a1 = a0, a2 = a0, a3 = a0;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
 #pragma unroll
-            for (int r = 0; r < 16; r += 4) {
-                // four independent chains, kept interleaved (the scheduler would otherwise run them one after the other)
-                const float d0 = S[jb][r + 0] - t, d1 = S[jb][r + 1] - t, d2 = S[jb][r + 2] - t, d3 = S[jb][r + 3] - t;
-                // (volatile asm keeps this order; the builtin form gets re-associated into one chain per accumulator)
-                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc0) : "v"(d0));
-                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc1) : "v"(d1));
-                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc2) : "v"(d2));
-                asm volatile("v_alignbit_b32 %0, %0, %1, 31" : "+v"(acc3) : "v"(d3));
-            }
-            if ((jb & 7) == 7 || jb == NBLK - 1) {     // 4 x 32 sign bits collected
-                below += __builtin_popcount(acc0) + __builtin_popcount(acc1) + __builtin_popcount(acc2) + __builtin_popcount(acc3);
-                acc0 = acc1 = acc2 = acc3 = 0;
+            for (int r = 0; r < 16; r += 8) {
+                const f32x2 i0 = ge_ind(f32x2{S[jb][r + 0], S[jb][r + 1]}, gc), i1 = ge_ind(f32x2{S[jb][r + 2], S[jb][r + 3]}, gc);
+                const f32x2 i2 = ge_ind(f32x2{S[jb][r + 4], S[jb][r + 5]}, gc), i3 = ge_ind(f32x2{S[jb][r + 6], S[jb][r + 7]}, gc);
+                a0 += i0; a1 += i1; a2 += i2; a3 += i3;
             }
         }
-        return 16 * NBLK - below;                     // s - t < 0 (sign set) <=> s < t; -inf pads count as below
+        const f32x2 a = (a0 + a1) + (a2 + a3);
+        return (int)(a[0] + a[1] + 0.5f);             // -inf pads count as below
     };
     auto count_ge = [&](float t) { return comm.rsum(count_local(t)); };
     float thr = -INF;
@@ -254,10 +309,20 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     if (state == 0) { thr = lo; state = 1; }         // (probe cap; not reached, see the bisection above)
     if (comm.any(state == 2)) {   // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
         float mx = -INF;
+        const float gch = ge_const(hv);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; mx = fmaxf(mx, s < hv ? s : -INF); }
+            for (int r = 0; r < 16; r += 2) {
+                if (!Comm::PACKED_COUNT) {
+                    mx = fmaxf(mx, fmaxf(S[jb][r] < hv ? S[jb][r] : -INF, S[jb][r + 1] < hv ? S[jb][r + 1] : -INF));
+                    continue;
+                }
+                // logits at or above hv are pushed to -3e38 (indicator times -3e38 added), the rest pass unchanged
+                const f32x2 s2 = {S[jb][r], S[jb][r + 1]};
+                const f32x2 v = ge_ind(s2, gch) * f32x2{-3.0e38f, -3.0e38f} + s2;
+                mx = fmaxf(mx, fmaxf(v[0], v[1]));
+            }
         mx = comm.rmax(mx);
         if (state == 2) thr = mx;
     }
@@ -527,7 +592,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
                 // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
                 const float m11 = m - 11.0f;
-                int kept = 0;
+                const float gc = TOPK ? ge_const(thr) : 0.f;
+                f32x2 kept = {0.f, 0.f};
 #pragma unroll
                 for (int jb = 0; jb < NBLK; ++jb) {
                     if (EXACT || c0 + jb < wnb) {
@@ -536,7 +602,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             float p[8], s8[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
-                            softmax8<TOPK>(s8, m11, thr, p, l2, kept);
+                            softmax8<TOPK>(s8, m11, gc, p, l2, kept);
                             f16x8 ph, pl;
                             split8(p, ph, pl);
                             const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
@@ -551,7 +617,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 if (TOPK) {
                     // a row kept more than k logits (exact ties at the k-th place): redo the chunk - the whole row -
                     // once, with the tie-break (topk_break_ties)
-                    surplus = kept + xor32i(kept) - kexp;
+                    { const int kc = kept_count(kept); surplus = kc + xor32i(kc) - kexp; }
                     if (!redo && __any(surplus > 0)) {
                         redo = true;
                         c0 -= NBLK;
@@ -720,7 +786,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // ---- P' = 2048 exp2(s - m), masked; O = P' V with two key blocks per k-step ----
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
-        int kept = 0;
+        f32x2 kept = {0.f, 0.f};
+        const float gc = ge_const(thr);
         f32x4 Om[2], Ox[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) { Om[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ox[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -731,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 float p[8], s8[8];
 #pragma unroll
                 for (int i = 0; i < 8; ++i) s8[i] = S[c][8 * jj + i];
-                softmax8<true>(s8, m11, thr, p, l2, kept);
+                softmax8<true>(s8, m11, gc, p, l2, kept);
                 f16x8 ph, pl;
                 if (FAST) {
 #pragma unroll
@@ -753,6 +820,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                         Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, Om[t], 0, 0, 0);
                     }
                 }
+                // (left to itself the scheduler hoists the V^T reads and the splits of many steps: ~290 spilled registers)
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         float l_row = comm.rsum(l2[0] + l2[1]);
@@ -775,7 +844,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // logits are computed again (they do not survive the pass: there are not enough registers), the tied logits
         // with the largest key indices are found one at a time and the share of each is taken out of the rows just
         // written:  o <- (o l - P' v) / (l - P'),  l <- l - P'.  (A second pass instead costs the launch 10 % at B = 64.)
-        const int surplus = comm.rsum(kept) - a.topk;
+        const int surplus = comm.rsum(kept_count(kept)) - a.topk;
         if (comm.any(surplus > 0)) {
             logits(S);
             const float e = __builtin_amdgcn_exp2f(thr - m11);                  // P' of a tied logit, as softmax8 computes it
@@ -811,6 +880,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 template <int NW>
 struct WideComm {
     static constexpr bool LOCAL_VOTE = false;    // any() crosses waves through LDS: the vote rides on the count exchange
+    static constexpr bool PACKED_COUNT = false;  // (the kernel is at its register limit: 13 spilled registers this way, 250 with the packed count)
     float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
     int wave, lane, par;
     template <typename Op>
@@ -957,7 +1027,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
 
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
-        int kept = 0;
+        f32x2 kept = {0.f, 0.f};
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
@@ -970,7 +1040,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                     float p[8], s8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
-                    softmax8<true>(s8, m11, thr, p, l2, kept);
+                    softmax8<true, false>(s8, m11, thr, p, l2, kept);
                     f16x8 ph, pl;
                     split8(p, ph, pl);
                     const _Float16* vp = vg + gb * 32 + t * 16;
