@@ -24,6 +24,7 @@ __device__ __forceinline__ void filler(float (&v)[8]) {
 template <int READS, int NV, int THREADS, int AHEAD>
 __global__ __launch_bounds__(THREADS) void k16(const _Float16* w, const _Float16* act, float* out, int reps) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
+    const long long t_start = __builtin_amdgcn_s_memtime();
     const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, g = lane >> 4;
     for (int i = tid; i < 64 * ROWH / 8; i += THREADS) reinterpret_cast<f16x8*>(smem)[i] = reinterpret_cast<const f16x8*>(w)[i];
     f16x8 xh[8], xl[8];
@@ -59,6 +60,7 @@ __global__ __launch_bounds__(THREADS) void k16(const _Float16* w, const _Float16
                     if (READS >= 2) fl[kn & 7] = *reinterpret_cast<const f16x8*>(src + 256);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (READS == 0) asm volatile("" : "+v"(fh[ks]));      // (keeps the block from being hoisted out of the loop)
                 const f16x8 ph = fh[ks], pl = READS >= 2 ? fl[ks] : fh[ks];
                 x = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, xl[ks], x, 0, 0, 0); filler<NV>(v); __builtin_amdgcn_sched_barrier(0);
                 m = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, xh[ks], m, 0, 0, 0); filler<NV>(v); __builtin_amdgcn_sched_barrier(0);
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(THREADS) void k16(const _Float16* w, const _Float16
 #pragma unroll
     for (int j = 0; j < 8; ++j) s += v[j];
     if (s == 123.456f) out[tid] = s;
+    if (tid == 0 && blockIdx.x == 0) reinterpret_cast<long long*>(out)[64] = __builtin_amdgcn_s_memtime() - t_start;
 }
 
 // ---- SHAPE 32: block = 32 weight rows, 16 k-steps of 16 (fragment = 32 rows x 16 K: lane (row l31, half hi) reads 8 halves)
@@ -111,6 +114,7 @@ __global__ __launch_bounds__(THREADS) void k32(const _Float16* w, const _Float16
                     if (READS >= 2) fl[kn & 7] = *reinterpret_cast<const f16x8*>(src + 256);
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if (READS == 0) asm volatile("" : "+v"(fh[ks & 7]));
                 const f16x8 ph = fh[ks & 7], pl = READS >= 2 ? fl[ks & 7] : fh[ks & 7];
                 x = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, xl[ks], x, 0, 0, 0); filler<2 * NV>(v); __builtin_amdgcn_sched_barrier(0);
                 m = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, xh[ks], m, 0, 0, 0); filler<2 * NV>(v); __builtin_amdgcn_sched_barrier(0);
@@ -148,8 +152,12 @@ void run() {
     const double kp = THREADS / 64 * SHAPE;
     const double flop = 2.0 * 3 * 256 * 256 * kp * reps * blocks;
     const double us_tile128 = ms * 1e3 / reps * 128.0 / kp;
-    printf("shape %2d reads %d nv %d threads %3d ahead %d: %7.2f us per 256x256x128-keypoint tile, %6.1f TFLOP/s = %4.1f %% of 2.5 PF\n",
+    long long ticks = 0;
+    (void)hipMemcpy(&ticks, reinterpret_cast<char*>(out) + 512, 8, hipMemcpyDeviceToHost);
+    printf("shape %2d reads %d nv %d threads %3d ahead %d: %7.2f us per 256x256x128-keypoint tile, %6.1f TFLOP/s = %4.1f %% of 2.5 PF",
            SHAPE, READS, NV, THREADS, AHEAD, us_tile128, flop / (ms * 1e-3) * 1e-12, flop / (ms * 1e-3) / 2.5e15 * 100);
+    if (SHAPE == 16) printf("   s_memtime: %.0f ticks per us, %.1f ticks per MFMA and wave", ticks / (ms * 1e3), (double)ticks / (3.0 * 8 * 16 * reps));
+    printf("\n");
 }
 
 
@@ -248,6 +256,7 @@ int main() {
         (void)hipMemcpy(act, hw, na * 2, hipMemcpyHostToDevice);
         delete[] hw;
     }
+    run<16, 0, 0, 512, 3>(); run<32, 0, 0, 512, 3>(); run<16, 0, 0, 256, 3>(); run<32, 0, 0, 256, 3>();
     run<16, 1, 0, 512, 3>(); run<16, 2, 0, 512, 3>(); run<16, 2, 0, 256, 3>();
     run<16, 2, 1, 512, 3>(); run<16, 2, 2, 512, 3>(); run<16, 2, 3, 512, 3>();
     run<32, 2, 0, 512, 3>(); run<32, 2, 0, 256, 3>(); run<32, 2, 2, 256, 3>(); run<32, 2, 2, 512, 3>();
