@@ -55,29 +55,22 @@ __device__ __forceinline__ int xor32i(int v) { return __shfl_xor(v, 32, 64); }
 __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) h[j] = (_Float16)p[j];
-    // residual p - (float)h straight from the packed halves and straight into the packed halves of l: one
-    // v_fma_mixlo/mixhi_f16 per value (the kernels that use this are bound by their vector instruction count)
+    // residual p - (float)h straight from the packed halves: one v_fma_mix_f32 per value instead of a conversion
+    // back and a subtraction (the kernels that use this are bound by their vector instruction count).
+    // (Measured and dropped: v_fma_mixlo_f16 / v_fma_mixhi_f16 writing the residual halves directly - 8 instead of 12
+    // instructions per 8 values, but a 16-bit destination write needs wait states the hazard recogniser does not supply
+    // for inline asm (wrong residuals in some kernel instances), and as one fenced block the scheduler cannot interleave
+    // it: attention_topk16_kernel 154 -> 161 us, attention_stream_kernel 65.5 -> 66.7 us.)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     const u32x4 hp = __builtin_bit_cast(u32x4, h);
-    u32x4 lp;
-    // One block, fenced by wait states: the compiler's hazard recogniser does not look into inline asm, and both a
-    // 16-bit destination write and a transcendental result (the exponentials feed this directly) need a wait state
-    // before the register is used again.  (As eight separate asm statements this produced wrong residuals in some
-    // instances of the kernels - whichever the scheduler happened to interleave badly - and correct ones in others.)
-    asm("s_nop 0\n\t"
-        "v_fma_mixlo_f16 %0, %4, 1.0, -%12 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %1, %6, 1.0, -%13 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %2, %8, 1.0, -%14 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixlo_f16 %3, %10, 1.0, -%15 op_sel:[0,0,0] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %0, %5, 1.0, -%12 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %1, %7, 1.0, -%13 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %2, %9, 1.0, -%14 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "v_fma_mixhi_f16 %3, %11, 1.0, -%15 op_sel:[0,0,1] op_sel_hi:[0,0,1]\n\t"
-        "s_nop 0"
-        : "=&v"(lp[0]), "=&v"(lp[1]), "=&v"(lp[2]), "=&v"(lp[3])
-        : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]), "v"(p[4]), "v"(p[5]), "v"(p[6]), "v"(p[7]),
-          "v"(hp[0]), "v"(hp[1]), "v"(hp[2]), "v"(hp[3]));
-    l = __builtin_bit_cast(f16x8, lp);
+    float r[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r[2 * j]) : "v"(p[2 * j]), "v"(hp[j]));
+        asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r[2 * j + 1]) : "v"(p[2 * j + 1]), "v"(hp[j]));
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) l[j] = (_Float16)r[j];
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // "s >= t" for two logits per instruction, as a number: clamp((s - t') 2^100) = 1 or 0, with t' the float just below
@@ -172,6 +165,9 @@ struct QuadComm {
 template <int NBLK, bool EXACT, typename Comm>
 __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
     const float INF = __builtin_inff();
+    // the packed indicator form needs the logits in vector registers proper: not the 256-logit instance (half of its
+    // row lives in accumulation registers) and not the split-key kernel (no register to spare)
+    constexpr bool PACKED = Comm::PACKED_COUNT && NBLK <= 8;
     float smin = INF, sum = 0.f, sq = 0.f;
     float mu, sd;
     if (EXACT) {
@@ -209,7 +205,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     // count(s >= t): the indicator of ge_ind() summed in four independent packed accumulators, one instruction per
     // logit in all (was two: v_sub + a sign bit shifted into a register by v_alignbit)
     auto count_local = [&](float t) {
-        if (!Comm::PACKED_COUNT) {
+        if (!PACKED) {
             // sign bits of s - t shifted into four accumulators (v_alignbit), counted 32 at a time: two instructions
             // per logit, but fewer live registers than the packed form below
             int below = 0;
@@ -314,7 +310,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
-                if (!Comm::PACKED_COUNT) {
+                if (!PACKED) {
                     mx = fmaxf(mx, fmaxf(S[jb][r] < hv ? S[jb][r] : -INF, S[jb][r + 1] < hv ? S[jb][r + 1] : -INF));
                     continue;
                 }
@@ -611,6 +607,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
                             Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
                             Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                            // (dynamic layers: left to itself the scheduler hoists the V^T reads and splits of many steps
+                            // over the indicator arithmetic - hundreds of spilled registers in the 512-register instance)
+                            if (TOPK) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
