@@ -18,6 +18,16 @@
 #include "common.hpp"
 #include <cstdlib>
 
+#ifdef SK_TRACE
+// phase trace of the cluster kernel (tools/ab_build.sh sinkhorn sktrace -DSK_TRACE; tools/sinkhorn_trace.py): s_memtime stamps
+// of waves 0 and 7 of workgroup 0 in iterations 40-47, 11 points per iteration
+__device__ long long g_sk_trace[2 * 8 * 12];
+extern "C" int mdgat_sk_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sk_trace), n * sizeof(long long)); }
+#define SK_TP(k) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7) && it >= 40 && it < 48) \
+    g_sk_trace[((wave == 7) * 8 + (it - 40)) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SK_TP(k) do {} while (0)
+#endif
 namespace {
 
 constexpr float NEG_BIG = -1.0e30f;   // finite stand-in for -inf (keeps a - b well defined)
@@ -469,6 +479,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
         for (int it = 0; it < a.iters; ++it) {
             // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
+            SK_TP(0);
             float psum = 0.f;
             if (RPW == 16) {
                 float racc[16];
@@ -479,6 +490,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
                     racc[r] = acc;
                 }
+                SK_TP(1);
                 psum = wave_sum16(racc, lane);                 // lane r: row r (lanes >= 16 are not used)
                 psum = lane < 16 ? psum : 0.f;
             } else {
@@ -505,6 +517,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
             ar = my_row_valid ? mu * __builtin_amdgcn_rcpf(fmaf(kbr, bM, psum)) : 0.f;
             const float dsum = wave_sum_dpp(kbr * ar);
+            SK_TP(2);
             // ---- column update, wave-local part (mdgat.py:284): sum_i K_ij a_i over this wave's rows ----
             float q[8];
 #pragma unroll
@@ -515,13 +528,16 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
                 for (int c = 0; c < 8; ++c) q[c] = fmaf(K[r][c], arr, q[c]);
             }
+            SK_TP(3);
             {
                 f32x4* qw = reinterpret_cast<f32x4*>(colp + wave * 512 + col0);
                 qw[0] = f32x4{q[0], q[1], q[2], q[3]};
                 qw[1] = f32x4{q[4], q[5], q[6], q[7]};
                 if (lane == 0) pdust[wave] = dsum;
             }
+            SK_TP(4);
             __syncthreads();
+            SK_TP(5);
             // ---- merge the 8 waves, exchange with the row-slab partners, new column scalings ----
             ++cep;
             {
@@ -546,7 +562,9 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     for (int pp = 0; pp < GMAX; ++pp) vals[pp] = 0.f;
                     if (GR > 1) {
                         xstore(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
+                        SK_TP(6);
                         poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd);
+                        SK_TP(7);
                     }
                     float total = 0.f;
 #pragma unroll
@@ -576,7 +594,9 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     if (lane == 0) bvec[512] = nuM * __builtin_amdgcn_rcpf(fmaf(kc, aN, total));
                 }
             }
+            SK_TP(8);
             __syncthreads();
+            SK_TP(9);
             {
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(bvec + col0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(bvec + col0 + 4);
@@ -585,7 +605,11 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 for (int c = 0; c < 8; ++c) if (gcol0 + c >= M) b[c] = 0.f;
                 bM = bvec[512];
             }
+            SK_TP(10);
             // ---- fold scalings that left [2^-40, 2^40] back into K and the absorbed potentials (rare) ----
+            // (Measured: with the folds hoisted out of the iteration loop - an inner loop that only reads the block - the
+            // 128 register copies per iteration disappear from the N <= 512 kernel, for -1 %; the two larger kernels spill
+            // 75 / 195 registers instead of 59 / 49: N = 2048 +12 %.)
             if (flags[0] != 0) {                   // identical in all row-slab partners (same b for this column slab)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
