@@ -107,7 +107,9 @@ def qk_roofline(dev, B, n, reps=20):
     ms = a.elapsed_time(b) / reps
     flops = B * 2 * 4 * (2.0 * n * n * 32)            # Q K^T only: half of an attention launch
     useful = flops / (ms * 1e-3) / 1e12
-    return {'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
+    sus = ops.mfma_sustained(dev)
+    return {'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'], 'frac_of_sustained': SPLIT_FACTOR * useful / sus['tflops'],
+            'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
             'avg_launch_ms': ms, 'algorithmic_flops_per_launch': flops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'achieved': SPLIT_FACTOR * useful, 'frac': SPLIT_FACTOR * useful / PEAK_F16_MFMA_TFLOPS,
             'useful_tflops': useful, 'frac_useful': useful / PEAK_F16_MFMA_TFLOPS,
@@ -243,6 +245,15 @@ def main():
                         'frac': ach / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': dom['ms'],
                         'bytes_per_launch': dom['bytes'],
                         'note': 'bytes = the streamed-form algorithmic traffic 2 S (n+1)^2 4 B per pair (SURVEY 8d)'}
+            if roof['bound'] == 'mfma':
+                # the ceiling that exists on this box: the matrix cores under nothing but MFMAs on random operands (the chip
+                # clocks to its power budget: ~1.6 instead of 2.4 GHz on this pool), measured live (mdgat_mfma_probe)
+                sus = ops.mfma_sustained(dev)
+                roof.update({'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
+                             'frac_of_sustained': roof['achieved'] / sus['tflops'],
+                             'sustained_note': 'sustained_peak = f16 MFMA TFLOP/s of an MFMA-only loop on random operands on '
+                                               'this device, measured in this run (mdgat_mfma_probe); frac stays against the '
+                                               'dense peak at 2.4 GHz'})
             out['roofline'] = roof
             if n % 64 == 0 and att == 'fp32':
                 out['roofline_qk'] = qk_roofline(dev, B, n)

@@ -184,6 +184,15 @@ int mdgat_attention_sel(int B, int N, int M, int cross, int topk, const float* q
 int mdgat_attention_qk_probe(int B, int N, int M, int cross, const float* qkv, float* msg,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement only (bench.py, roofline.sustained_*): the rate this device SUSTAINS on v_mfma_f32_16x16x32_f16 with random
+ * operands resident in registers (two waves per SIMD, nothing but MFMAs, one workgroup pair per CU, `reps` x 24 MFMAs per
+ * wave) - the chip clocks to its power budget under such a load, well below the 2.4 GHz the dense peak is quoted at.
+ * workspace: >= 136 KB of device memory, 256-byte aligned.  ms_out: duration of the timed launch (HIP events on `stream`, synchronises),
+ * flops_out: FLOPs it executed, ticks_out: shader cycles (s_memtime) one wave spent in its loop.  Not part of the
+ * matching path; replaces nothing in the reference. */
+int mdgat_mfma_probe(int reps, void* workspace, size_t workspace_bytes, float* ms_out, double* flops_out,
+                     long long* ticks_out, void* stream);
+
 /* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
  * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */
 int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw,

@@ -73,17 +73,26 @@ __device__ __forceinline__ void split8(const float (&p)[8], f16x8& h, f16x8& l) 
     for (int j = 0; j < 8; ++j) l[j] = (_Float16)r[j];
 }
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-// "s >= t" for two logits per instruction, as a number: clamp((s - t') 2^100) = 1 or 0, with t' the float just below
-// t (the product is exact inside the FMA, so every s >= t gives at least ulp 2^100 >= 1 and every s <= t' at most 0).
-// Compare / select / add-carry cost two instructions per logit and a lane mask in scalar registers each (the pass over a
-// row ran out of them and spilled); the indicator costs half an instruction, and counting it another half (v_pk_add).
-// ge_const(t) is the addend of the FMA.  Logits closer than 2^-90 to each other AND to zero count as tied (t' is kept
-// 2^-90 away from t); -inf pads give 0; t = -inf keeps every finite logit.
+// Logits of magnitude below 2^-70 count as ZERO in every comparison of the top-k selection ("tied at zero"): a threshold t
+// in that zone stands for T0 = the float above -2^-70, and "s >= T0" is exactly "s is zero, tiny or positive".  Real-valued
+// data has no such logits other than exact zeros (zero key vectors); the rule exists so that the packed indicator below is
+// EXACT for every float - it cannot resolve differences below 2^-100.  Every threshold is canonicalised before it is
+// compared with anything (canon_thr), ties at a canonical T0 are the whole zone (tied_at).
+#define MDGAT_TINY 0x1p-70f
+#define MDGAT_T0 (-0x1.fffffep-71f)
+__device__ __forceinline__ float canon_thr(float t) { return fabsf(t) < MDGAT_TINY ? MDGAT_T0 : t; }
+__device__ __forceinline__ bool tied_at(float s, float thr) { return thr == MDGAT_T0 ? fabsf(s) < MDGAT_TINY : s == thr; }
+// "s >= t" for two logits per instruction, as a number: clamp((s - t') 2^100) = 1 or 0, with t' the float just below the
+// canonical t (the product is exact inside the FMA; |t| >= 2^-70 or t = T0, so every s >= t gives at least ulp(t) 2^100 >= 1
+// and every s <= t' at most 0).  Compare / select / add-carry cost two instructions per logit and a lane mask in scalar
+// registers each (the pass over a row ran out of them and spilled); the indicator costs half an instruction, and counting
+// it another half (v_pk_add).  ge_const(t), t canonical, is the addend of the FMA; -inf pads give 0; t = -inf keeps
+// every finite logit.
 #define MDGAT_GE_BIG 1.2676506002282294e30f      // 2^100
 __device__ __forceinline__ float ge_const(float t) {
     const int b = __builtin_bit_cast(int, t);
     const int bp = t > 0.f ? b - 1 : (b | (int)0x80000000) + 1;
-    const float tp = fminf(__builtin_bit_cast(float, bp), t - 0x1p-90f);
+    const float tp = __builtin_bit_cast(float, bp);
     return t == -__builtin_inff() ? 3.0e38f : -tp * MDGAT_GE_BIG;
 }
 __device__ __forceinline__ f32x2 ge_ind(f32x2 s, float c) {
@@ -205,6 +214,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     // count(s >= t): the indicator of ge_ind() summed in four independent packed accumulators, one instruction per
     // logit in all (was two: v_sub + a sign bit shifted into a register by v_alignbit)
     auto count_local = [&](float t) {
+        t = canon_thr(t);
         if (!PACKED) {
             // sign bits of s - t shifted into four accumulators (v_alignbit), counted 32 at a time: two instructions
             // per logit, but fewer live registers than the packed form below
@@ -305,13 +315,14 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     if (state == 0) { thr = lo; state = 1; }         // (probe cap; not reached, see the bisection above)
     if (comm.any(state == 2)) {   // thr = largest logit below hv: exactly k logits are >= it (more only on ties)
         float mx = -INF;
-        const float gch = ge_const(hv);
+        const float hvc = canon_thr(hv);
+        const float gch = ge_const(hvc);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 if (!PACKED) {
-                    mx = fmaxf(mx, fmaxf(S[jb][r] < hv ? S[jb][r] : -INF, S[jb][r + 1] < hv ? S[jb][r + 1] : -INF));
+                    mx = fmaxf(mx, fmaxf(S[jb][r] < hvc ? S[jb][r] : -INF, S[jb][r + 1] < hvc ? S[jb][r + 1] : -INF));
                     continue;
                 }
                 // logits at or above hv are pushed to -3e38 (indicator times -3e38 added), the rest pass unchanged
@@ -324,10 +335,11 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     }
     if (!EXACT && comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
         float e1 = INF;
+        const float loc = canon_thr(lo);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e1 = fminf(e1, s >= lo ? s : INF); }
+            for (int r = 0; r < 16; ++r) { const float s = S[jb][r]; e1 = fminf(e1, s >= loc ? s : INF); }
         e1 = comm.rmin(e1);
         float e2 = INF;
 #pragma unroll
@@ -339,7 +351,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         const int c2 = count_ge(e2);
         if (state == 3) thr = (c2 >= k) ? e2 : e1;
     }
-    return thr;
+    return canon_thr(thr);          // (what every later comparison uses)
 }
 
 // Exactly k keys per row (torch.topk keeps exactly k; which of several EQUAL logits it keeps is unspecified there -
@@ -366,7 +378,7 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cand = (S[jb][r] == thr && Layout::koff(jb, r) < below) ? Layout::koff(jb, r) : cand;   // (koff grows with (jb, r))
+            for (int r = 0; r < 16; ++r) cand = (tied_at(S[jb][r], thr) && Layout::koff(jb, r) < below) ? Layout::koff(jb, r) : cand;   // (koff grows with (jb, r))
         // (key indices are < 4096: exact as floats)
         const int top = (int)comm.rmax(cand >= 0 ? (float)(cand + lane_off) : -1.0f);
         if (surplus > 0) lim = top;
@@ -379,7 +391,7 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (S[jb][r] == thr && Layout::koff(jb, r) >= from) S[jb][r] = -__builtin_inff();
+                if (tied_at(S[jb][r], thr) && Layout::koff(jb, r) >= from) S[jb][r] = -__builtin_inff();
     }
 }
 

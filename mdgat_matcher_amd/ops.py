@@ -117,6 +117,21 @@ class QkProbe:
         return self.msg
 
 
+def mfma_sustained(device, reps: int = 4000) -> dict:
+    """Measurement only (bench.py ``roofline.sustained_*``): the f16 MFMA rate ``device`` sustains on random operands
+    (``mdgat_mfma_probe``: nothing but matrix instructions, two waves per SIMD) and the shader clock it runs at meanwhile."""
+    import ctypes as C
+    device = torch.device(device)
+    lib = _lib.load()
+    with torch.cuda.device(device):
+        ws = torch.empty(1 << 18, dtype=torch.uint8, device=device)
+        ms, flops, ticks = C.c_float(), C.c_double(), C.c_longlong()
+        _lib.check(lib.mdgat_mfma_probe(reps, ws.data_ptr(), ws.numel(), C.byref(ms), C.byref(flops), C.byref(ticks),
+                                        torch.cuda.current_stream(device).cuda_stream), 'mdgat_mfma_probe')
+    return {'tflops': flops.value / (ms.value * 1e-3) / 1e12, 'clock_ghz': ticks.value / (ms.value * 1e6),
+            'ms': ms.value, 'ticks_per_mfma_per_simd': ticks.value / (24.0 * reps * 2)}
+
+
 def pointwise(A: torch.Tensor, W: torch.Tensor, bias=None, relu=False, residual=None) -> torch.Tensor:
     """Conv1d(k=1) over points: A [rows, K] x W [Cout, K]^T (+bias, ReLU, +residual) -> [rows, Cout]."""
     _need_cuda(A, W)

@@ -222,6 +222,50 @@ def test_attention_topk_count_on_hard_distributions(n, k, dist):
         assert rep[0]['max_gap'] < 5e-6 * scale and rep[0]['rows'] <= 4, rep[0]
 
 
+@pytest.mark.parametrize('n,k', [(512, 128), (512, 64), (256, 128), (128, 64), (1024, 128)])
+@pytest.mark.parametrize('case', ['zero_keys', 'all_negative', 'tiny'])
+def test_attention_topk_threshold_at_zero_and_below(n, k, case):
+    """The kernels test "logit >= threshold" as clamp((s - t') 2^100) with t' the float below t (attention.hip, ge_ind).
+    Edge cases of that form: the k-th place falls into a block of logits that are EXACTLY zero (zero key vectors:
+    threshold 0, its predecessor is a denormal - the guard keeps t' 2^-90 away), every logit negative (predecessor of a
+    negative float is one step further from zero), and logits of magnitude 1e-30 (differences far below one but far
+    above 2^-100).  Exactly k keys per row, ties towards the lowest indices, message equal to the oracle's with that
+    selection forced."""
+    rs = np.random.RandomState(n + k + len(case))
+    qkv = torch.from_numpy(rs.standard_normal((1, 2 * n, 3, 4, 32)))
+    if case == 'zero_keys':
+        # fewer than k keys have positive logits for most rows: all but k // 2 keys of each frame are zero vectors
+        keep = k // 2
+        for base in (0, n):
+            zero = np.setdiff1d(np.arange(n), rs.choice(n, keep, replace=False))
+            qkv[:, base + zero, 1] = 0.0
+    elif case == 'all_negative':
+        qkv[:, :, 0, :, 0] = 40.0                              # q . k dominated by -40 * |k_0|
+        qkv[:, :, 1, :, 0] = -qkv[:, :, 1, :, 0].abs() - 0.5
+    else:
+        qkv[:, :, 1] *= 1e-30
+    out, (sel0, sel1) = ops.attention(qkv.to(DEV), n, n, False, topk=k, return_selection=True)
+    # the kernels without the tap keep every tied key in their pass and take the surplus out of the written rows again, one
+    # key at a time: with HUNDREDS of zero keys tied at the k-th place that correction is applied hundreds of times per row
+    # and its rounding adds up (measured 1.7e-5; a handful of ties, the realistic case: < 1e-6, test_attention_topk_with_ties)
+    assert (out - ops.attention(qkv.to(DEV), n, n, False, topk=k)).abs().max() < (5e-5 if case == 'zero_keys' else 1e-6)
+    out = out.cpu().double()
+    for lo, hi, sel in ((0, n, sel0.cpu()), (n, 2 * n, sel1.cpu())):
+        assert (sel.sum(-1) == k).all(), (case, int(sel.sum(-1).min()), int(sel.sum(-1).max()))
+        q, kk, v = (qkv[:, lo:hi, i].permute(0, 3, 2, 1) for i in range(3))
+        rep = []
+        ref, _ = O.dynamic_attention(q, kk, v, k, forced=sel, report=rep)
+        assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < 1e-5
+        assert rep[0]['bad_count'] == 0 and rep[0]['max_gap'] < 5e-6, rep[0]
+        if case == 'zero_keys':
+            # rows that need zero-logit keys to reach k take the lowest-indexed ones: the kept zero keys of a row form a
+            # prefix of the zero keys (in index order)
+            zmask = (qkv[0, lo:hi, 1].abs().sum((1, 2)) == 0)                       # [n]
+            kept_zero = sel[0][:, :, zmask]                                         # [H, n, zeros]
+            assert (kept_zero[..., :-1].long() >= kept_zero[..., 1:].long()).all()
+            assert kept_zero.any()
+
+
 @pytest.mark.parametrize('n', [256, 512, 1024])
 def test_attention_topk_unmeasured_bracket_ends(n):
     # Shapes whose rows fill whole 32-key blocks seed the threshold search from sub-sampled statistics and an
