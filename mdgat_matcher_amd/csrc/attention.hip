@@ -496,9 +496,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
         float m_run = NEG_INF;
         f32x2 l2 = {0.f, 0.f};
-        f32x16 Om, Ox;
+        f32x16 Om;                        // (one accumulator: the residual plane of V^T is unscaled too)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
         bool redo = false;                                      // dynamic layers: exact ties at the k-th place
         int surplus = 0;
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
@@ -521,17 +521,16 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
                         const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
                         const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                        f32x16 acc, acx;
+                        // one accumulator: the residual planes are unscaled (common.hpp); the small cross terms first
+                        f32x16 acc;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acc, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
-                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
-                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
-                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
-                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
                         if (!EXACT && last_partial && wb0 + c0 + jb == nblk - 1) {   // wave-uniform
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
@@ -592,7 +591,6 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         for (int r = 0; r < 16; ++r) {
                             const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
                             Om[r] *= f;
-                            Ox[r] *= f;
                         }
                     }
                 }
@@ -616,9 +614,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
                             const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
                             const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
-                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
-                            Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Om, 0, 0, 0);
                             Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
                             // (dynamic layers: left to itself the scheduler hoists the V^T reads and splits of many steps
                             // over the indicator arithmetic - hundreds of spilled registers in the 512-register instance)
                             if (TOPK) __builtin_amdgcn_sched_barrier(0);
@@ -635,7 +633,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         m_run = NEG_INF;
                         l2 = f32x2{0.f, 0.f};
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+                        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
                     }
                 }
             }
@@ -651,7 +649,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
             const int row = mfma32_row(r, hi);
             const float inv = __shfl(inv_l, row, 64);
             const int q = qw + row;
-            if (q < nq) out[(size_t)q * 128] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]) * inv;
+            if (q < nq) out[(size_t)q * 128] = Om[r] * inv;
         }
     }
 }
@@ -752,6 +750,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                     // A operand: key l15 of the block, dims 8 g ..; (key & 7) = (l15 & 7): the swizzle is a per-lane constant
                     const f16x8 kh = *reinterpret_cast<const f16x8*>(kfrag_h + blk * (16 * 64));
                     const f16x8 kl = *reinterpret_cast<const f16x8*>(kfrag_l + blk * (16 * 64));
+                    // (the residual planes are unscaled, common.hpp; two accumulators all the same: three DEPENDENT 16x16x32
+                    // products in a row cost this kernel more than the add they save - 148-152 -> 151-156 us per launch)
                     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acx = {0.f, 0.f, 0.f, 0.f};
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, acc, 0, 0, 0);
                     if (!FAST) {
@@ -759,7 +759,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                         acx = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, acx, 0, 0, 0);
                     }
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) S[c][4 * j + r] = FAST ? acc[r] : fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
+                    for (int r = 0; r < 4; ++r) S[c][4 * j + r] = FAST ? acc[r] : acc[r] + acx[r];
                 }
             }
         };
@@ -799,9 +799,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         f32x2 l2 = {0.f, 0.f};
         f32x2 kept = {0.f, 0.f};
         const float gc = ge_const(thr);
-        f32x4 Om[2], Ox[2];
+        f32x4 Om[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) { Om[t] = f32x4{0.f, 0.f, 0.f, 0.f}; Ox[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        for (int t = 0; t < 2; ++t) Om[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
 #pragma unroll
@@ -817,19 +817,24 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                     pl = ph;
                 } else split8(p, ph, pl);
                 const int key0 = (4 * c + 2 * jj) * 16 + 4 * g;  // this lane's keys: key0 .. key0 + 3 and key0 + 16 .. key0 + 19
+                f16x8 vh[2], vl[2];
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {                   // dims 16 t + l15
                     const _Float16* vp = Vs + (16 * t + l15) * VSTR + key0;
-                    f16x8 vh, vl;
                     const f16x4 vh0 = *reinterpret_cast<const f16x4*>(vp), vh1 = *reinterpret_cast<const f16x4*>(vp + 16);
                     const f16x4 vl0 = *reinterpret_cast<const f16x4*>(vp + 32 * VSTR), vl1 = *reinterpret_cast<const f16x4*>(vp + 32 * VSTR + 16);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) { vh[i] = vh0[i]; vh[4 + i] = vh1[i]; vl[i] = vl0[i]; vl[4 + i] = vl1[i]; }
-                    Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, Om[t], 0, 0, 0);
-                    if (!FAST) {
-                        Ox[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, Ox[t], 0, 0, 0);
-                        Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, Om[t], 0, 0, 0);
-                    }
+                    for (int i = 0; i < 4; ++i) { vh[t][i] = vh0[i]; vh[t][4 + i] = vh1[i]; vl[t][i] = vl0[i]; vl[t][4 + i] = vl1[i]; }
+                }
+                // one accumulator per dim half (the residual plane of V^T is unscaled); the two halves alternate so that no
+                // product waits for the one before it
+#pragma unroll
+                for (int t = 0; t < 2; ++t) Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh[t], Om[t], 0, 0, 0);
+                if (!FAST) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl[t], Om[t], 0, 0, 0);
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) Om[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh[t], Om[t], 0, 0, 0);
                 }
                 // (left to itself the scheduler hoists the V^T reads and the splits of many steps: ~290 spilled registers)
                 __builtin_amdgcn_sched_barrier(0);
@@ -845,8 +850,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             const float inv = __shfl(inv_l, row, 64);
             const int q = qw + row;
             if (q < nq) {
-                out[(size_t)q * 128] = fmaf(Ox[0][r], MDGAT_SPLIT_INV, Om[0][r]) * inv;
-                out[(size_t)q * 128 + 16] = fmaf(Ox[1][r], MDGAT_SPLIT_INV, Om[1][r]) * inv;
+                out[(size_t)q * 128] = Om[0][r] * inv;
+                out[(size_t)q * 128 + 16] = Om[1][r] * inv;
             }
         }
         if (TAP) continue;
@@ -873,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                         for (int t = 0; t < 2; ++t) {
                             const _Float16* vp = Vs + (16 * t + l15) * VSTR + x;
                             const float vh = (float)vp[0], vl = (float)vp[32 * VSTR];
-                            const float c = FAST ? ph * vh : fmaf(ph * vl, MDGAT_SPLIT_INV, fmaf(pl, vh, ph * vh));
+                            const float c = FAST ? ph * vh : fmaf(ph, vl, fmaf(pl, vh, ph * vh));
                             float* o = out + (size_t)(qw + row) * 128 + 16 * t;
                             *o = (*o * lr - c) / (lr - er);
                         }
@@ -983,17 +988,15 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
                 const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
                 const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                f32x16 acc, acx;
+                f32x16 acc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
+                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acc, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
-                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = fmaf(acx[r], MDGAT_SPLIT_INV, acc[r]);
                 if (last_partial && gb == nblk - 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -1039,9 +1042,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
         f32x2 kept = {0.f, 0.f};
-        f32x16 Om, Ox;
+        f32x16 Om;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             const int gb = kw * NBLK + jb;
@@ -1057,9 +1060,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                     const _Float16* vp = vg + gb * 32 + t * 16;
                     const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
                     const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
-                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
-                    Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Om, 0, 0, 0);
                     Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
+                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
                 }
             }
         }
@@ -1068,7 +1071,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         l += xor32(l);
         float* ob = obuf + wave * 17 * 64;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = fmaf(Ox[r], MDGAT_SPLIT_INV, Om[r]);
+        for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = Om[r];
         ob[16 * 64 + lane] = l;
         __syncthreads();
         if (kw == 0 && qw < nq) {
@@ -1131,9 +1134,9 @@ __global__ __launch_bounds__(256) void qkv_split_kernel(const float* qkv, _Float
         const float q = src[0] * (MDGAT_LOG2E * 0.17677669529663687f), k = src[128], v = src[256];
         _Float16 h, l;
         const size_t o = (((size_t)b * P + p) * 4 + head) * 64 + d;
-        mdgat_split(q, h, l); q16[o] = h; q16[o + 32] = l;
-        mdgat_split(k, h, l); k16[o] = h; k16[o + 32] = l;
-        mdgat_split(v, h, l); vt[0] = h; vt[(size_t)32 * PP] = l;
+        mdgat_split_unscaled(q, h, l); q16[o] = h; q16[o + 32] = l;
+        mdgat_split_unscaled(k, h, l); k16[o] = h; k16[o + 32] = l;
+        mdgat_split_unscaled(v, h, l); vt[0] = h; vt[(size_t)32 * PP] = l;
     }
 }
 

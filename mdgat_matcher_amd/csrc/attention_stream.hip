@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 Sc[2];           // logits of the chunk whose softmax is running: register r of block jb = key 32 jb + 16 (r >> 3) + 8 hi + (r & 7)
     f32x16 A, X;            // products of the block in flight (main, residual terms)
-    f32x16 Om = zero16, Ox = zero16;   // O^T: register r = dim 8 (r >> 2) + 4 hi + (r & 3) of query l31
+    f32x16 Om = zero16;     // O^T: register r = dim 8 (r >> 2) + 4 hi + (r & 3) of query l31 (one accumulator: the residual plane of V^T is unscaled)
     f32x2 l2 = {0.f, 0.f};
     float mxa = NEG_INF, mxb = NEG_INF;
 
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
 #pragma unroll
             for (int r = 8 * u; r < 8 * u + 8; r += 2) {
                 if (FAST) { Sc[jb][r] = A[r]; Sc[jb][r + 1] = A[r + 1]; continue; }
-                const f32x2 v = f32x2{X[r], X[r + 1]} * f32x2{MDGAT_SPLIT_INV, MDGAT_SPLIT_INV} + f32x2{A[r], A[r + 1]};
+                const f32x2 v = f32x2{X[r], X[r + 1]} + f32x2{A[r], A[r + 1]};      // (unscaled residual planes: common.hpp)
                 Sc[jb][r] = v[0]; Sc[jb][r + 1] = v[1];
             }
         } else {
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         const int pb = i & 1;
         if (k == 0) Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[pb], php[pb], Om, 0, 0, 0);
         else if (FAST) {}
-        else if (k == 1) Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[pb], php[pb], Ox, 0, 0, 0);
+        else if (k == 1) Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl[pb], php[pb], Om, 0, 0, 0);
         else Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh[pb], plp[pb], Om, 0, 0, 0);
     };
 
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
         });
         if (!__all(sc == 1.0f)) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { Om[r] *= sc; if (!FAST) Ox[r] *= sc; }
+            for (int r = 0; r < 16; ++r) Om[r] *= sc;
         }
         SLOT_END();
         // step 1 beside P.V of step 0, then the logits of block 0 combined (Sc[0] is free after vs(1, 0))
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     for (int g4 = 0; g4 < 4; ++g4) {
         f32x4 o;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (FAST ? Om[4 * g4 + j] : fmaf(Ox[4 * g4 + j], MDGAT_SPLIT_INV, Om[4 * g4 + j])) * inv_l;
+        for (int j = 0; j < 4; ++j) o[j] = Om[4 * g4 + j] * inv_l;
         *reinterpret_cast<f32x4_a*>(T + l31 * OROW + 8 * g4 + 4 * hi) = o;
     }
     float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32;

@@ -23,6 +23,14 @@ __device__ __forceinline__ void mdgat_split(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;
     l = (_Float16)((x - (float)h) * MDGAT_SPLIT_SCALE);
 }
+// The q / k / v operands of the attention kernels carry their residual UNSCALED, x = hi + lo with lo = f16(x - hi): for
+// |x| < 0.25 that is an f16 denormal, which the matrix cores honour exactly (tools/ubench/mfma_denorm.hip), its rounding
+// is at most 2^-25 absolute (the class of an fp32 product for operands of order one: tools/precision_probe.py, UNSCALED=1),
+// and hi.hi + hi.lo + lo.hi then accumulate in ONE register set - no second accumulator, no combine per logit.
+__device__ __forceinline__ void mdgat_split_unscaled(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
 #endif
 
 // row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
@@ -98,7 +106,7 @@ int launch_split_rows_pad(const float* w, _Float16* out, int rows, int Kin, int 
 
 // q/k/v of every point in the split-f16 operand layouts of the attention kernel (attention.hip)
 struct Qkv16 {
-    _Float16* q16;    // [B][P][4 heads][2 planes][32 dims], pre-scaled by log2(e) / sqrt(32)
+    _Float16* q16;    // [B][P][4 heads][2 planes][32 dims], pre-scaled by log2(e) / sqrt(32); planes = (hi, unscaled residual)
     _Float16* k16;    // [B][P][4][2][32]
     _Float16* vt16;   // [B][4][2][32][PP]: V transposed, keys contiguous; frame 1 starts at column Npad
     int Npad, PP;     // Npad = N rounded up to 32, PP = Npad + (M rounded up to 32)

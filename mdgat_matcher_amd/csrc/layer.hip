@@ -317,7 +317,10 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
     };
     auto load_bias8 = [&](const float* b) __attribute__((always_inline)) { load8(b + 8 * g, pbias); };
     // the split pv -> (h, l) in four steps (a fifth slot stays empty)
-    auto split_step = [&](int s_, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+    // SCALED: the residual plane carries the factor 2048 (operands of this kernel's own products); the q / k / v planes
+    // written for the attention kernels are UNSCALED (lo = f16(x - hi), f16 denormals included: the matrix cores honour
+    // them), so that all three products of a contraction there go into one accumulator
+    auto split_step = [&](int s_, f16x8& h, f16x8& l, bool SCALED = true) __attribute__((always_inline)) {
         typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
         if (s_ == 0) {
 #pragma unroll
@@ -331,8 +334,10 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                 asm("v_fma_mix_f32 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(pv[2 * j + 1]) : "v"(pv[2 * j + 1]), "v"(hp[j]));
             }
         } else if (s_ == 2) {
+            if (SCALED) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_SPLIT_SCALE;
+                for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_SPLIT_SCALE;
+            }
         } else if (s_ == 3) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) l[j] = (_Float16)pv[j];
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pv[j] *= MDGAT_LOG2E * 0.17677669529663687f;   // log2(e) / sqrt(32) on q
                 }
-            } else if (u <= 9) split_step(u - 5, sth, stl);
+            } else if (u <= 9) split_step(u - 5, sth, stl, false);
             else if (u == 10) {
                 *reinterpret_cast<f16x8_a*>(tile16 + l15 * QKROW + 8 * g) = sth;
                 *reinterpret_cast<f16x8_a*>(tile16 + l15 * QKROW + 32 + 8 * g) = stl;
@@ -402,7 +407,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                 else if (u == 3) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias_v[j >> 2];
-                } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl);
+                } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl, false);
                 else if (u == 10) {
                     _Float16* c0 = vsh(qb & 1, l15, 16 * wave + 4 * g);
                     *reinterpret_cast<f16x4_a*>(c0) = f16x4{sth[0], sth[1], sth[2], sth[3]};
@@ -418,7 +423,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                     else if (u == 3) {
 #pragma unroll
                         for (int j = 0; j < 8; ++j) pv[j] = o[j] + pbias_v[j >> 2];
-                    } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl);
+                    } else if (u >= 5 && u <= 9) split_step(u - 5, sth, stl, false);
                     else if (u == 10) {
                         // tile rows: 32 plane + dim; 16 keypoints (halves) per row
                         *reinterpret_cast<f16x4_a*>(tile16 + l15 * VROW + 4 * g) = f16x4{sth[0], sth[1], sth[2], sth[3]};
@@ -448,7 +453,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
                     const float bias = bias3[qb * 32 + dim];
                     _Float16 h[4], l[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) mdgat_split(o[4 * blk + j] + bias, h[j], l[j]);
+                    for (int j = 0; j < 4; ++j) mdgat_split_unscaled(o[4 * blk + j] + bias, h[j], l[j]);
                     if (fast) {
                         const int bb = p0 / P, pp = p0 - bb * P;
                         _Float16* row_h = a.vt16 + (((size_t)bb * 4 + head) * 2 * 32 + dim) * a.PP;

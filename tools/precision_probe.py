@@ -6,6 +6,8 @@ format and compares Z with the fp64 oracle.  Schemes:
   f16x3    a = hi + lo/2048 with hi, lo fp16; a.b ~ hi.hi + (hi.lo + lo.hi)/2048   (3 fp16 MFMAs)
   bf16x3   a = hi + lo with hi, lo bf16;      a.b ~ hi.hi + hi.lo + lo.hi          (3 bf16 MFMAs)
   f16      single fp16 operands
+  f16x3u   like f16x3 with UNSCALED residual planes lo = f16(a - hi): one accumulator for all three MFMAs, no combine
+           (UNSCALED=1 runs it for the q.k and p.v classes)
 Per-operand ablation of f16x3 (which of the cross terms does a product need for the 1e-4 bar?): a.b = hi.hi + a_hi.b_lo + a_lo.b_hi
   f16x2a   a single f16 (drops a_lo.b_hi), b split     - for P.V: probabilities as ONE f16, V split
   f16x2ac  the same with the row sum taken over the ROUNDED a (P.V only: softmax weights still sum to one)
@@ -46,6 +48,10 @@ def make_mm(scheme):
             ah, al = split_f16(a)
             bh, bl = split_f16(b)
             return ah @ bh + (ah @ bl + al @ bh) * (1.0 / 2048.0)
+        if scheme == 'f16x3u':       # unscaled residual planes: lo = f16(a - hi) (f16 denormals kept: the MFMA honours them)
+            ah, bh = a.half().float(), b.half().float()
+            al, bl = (a - ah).half().float(), (b - bh).half().float()
+            return ah @ bh + ah @ bl + al @ bh
         if scheme in ('f16x2a', 'f16x2ac'):
             ah = a.half().float()
             bh, bl = split_f16(b)
@@ -127,6 +133,8 @@ def main():
             combos = (('f32', 'f32', 'f32'), ('f16x3', 'f16x3', 'f16x3'), ('bf16x3', 'bf16x3', 'bf16x3'),
                       ('f16x3', 'f16x3', 'f16'), ('f16x3', 'f32', 'f32'), ('f32', 'f16x3', 'f32'),
                       ('f32', 'f32', 'f16x3'), ('f32', 'f32', 'f16'))
+            if os.environ.get('UNSCALED'):
+                combos = (('f16x3', 'f16x3', 'f16x3'), ('f16x3', 'f16x3u', 'f16x3'), ('f16x3', 'f16x3u', 'f16x3u'), ('f16x3u', 'f16x3u', 'f16x3u'))
             if os.environ.get('ABLATE'):
                 combos = (('f16x3', 'f16x3', 'f16x3'),
                           ('f16x3', 'f16x3', 'f16x2a'), ('f16x3', 'f16x3', 'f16x2ac'), ('f16x3', 'f16x3', 'f16x2b'),
