@@ -77,11 +77,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // in that zone stands for T0 = the float above -2^-70, and "s >= T0" is exactly "s is zero, tiny or positive".  Real-valued
 // data has no such logits other than exact zeros (zero key vectors); the rule exists so that the packed indicator below is
 // EXACT for every float - it cannot resolve differences below 2^-100.  Every threshold is canonicalised before it is
-// compared with anything (canon_thr), ties at a canonical T0 are the whole zone (tied_at).
+// compared with anything (canon_thr), ties at a canonical T0 are the whole zone (tie_top).
 #define MDGAT_TINY 0x1p-70f
 #define MDGAT_T0 (-0x1.fffffep-71f)
 __device__ __forceinline__ float canon_thr(float t) { return fabsf(t) < MDGAT_TINY ? MDGAT_T0 : t; }
-__device__ __forceinline__ bool tied_at(float s, float thr) { return thr == MDGAT_T0 ? fabsf(s) < MDGAT_TINY : s == thr; }
+// the logits tied at the canonical threshold thr are those in [thr, tie_top(thr)]
+__device__ __forceinline__ float tie_top(float thr) { return thr == MDGAT_T0 ? 0x1.fffffep-71f : thr; }
 // "s >= t" for two logits per instruction, as a number: clamp((s - t') 2^100) = 1 or 0, with t' the float just below the
 // canonical t (the product is exact inside the FMA; |t| >= 2^-70 or t = T0, so every s >= t gives at least ulp(t) 2^100 >= 1
 // and every s <= t' at most 0).  Compare / select / add-carry cost two instructions per logit and a lane mask in scalar
@@ -104,8 +105,8 @@ __device__ __forceinline__ f32x2 ge_ind(f32x2 s, float c) {
 }
 // p[j] = exp2(s[j] - m11), zero below the threshold (dynamic layers; gc = ge_const(threshold), `kept` counts the logits
 // at or above it in two packed halves); the row sum in two packed halves
-// PK = false (attention_topk_wide_kernel, which has no register to spare for the packed form): gc is the threshold
-// itself, compare and select; nothing is counted.
+// PK = false (the kernels whose row does not sit in vector registers proper: attention_topk_wide_kernel, the 512-logit
+// instance of attention_kernel): gc is the threshold itself, compare and select.
 template <bool TOPK, bool PK = true>
 __device__ __forceinline__ void softmax8(const float* s, float m11, float gc, float (&p)[8], f32x2& l2, f32x2& kept) {
 #pragma unroll
@@ -115,6 +116,7 @@ __device__ __forceinline__ void softmax8(const float* s, float m11, float gc, fl
         f32x2 e = {__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
         if (TOPK && !PK) {
             e[0] = (s[j] >= gc) ? e[0] : 0.f; e[1] = (s[j + 1] >= gc) ? e[1] : 0.f;
+            kept[0] += (s[j] >= gc) ? 1.f : 0.f; kept[1] += (s[j + 1] >= gc) ? 1.f : 0.f;     // (dead code where the caller ignores it)
         } else if (TOPK) {
             const f32x2 ind = ge_ind(s2, gc);
             e *= ind;
@@ -322,7 +324,8 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
                 if (!PACKED) {
-                    mx = fmaxf(mx, fmaxf(S[jb][r] < hvc ? S[jb][r] : -INF, S[jb][r + 1] < hvc ? S[jb][r + 1] : -INF));
+                    mx = fmaxf(mx, S[jb][r] < hvc ? S[jb][r] : -INF);
+                    mx = fmaxf(mx, S[jb][r + 1] < hvc ? S[jb][r + 1] : -INF);
                     continue;
                 }
                 // logits at or above hv are pushed to -3e38 (indicator times -3e38 added), the rest pass unchanged
@@ -371,6 +374,7 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
     // lim = smallest key index to drop: the surplus-th largest index among the tied logits, found one at a time (the
     // registers are only written after the loop: modifying S inside it costs the kernels dozens of spilled registers)
     int lim = 1 << 20;
+    const float thi = tie_top(thr);
 #pragma unroll 1
     while (comm.any(surplus > 0)) {
         const int below = lim - lane_off;
@@ -378,7 +382,7 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cand = (tied_at(S[jb][r], thr) && Layout::koff(jb, r) < below) ? Layout::koff(jb, r) : cand;   // (koff grows with (jb, r))
+            for (int r = 0; r < 16; ++r) cand = (S[jb][r] >= thr && S[jb][r] <= thi && Layout::koff(jb, r) < below) ? Layout::koff(jb, r) : cand;   // (koff grows with (jb, r))
         // (key indices are < 4096: exact as floats)
         const int top = (int)comm.rmax(cand >= 0 ? (float)(cand + lane_off) : -1.0f);
         if (surplus > 0) lim = top;
@@ -391,7 +395,7 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (tied_at(S[jb][r], thr) && Layout::koff(jb, r) >= from) S[jb][r] = -__builtin_inff();
+                if (S[jb][r] <= thi && Layout::koff(jb, r) >= from) S[jb][r] = -__builtin_inff();    // (logits below thr are not kept anyway)
     }
 }
 
@@ -496,9 +500,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
         float m_run = NEG_INF;
         f32x2 l2 = {0.f, 0.f};
-        f32x16 Om;                        // (one accumulator: the residual plane of V^T is unscaled too)
+        f32x16 Om, Ox;                    // (main and residual terms apart: two independent chains of products)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
         bool redo = false;                                      // dynamic layers: exact ties at the k-th place
         int surplus = 0;
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
@@ -521,16 +525,19 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
                         const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
                         const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                        // one accumulator: the residual planes are unscaled (common.hpp); the small cross terms first
-                        f32x16 acc;
+                        // (unscaled residual planes, common.hpp; two accumulators all the same: one chain of six dependent
+                        // products cost these kernels 5-50 %, most where a SIMD holds a single wave)
+                        f32x16 acc, acx;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acc, 0, 0, 0);
+                        for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+                        acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[r] += acx[r];
                         if (!EXACT && last_partial && wb0 + c0 + jb == nblk - 1) {   // wave-uniform
 #pragma unroll
                             for (int r = 0; r < 16; ++r)
@@ -591,6 +598,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         for (int r = 0; r < 16; ++r) {
                             const float f = __shfl(sc, mfma32_row(r, hi), 64);   // output row r belongs to that query
                             Om[r] *= f;
+                            Ox[r] *= f;
                         }
                     }
                 }
@@ -598,7 +606,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
 
                 // ---- P' = 2048 exp2(s - m) split to f16 in place, row sum, O += P' V ----
                 const float m11 = m - 11.0f;
-                const float gc = TOPK ? ge_const(thr) : 0.f;
+                constexpr bool PKPASS = NBLK <= 8;          // (the 512-logit instance: 2x slower with the packed pass)
+                const float gc = !TOPK ? 0.f : PKPASS ? ge_const(thr) : thr;
                 f32x2 kept = {0.f, 0.f};
 #pragma unroll
                 for (int jb = 0; jb < NBLK; ++jb) {
@@ -608,18 +617,18 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             float p[8], s8[8];
 #pragma unroll
                             for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
-                            softmax8<TOPK>(s8, m11, gc, p, l2, kept);
+                            softmax8<TOPK, PKPASS>(s8, m11, gc, p, l2, kept);
                             f16x8 ph, pl;
                             split8(p, ph, pl);
                             const _Float16* vp = Vs + l31 * VSTR + (c0 + jb) * 32 + t * 16 + 8 * hi;
                             const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
                             const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + 32 * VSTR);
-                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Om, 0, 0, 0);
-                            Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
                             Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                            Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                            Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Ox, 0, 0, 0);
                             // (dynamic layers: left to itself the scheduler hoists the V^T reads and splits of many steps
                             // over the indicator arithmetic - hundreds of spilled registers in the 512-register instance)
-                            if (TOPK) __builtin_amdgcn_sched_barrier(0);
+                            if (TOPK && PKPASS) __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -633,7 +642,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                         m_run = NEG_INF;
                         l2 = f32x2{0.f, 0.f};
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
+                        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
                     }
                 }
             }
@@ -649,7 +658,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
             const int row = mfma32_row(r, hi);
             const float inv = __shfl(inv_l, row, 64);
             const int q = qw + row;
-            if (q < nq) out[(size_t)q * 128] = Om[r] * inv;
+            if (q < nq) out[(size_t)q * 128] = (Om[r] + Ox[r]) * inv;
         }
     }
 }
@@ -988,15 +997,17 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
                 const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
                 const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
-                f32x16 acc;
+                f32x16 acc, acx;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acc, 0, 0, 0);
+                for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, qh[0], acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh0, ql[0], acx, 0, 0, 0);
                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, qh[1], acc, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh1, ql[1], acx, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl0, qh[0], acx, 0, 0, 0);
+                acx = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl1, qh[1], acx, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[r] += acx[r];
                 if (last_partial && gb == nblk - 1) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
@@ -1042,9 +1053,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
         f32x2 kept = {0.f, 0.f};
-        f32x16 Om;
+        f32x16 Om, Ox;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) Om[r] = 0.f;
+        for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             const int gb = kw * NBLK + jb;
@@ -1060,9 +1071,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                     const _Float16* vp = vg + gb * 32 + t * 16;
                     const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
                     const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
-                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Om, 0, 0, 0);
-                    Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Om, 0, 0, 0);
                     Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
+                    Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
+                    Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Ox, 0, 0, 0);
                 }
             }
         }
@@ -1071,7 +1082,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         l += xor32(l);
         float* ob = obuf + wave * 17 * 64;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = Om[r];
+        for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = Om[r] + Ox[r];
         ob[16 * 64 + lane] = l;
         __syncthreads();
         if (kw == 0 && qw < nq) {
