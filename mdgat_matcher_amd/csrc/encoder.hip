@@ -38,22 +38,25 @@ constexpr int OFF_D1 = OFF_D0 + 64 * RH48;         // 128 x RH64
 constexpr int OFF_EL = OFF_D1 + 128 * RH64;        // 2 x 32 x RH256
 constexpr int OFF_END = OFF_EL + 2 * 32 * RH256;   // then fp32: kenc0 w [32][4], b [32], biases
 
+// Eight waves = 256 keypoints per workgroup, one workgroup per CU (the weights fill the LDS): two waves per SIMD, so that one
+// wave's matrix instructions run beside the other's loads, splits and 32-byte row stores (four waves: 64 -> see DESIGN.md)
+constexpr int ENC_THREADS = 512;
 // copy `rows` rows of 2K halves (contiguous in memory) into padded LDS rows
 template <int K>
 __device__ __forceinline__ void copy_rows(const _Float16* g, _Float16* dst, int rows, int tid) {
     constexpr int CPR = 2 * K * 2 / 16, ROWH = 2 * K + 8;
-    for (int c = tid; c < rows * CPR; c += 256)
+    for (int c = tid; c < rows * CPR; c += ENC_THREADS)
         *reinterpret_cast<f32x4*>(dst + (c / CPR) * ROWH + (c % CPR) * 8) = *reinterpret_cast<const f32x4*>(g + (size_t)c * 8);
 }
 
-__global__ __launch_bounds__(256, 1) void encoder_kernel(EncArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wrow = perm32(l31);
-    const int pt = min(blockIdx.x * 128 + wave * 32 + l31, a.R - 1);
+    const int pt = min(blockIdx.x * (ENC_THREADS / 2) + wave * 32 + l31, a.R - 1);
     float* fl = reinterpret_cast<float*>(smem + OFF_END);
     float* k0w = fl;            // [32][4]
     float* k0b = fl + 128;      // [32]
@@ -239,6 +242,6 @@ int launch_encoder(const EncoderLaunch& p, hipStream_t s) {
     const size_t lds = (size_t)OFF_END * sizeof(_Float16) + 672 * sizeof(float);
     static std::atomic<unsigned long long> optin;
     if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(encoder_kernel), lds, optin, "encoder LDS attribute")) return rc;
-    hipLaunchKernelGGL(encoder_kernel, dim3((a.R + 127) / 128), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(encoder_kernel, dim3((a.R + ENC_THREADS / 2 - 1) / (ENC_THREADS / 2)), dim3(ENC_THREADS), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "encoder launch");
 }
