@@ -442,3 +442,13 @@ def test_knn_exact_ties_lowest_index_first():
     assert same.any() and (idx[..., 1:][same] > idx[..., :-1][same]).all()          # ties: ascending index
     kth = got[..., -1:]
     assert ((d < kth).sum(-1) <= 7).all() and ((d <= kth).sum(-1) >= 7).all()
+
+
+def test_mfma_sustained_probe():
+    """bench.py's ceiling measurement (mdgat_mfma_probe): a positive rate below the dense peak at 2.4 GHz, a plausible clock,
+    and about 16 cycles per 16x16x32 MFMA and SIMD (two waves take turns on the pipe)."""
+    r = ops.mfma_sustained(DEV, reps=500)
+    assert 200.0 < r['tflops'] < 2600.0, r
+    assert 0.5 < r['clock_ghz'] < 2.6, r
+    assert 15.5 < r['ticks_per_mfma_per_simd'] < 24.0, r
+
