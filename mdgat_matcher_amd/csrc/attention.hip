@@ -3,11 +3,11 @@
 // those, zero elsewhere).  The N x M logits / probabilities are never written to memory.
 //
 // Arithmetic: fp32-equivalent products on the f16 matrix cores.  Every operand x is carried as two
-// halves x = hi + lo / 2048 (hi = f16(x), lo = f16((x - hi) * 2048): 22 mantissa bits) and a product
-// is three v_mfma_f32_32x32x16_f16: hi.hi into the main fp32 accumulator, hi.lo + lo.hi into a second
-// one that is added with weight 1/2048.  The dropped lo.lo term is 2^-22 relative - the same class as
+// halves x = hi + lo (hi = f16(x), lo = f16(x - hi), the residual UNSCALED - f16 denormals included, which the
+// matrix cores honour: common.hpp; 22 mantissa bits for operands of order one) and a product is three
+// v_mfma_f32_32x32x16_f16: hi.hi, hi.lo and lo.hi.  The dropped lo.lo term is 2^-22 relative - the same class as
 // the rounding of an fp32 FMA chain (tools/precision_probe.py: max|dZ| 1.3e-5 either way) at 16/3 times
-// the rate of v_mfma_f32_32x32x2_f32.
+// the rate of v_mfma_f32_32x32x2_f32.  (The probabilities are carried times 2048 so that their residual is a normal f16.)
 //
 // gfx950 mapping.  One workgroup = 4 waves owns one (pair, frame, head): the head's K rows (hi | lo
 // halves, 144-byte padded rows) and V^T rows (keys contiguous, per plane) for all <= 512 keys are

@@ -13,7 +13,8 @@
 //   * the output is accumulated transposed, O^T = V^T P^T: a lane then holds 16 dims of ITS OWN query, and the
 //     online-softmax rescale is a plain multiply (no cross-lane traffic); the tile goes out through LDS as whole
 //     128-byte head slices.
-// Arithmetic is that of attention.hip: split f16 operands (x = hi + lo / 2048), three MFMAs per product.
+// Arithmetic is that of attention.hip: split f16 operands with unscaled residual planes (x = hi + lo, common.hpp), three
+// MFMAs per product.
 //
 // LDS chunk = four blocks of 32 rows x 128 B (K keys 0-31, K keys 32-63, V^T plane hi, V^T plane lo; a V^T row is
 // the 64 keys of one (plane, dim)).  A block is four 1 KB copy pieces (8 rows each); inside a piece the 16-byte
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
             for (int j = 0; j < 8; ++j) plp[pb][j] = (_Float16)pv[j];
         }
     };
-    // P.V product k of step i: O^T += V^T P^T (p' = hi + lo unscaled; the lo plane of V carries the factor 2048)
+    // P.V product k of step i: O^T += V^T P^T (p' = hi + lo and v = hi + lo, both residuals unscaled: one accumulator)
     auto pvm = [&](int i, int k) __attribute__((always_inline)) {
         if (QK_ONLY) return;
         const int pb = i & 1;
