@@ -5,9 +5,10 @@ import ctypes, os, sys, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mdgat_matcher_amd import ops, _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 dev = torch.device('cuda', 0)
 g = torch.Generator().manual_seed(0)
-scores = (torch.randn(B, 512, 512, generator=g) * 3).to(dev)
+scores = (torch.randn(B, N, N, generator=g) * 3).to(dev)
 for _ in range(3):
     Z = ops.sinkhorn(scores, 1.0, 100)
 torch.cuda.synchronize()
