@@ -21,6 +21,11 @@ def init_distributed(n_gpus_requested: int = 1, backend: str | None = None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
+    if os.environ.get('MDGAT_SHARE_DEVICE'):
+        # test hook (tests/test_gpu_forward.py::test_bench_two_ranks_one_gpu): every rank drives device 0 and the
+        # collectives run on gloo - the N > 1 control flow of bench.py on a box with a single GPU (RCCL refuses two ranks
+        # on one device)
+        local, backend = 0, 'gloo'
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
@@ -42,7 +47,12 @@ def partition(n_pairs: int, rank: int, world: int):
 
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.broadcast(blob, src=src)
+        if blob.is_cuda and dist.get_backend() != 'nccl':      # gloo: through host memory
+            host = blob.cpu()
+            dist.broadcast(host, src=src)
+            blob.copy_(host)
+        else:
+            dist.broadcast(blob, src=src)
     return blob
 
 
