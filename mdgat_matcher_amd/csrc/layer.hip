@@ -35,6 +35,7 @@
 // contiguous row" (what the memory system wants) and the fragment order (what the MFMAs want).
 // V uses the non-swapped product (a lane holds 4 consecutive keypoints of one dim) for the transposed V^T layout.
 #include <utility>
+#include <cstdlib>
 #include "common.hpp"
 #ifdef LAYER_TRACE
 __device__ long long g_dbg[8192];
@@ -72,7 +73,9 @@ constexpr int SLOT_CHUNKS = 17;
 constexpr int SLOT_BYTES = SLOT_CHUNKS * 1024;
 constexpr int SLOT_HALVES = SLOT_BYTES / 2;
 constexpr int NSLOT = 5, LOOKAHEAD = 3;
-constexpr int NWAVE = 8;                     // waves per workgroup (16 keypoints each): 128 keypoints, one workgroup per CU
+// waves per workgroup (16 keypoints each), template parameter NW: 8 (128 keypoints, two waves per SIMD: the throughput shape) or 4
+// (64 keypoints, one wave per SIMD: small batches, where a launch has fewer 128-keypoint tiles than half the CUs - a wave that has
+// its SIMD's matrix pipe to itself finishes its chain of 864 products sooner than two waves sharing it)
 constexpr int WPTS = 16;                     // keypoints per wave
 constexpr int TROW = 132;                    // floats per row of a wave's activation tile (128 channels + 16 B pad)
 constexpr int TILE_FLOATS = WPTS * TROW;     // [16 keypoints][TROW]: 8448 B per wave
@@ -105,17 +108,19 @@ struct LayerArgs {
 // 16-byte pieces.  Inline asm: the compiler must not know that LDS is written (it would order every later ds_read
 // behind the copy); completion is awaited explicitly (stage_wait) before the stage barrier.  The 3 copies of a
 // wave are issued one at a time between the matrix instructions of the running stage.
+template <int NW>
 __device__ __forceinline__ void stage_dma_slice(const _Float16* g, unsigned lds_addr, int wave, int lane, int i) {
-    const int c = min(wave + NWAVE * i, SLOT_CHUNKS - 1);  // (the last chunk is copied more than once: no branch)
+    const int c = min(wave + NW * i, SLOT_CHUNKS - 1);  // (the last chunk is copied more than once: no branch)
     // scalar base + per-lane 32-bit offset: the address arithmetic stays on the scalar unit
     const char* src = reinterpret_cast<const char*>(g) + c * 1024;
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
                  :: "s"(lds_addr + c * 1024), "v"(lane * 16), "s"(src) : "memory");
 }
-constexpr int DMA_SLICES = (SLOT_CHUNKS + NWAVE - 1) / NWAVE;
+template <int NW> constexpr int dma_slices() { return (SLOT_CHUNKS + NW - 1) / NW; }
+template <int NW>
 __device__ __forceinline__ void stage_dma(const _Float16* g, unsigned lds_addr, int wave, int lane) {
 #pragma unroll
-    for (int i = 0; i < DMA_SLICES; ++i) stage_dma_slice(g, lds_addr, wave, lane, i);
+    for (int i = 0; i < dma_slices<NW>(); ++i) stage_dma_slice<NW>(g, lds_addr, wave, lane, i);
 }
 // f(0), f(1), ... f(N - 1) with literal arguments (a `#pragma unroll` loop over large inlined bodies is not reliably
 // unrolled, and a rolled loop would index the register arrays of the epilogues dynamically)
@@ -138,8 +143,9 @@ __device__ __forceinline__ void stage_wait() {
 }
 // end of a PAIR of stages (last stage h1) that share one barrier: stages h1 + 1 and h1 + 2 must have landed, the copy of
 // stage h1 + 3 (issued during h1) may be in flight.  Needs NSLOT >= 5: stage h + 3 and h + 4 land in the slots of the pair before.
+template <int NW>
 __device__ __forceinline__ void end_of_pair(int h1, int nstage) {
-    if (h1 + 3 < nstage) stage_wait<DMA_SLICES>();
+    if (h1 + 3 < nstage) stage_wait<dma_slices<NW>()>();
     else stage_wait<0>();
 }
 
@@ -216,8 +222,10 @@ __device__ __forceinline__ void block_mma16(const _Float16* buf, int l15, int g,
 // DO_MLP 0: phase 3 only (first layer / no layers).  MODE3 1: q|k|v (12 units), 2: final projection (4).
 // VW 1 (MODE3 1, frames that are multiples of 128 keypoints): the V^T row pieces of the whole workgroup are gathered
 // in LDS, so that each (plane, dim) row goes out as 256 contiguous bytes instead of eight 32-byte pieces.
-template <int DO_MLP, int MODE3, int VW>
-__global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
+template <int DO_MLP, int MODE3, int VW, int NW>
+__global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
+    constexpr int NWAVE = NW, DMA_SLICES = dma_slices<NW>();
+    static_assert(!VW || NW == 8, "the V^T gather buffers are laid out for 128-keypoint workgroups");
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];   // 4 stage slots, 768 floats of biases, 8 tiles
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -253,7 +261,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
     };
     // copy of stage h + LOOKAHEAD, slice i (issued during stage h)
     auto copy_ahead = [&](int h, int i) __attribute__((always_inline)) {
-        if (h + LOOKAHEAD < NSTAGE) stage_dma_slice(stage_src(h + LOOKAHEAD), ldsb(h + LOOKAHEAD), wave, lane, i);
+        if (h + LOOKAHEAD < NSTAGE) stage_dma_slice<NW>(stage_src(h + LOOKAHEAD), ldsb(h + LOOKAHEAD), wave, lane, i);
     };
     TR(0);
     if (DO_MLP) {
@@ -490,7 +498,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             f32x4 tm[8], tx[8];
             rows_load(a.msg, tm);
             rows_load(a.x, tx);
-            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma(stage_src(h), ldsb(h), wave, lane); });
+            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma<NW>(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tm);
             for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[4 + ks], al[4 + ks]); });
             rows_to_tile(tx);                    // stays in the tile: residual of phase 2
@@ -528,7 +536,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             block_mma16<8, ROWH256>(bufp(2 * rb), l15, g, ah, al, acc[rb & 1].pm, acc[rb & 1].px, inter(2 * rb, 0));
             block_mma16<8, ROWH256>(bufp(2 * rb + 1), l15, g, ah, al, acc[rb & 1].qm, acc[rb & 1].qx, inter(2 * rb + 1, 24));
             TR(11);
-            end_of_pair(2 * rb + 1, NSTAGE);
+            end_of_pair<NW>(2 * rb + 1, NSTAGE);
             TR(12);
         });
 
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
             block_mma16<8, ROWH256>(bufp(H0 + 2 * ob), l15, g, hh, hl, acc[ob & 1].pm, acc[ob & 1].px, inter(H0 + 2 * ob, 0));
             block_mma16<8, ROWH256>(bufp(H0 + 2 * ob + 1), l15, g, hh, hl, acc[ob & 1].qm, acc[ob & 1].qx, inter(H0 + 2 * ob + 1, 24));
             TR(21);
-            end_of_pair(H0 + 2 * ob + 1, NSTAGE);
+            end_of_pair<NW>(H0 + 2 * ob + 1, NSTAGE);
             TR(22);
         });
         // the epilogue of the last unit (set 1) is not overlapped: phase 3 needs all of the new x
@@ -574,7 +582,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         {
             f32x4 tx[8];
             rows_load(a.x, tx);
-            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma(stage_src(h), ldsb(h), wave, lane); });
+            for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma<NW>(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tx);
         }
         for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, xnh[ks], xnl[ks]); });
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(64 * NWAVE) void layer_kernel(LayerArgs a) {
         if (MODE3 == 1 && q >= 8) unit_mma16<4, false, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         else unit_mma16<4, true, ROWH128>(cur, l15, g, xnh, xnl, acc[q & 1], inter);
         TR(32);
-        if ((q & 1) && q + 1 < NB3) end_of_pair(H0 + q, NSTAGE);
+        if ((q & 1) && q + 1 < NB3) end_of_pair<NW>(H0 + q, NSTAGE);
         else if (VW && q >= 10) __syncthreads();       // the gather buffers change hands every unit from here on
         TR(33);
     });
@@ -631,17 +639,18 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* w, _Float1
     }
 }
 
-template <int DO_MLP, int MODE3, int VW>
+template <int DO_MLP, int MODE3, int VW, int NW>
 int launch_layer_t(const LayerArgs& a, hipStream_t s) {
+    constexpr int NWAVE = NW;
     const size_t lds = (size_t)NSLOT * SLOT_BYTES + (768 + NWAVE * TILE_FLOATS) * sizeof(float)
 #ifdef LAYER_TRACE
         + 2 * 256 * 8
 #endif
         ;
     static std::atomic<unsigned long long> optin;        // (one per template instance)
-    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3, VW>), lds, optin, "layer LDS attribute")) return rc;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(layer_kernel<DO_MLP, MODE3, VW, NW>), lds, optin, "layer LDS attribute")) return rc;
     constexpr int TILE_PTS = WPTS * NWAVE;
-    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3, VW>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
+    hipLaunchKernelGGL((layer_kernel<DO_MLP, MODE3, VW, NW>), dim3((a.R + TILE_PTS - 1) / TILE_PTS), dim3(64 * NWAVE), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "layer launch");
 }
 
@@ -661,7 +670,13 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     a.w1s = p.w1s; a.b1 = p.b1; a.w2s = p.w2s; a.b2 = p.b2; a.w3s = p.w3s; a.b3 = p.b3;
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
     a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP;
+    // small launches (fewer 128-keypoint tiles than half the CUs of the part): 64-keypoint workgroups, one wave per SIMD
+    static const int small_tiles = [] { const char* e = getenv("MDGAT_LAYER_SMALL_TILES"); return e ? atoi(e) : 128; }();
+    if ((p.R + 127) / 128 <= small_tiles) {
+        if (p.do_mlp) return p.mode3 != 1 ? launch_layer_t<1, 2, 0, 4>(a, s) : launch_layer_t<1, 1, 0, 4>(a, s);
+        return p.mode3 != 1 ? launch_layer_t<0, 2, 0, 4>(a, s) : launch_layer_t<0, 1, 0, 4>(a, s);
+    }
     const bool vw = p.mode3 == 1 && ((p.N | p.M) & 127) == 0;
-    if (p.do_mlp) return p.mode3 != 1 ? launch_layer_t<1, 2, 0>(a, s) : vw ? launch_layer_t<1, 1, 1>(a, s) : launch_layer_t<1, 1, 0>(a, s);
-    return p.mode3 != 1 ? launch_layer_t<0, 2, 0>(a, s) : vw ? launch_layer_t<0, 1, 1>(a, s) : launch_layer_t<0, 1, 0>(a, s);
+    if (p.do_mlp) return p.mode3 != 1 ? launch_layer_t<1, 2, 0, 8>(a, s) : vw ? launch_layer_t<1, 1, 1, 8>(a, s) : launch_layer_t<1, 1, 0, 8>(a, s);
+    return p.mode3 != 1 ? launch_layer_t<0, 2, 0, 8>(a, s) : vw ? launch_layer_t<0, 1, 1, 8>(a, s) : launch_layer_t<0, 1, 0, 8>(a, s);
 }
