@@ -270,6 +270,7 @@ struct SksArgs {
     unsigned* error_word;
     unsigned* host_error;        // optional, host-mapped: set together with error_word so that the owner of a handle learns of it
     int B, N, M, iters, ngroups, GR, GC;
+    int xcd_map;         // workgroup blockIdx = (slot * P + partner) * 8 + xcd: the partners of a pair share blockIdx % 8 (launch_scaling)
     // fused arg-max of the match extraction (mdgat.py:441-483): per row over this workgroup's columns, per column over
     // its rows (merged later); ext_mode < 0: off.  Z may be NULL when only the matches are wanted.
     int ext_mode;
@@ -345,10 +346,11 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int P = GR * GC;
     int group, w;
-    if ((a.ngroups & 7) == 0) {           // partners share blockIdx % 8 (observed: the XCD)
+    if (a.xcd_map) {                      // partners share blockIdx % 8 (observed: the XCD); the grid is padded to 8 groups per slot
         const int xcd = blockIdx.x & 7, q = blockIdx.x >> 3;
         w = q % P;
         group = (q / P) * 8 + xcd;
+        if (group >= a.ngroups) return;   // (padding: the whole workgroup leaves)
     } else {
         group = blockIdx.x / P;
         w = blockIdx.x % P;
@@ -975,12 +977,20 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     int ngroups = num_cu / P;
     if (ngroups > sk_max_groups(N, M)) ngroups = sk_max_groups(N, M);
     if (ngroups > B) ngroups = B;
-    if (ngroups >= 8) ngroups &= ~7;
+    // Placement: the workgroups of a pair exchange through L2 every iteration, which is fast and steady only inside one XCD
+    // (workgroup i runs on XCD i % 8): group g takes the workgroups with blockIdx % 8 == g % 8, and the grid is padded to a
+    // multiple of 8 groups - the surplus workgroups leave at once.  (Before: only batches that are multiples of 8 were placed,
+    // others ran their partners on four different XCDs - 1.0 ms against an erratic 1.0 ... 3.5 ms per forward at B = 2 ... 4 -
+    // and a batch of 12 ran as 8 + 4.)  A pair's workgroups must fit the 32 CUs of an XCD next to the other groups placed there.
+    static const bool cooperative = getenv("MDGAT_SK_COOPERATIVE") != nullptr;
+    const int ng8 = (ngroups + 7) & ~7;
+    const bool xcd_map = P * (ng8 / 8) <= num_cu / 8 && (!cooperative || ngroups == ng8);
+    const int grid = xcd_map ? ng8 * P : ngroups * P;
     if (ngroups < 1) { mdgat_set_error("sinkhorn: %d workgroups per pair do not fit the device", P); return MDGAT_ERR_UNSUPPORTED; }
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
     if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), host_error, B, N, M, iters, ngroups, GR, GC, -1, nullptr, nullptr, nullptr, nullptr};
+              static_cast<unsigned*>(ws), host_error, B, N, M, iters, ngroups, GR, GC, xcd_map ? 1 : 0, -1, nullptr, nullptr, nullptr, nullptr};
     if (ex) {
         char* p = static_cast<char*>(ws) + slots_bytes(N, M);
         a.ext_mode = ex->mode;
@@ -1001,9 +1011,8 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     // spins stay as the safety net (a partner that never arrives poisons the outputs and is reported on the next call);
     // MDGAT_SK_COOPERATIVE=1 selects the cooperative launch, which makes the runtime check co-residency.
     hipError_t e;
-    static const bool cooperative = getenv("MDGAT_SK_COOPERATIVE") != nullptr;
-    if (cooperative || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
-    else e = hipLaunchKernel(kern, dim3(ngroups * P), dim3(SKS_THREADS), args, 0, s);
+    if (cooperative || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
+    else e = hipLaunchKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
     if (ex) {
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, a.error_word,
