@@ -27,6 +27,14 @@
 #include "common.hpp"
 #include <cstdlib>
 
+#ifdef WIDE_TRACE
+__device__ long long g_wide_trace[4 * 8];
+extern "C" int mdgat_wide_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_trace), n * sizeof(long long)); }
+#define WT(k) do { if (blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7)) \
+    g_wide_trace[((threadIdx.x >> 6) == 7) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WT(k) do {} while (0)
+#endif
 namespace {
 
 constexpr int KROWH = 72;   // K row in LDS, halves: 32 hi | 32 lo | 8 pad (144 B = 9 x 16 B: conflict free)
@@ -987,16 +995,27 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         }
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
         f32x16 S[NBLK];
+        // K fragments come straight from L2: the loads of block jb + 1 are issued before the products of block jb (left to
+        // itself the compiler puts every load right in front of its use and waits for it: ~24 exposed round trips per tile)
+        f16x8 kn[4];
+        auto kload = [&](int jb, f16x8 (&k)[4]) __attribute__((always_inline)) {
+            const int gb = kw * NBLK + jb;
+            const int key = min(gb * 32 + krow, nk - 1);          // rows past the end: any finite data, masked below
+            const _Float16* kp = kg + (size_t)key * 256;
+            k[0] = *reinterpret_cast<const f16x8*>(kp);
+            k[1] = *reinterpret_cast<const f16x8*>(kp + 16);
+            k[2] = *reinterpret_cast<const f16x8*>(kp + 32);
+            k[3] = *reinterpret_cast<const f16x8*>(kp + 48);
+        };
+        WT(0);
+        kload(0, kn);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             const int gb = kw * NBLK + jb;
+            const f16x8 kh0 = kn[0], kh1 = kn[1], kl0 = kn[2], kl1 = kn[3];
+            if (jb + 1 < NBLK) kload(jb + 1, kn);
+            __builtin_amdgcn_sched_barrier(0);
             if (gb < nblk) {
-                const int key = min(gb * 32 + krow, nk - 1);      // rows past the end: any finite data, masked below
-                const _Float16* kp = kg + (size_t)key * 256;
-                const f16x8 kh0 = *reinterpret_cast<const f16x8*>(kp);
-                const f16x8 kh1 = *reinterpret_cast<const f16x8*>(kp + 16);
-                const f16x8 kl0 = *reinterpret_cast<const f16x8*>(kp + 32);
-                const f16x8 kl1 = *reinterpret_cast<const f16x8*>(kp + 48);
                 f32x16 acc, acx;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acx[r] = 0.f; }
@@ -1019,13 +1038,16 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
             }
         }
+        WT(1);
         float m = NEG_INF;
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
         m = comm.rmax(m);
+        WT(2);
         const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
+        WT(3);
         {
             // exact ties at the k-th place (topk_break_ties): this kernel counts what the threshold keeps BEFORE its pass
             // (a pass redone after the fact costs it 40 spilled registers, and a probe here is a workgroup exchange anyway)
@@ -1050,27 +1072,38 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 }
         }
 
+        WT(4);
         const float m11 = m - 11.0f;
         f32x2 l2 = {0.f, 0.f};
         f32x2 kept = {0.f, 0.f};
         f32x16 Om, Ox;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { Om[r] = 0.f; Ox[r] = 0.f; }
+        // V^T fragments likewise: the loads of step + 1 before the exponentials of this step
+        f16x8 vhn, vln;
+        auto vload = [&](int step, f16x8& h, f16x8& l) __attribute__((always_inline)) {
+            const int gb = min(kw * NBLK + (step >> 1), nblk - 1);
+            const _Float16* vp = vg + gb * 32 + (step & 1) * 16;
+            h = *reinterpret_cast<const f16x8*>(vp);
+            l = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
+        };
+        vload(0, vhn, vln);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             const int gb = kw * NBLK + jb;
-            if (gb < nblk) {
+            {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
+                    const f16x8 vh = vhn, vl = vln;
+                    if (2 * jb + t + 1 < 2 * NBLK) vload(2 * jb + t + 1, vhn, vln);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (gb >= nblk) continue;
                     float p[8], s8[8];
 #pragma unroll
                     for (int j = 0; j < 8; ++j) s8[j] = S[jb][8 * t + j];
                     softmax8<true, false>(s8, m11, thr, p, l2, kept);
                     f16x8 ph, pl;
                     split8(p, ph, pl);
-                    const _Float16* vp = vg + gb * 32 + t * 16;
-                    const f16x8 vh = *reinterpret_cast<const f16x8*>(vp);
-                    const f16x8 vl = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
                     Om = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vh, Om, 0, 0, 0);
                     Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(ph, vl, Ox, 0, 0, 0);
                     Ox = __builtin_amdgcn_mfma_f32_32x32x16_f16(pl, vh, Ox, 0, 0, 0);
@@ -1078,6 +1111,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             }
         }
         (void)kept;
+        WT(5);
         float l = l2[0] + l2[1];
         l += xor32(l);
         float* ob = obuf + wave * 17 * 64;
@@ -1090,19 +1124,24 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
 #pragma unroll
             for (int w = 0; w < NW; ++w) lt += obuf[(qgroup * NW + w) * 17 * 64 + 16 * 64 + lane];
             const float inv_l = 1.0f / lt;
-            float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
+            // (the addresses below do not depend on the pass: hoisted out of the pass loop they live across the whole kernel,
+            // are spilled, and come back as 17 serialised scratch round trips - `late` keeps them here)
+            int late = 0;
+            asm volatile("" : "+v"(late));
+            float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31 + late;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = mfma32_row(r, hi);
+                const int row = mfma32_row(r, hi + late);
                 const float inv = __shfl(inv_l, row, 64);
                 const int q = qw + row;
                 float o = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) o += obuf[(qgroup * NW + w) * 17 * 64 + r * 64 + lane];
+                for (int w = 0; w < NW; ++w) o += obuf[(qgroup * NW + w) * 17 * 64 + r * 64 + lane + late];
                 if (q < nq) out[(size_t)q * 128] = o * inv;
             }
         }
         __syncthreads();     // obuf is reused by the next pass
+        WT(7);
     }
 }
 
