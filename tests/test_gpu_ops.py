@@ -319,10 +319,13 @@ def test_sinkhorn_vs_oracle(N, M, iters):
         assert (Z - ref).abs().max() < 1e-4, streaming
 
 
-@pytest.mark.parametrize('B,N,M', [(1, 512, 512), (70, 512, 512), (5, 200, 300), (9, 500, 37), (3, 128, 512), (130, 129, 64)])
+@pytest.mark.parametrize('B,N,M', [(1, 512, 512), (70, 512, 512), (5, 200, 300), (9, 500, 37), (3, 128, 512), (130, 129, 64),
+                                   (2, 512, 512), (7, 512, 512), (12, 512, 512), (13, 300, 512), (60, 512, 100), (3, 1000, 400),
+                                   (5, 2048, 300), (2, 2048, 2048)])
 def test_sinkhorn_cluster_matches_streaming(B, N, M):
     """The two kernels implement the same iteration: they must agree to fp32 round-off for any batch size
-    (more pairs than resident groups: the persistent loop; ragged shapes: the masks)."""
+    (more pairs than resident groups: the persistent loop; ragged shapes: the masks; batches that are not multiples of 8:
+    the grid padded to 8 groups for the XCD placement, surplus workgroups leaving at once; 2048 x 2048: no placement)."""
     s = torch.randn(B, N, M, device=DEV, generator=torch.Generator(DEV).manual_seed(B + N)) * 3
     Zc = ops.sinkhorn(s, 1.0, 30)
     Zs = ops.sinkhorn(s, 1.0, 30, streaming=True)
