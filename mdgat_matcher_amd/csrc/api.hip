@@ -218,7 +218,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
                         const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
                         const float* rec0, const float* rec1, int normalize_fpfh,
                         int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
-                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0) {
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
     if (*static_cast<volatile unsigned*>(h->host_error)) {
@@ -327,7 +327,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     // (Z is only materialised when the caller asks for it or the streaming Sinkhorn needs it for the extraction)
     const bool fused = ws.sk_bytes != 0;   // N, M <= 2048: the cluster kernel, arg-maxes fused
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
-    const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1};
+    const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust};
     unsigned* host_error_dev = nullptr;
     if ((rc = mdgat_check_hip(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_error_dev), h->host_error, 0), "hipHostGetDevicePointer"))) return rc;
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, host_error_dev))) return rc;
@@ -345,13 +345,46 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     return MDGAT_OK;
 }
 
+// Large batches run in slices.  Pairs are independent, and a slice of ~64 pairs already fills the part (512 tiles of the layer
+// kernel, 2048 workgroups of the attention kernel, one Sinkhorn workgroup per CU at N = M = 512) - but its working set
+// (q / k / v: 1.6 MB per pair and layer at N = M = 512) still fits the 256 MB Infinity Cache between the kernel that writes it
+// and the one that reads it, which a batch of 128 no longer does: 20 400 pairs/s at B = 64 against 19 100-19 500 at
+// B = 128 ... 512 before.  Slices are balanced (B = 100 -> 2 x 50); the one batch-wide rule of the reference, mdgat.py:465-467,
+// is applied over the whole batch afterwards.  Taps (whole-batch layouts) run unsliced.
+static int forward_sliced(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
+                          const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
+                          const float* rec0, const float* rec1, int normalize_fpfh,
+                          int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                          const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+    static const long slice_points = [] { const char* e = getenv("MDGAT_FORWARD_SLICE_POINTS"); return e ? atol(e) : 65536L; }();
+    const long per_pair = (long)N + M;
+    long slice = per_pair > 0 ? slice_points / per_pair : 0;        // pairs per slice (64 at N = M = 512)
+    if (slice < 1) slice = 1;
+    if (!h || taps || B <= 0 || N <= 0 || M <= 0 || slice_points <= 0 || (long)B <= slice + slice / 2 || !matches0 || !matches1 || !mscores0 || !mscores1)
+        return forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
+                            mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+    const int nslices = (int)((B + slice - 1) / slice);
+    const int per = (B + nslices - 1) / nslices;
+    auto off = [](const float* p, size_t n) { return p ? p + n : nullptr; };
+    for (int c = 0; c < B; c += per) {
+        const int b = B - c < per ? B - c : per;
+        const size_t c_ = (size_t)c;
+        if (int rc = forward_impl(h, b, N, M, off(kpts0, c_ * N * 3), off(sigma0, c_ * N), off(fpfh0, c_ * N * 33), off(kpts1, c_ * M * 3),
+                                  off(sigma1, c_ * M), off(fpfh1, c_ * M * 33), off(rec0, c_ * N * 37), off(rec1, c_ * M * 37), normalize_fpfh,
+                                  matches0 + c_ * N, matches1 + c_ * M, mscores0 + c_ * N, mscores1 + c_ * M,
+                                  Z ? Z + c_ * (N + 1) * (M + 1) : nullptr, nullptr, workspace, workspace_bytes, stream, 1))
+            return rc;
+    }
+    return launch_alldust_fixup(B, N, M, h->cfg.extract_mode, matches0, mscores1, static_cast<hipStream_t>(stream));
+}
+
 extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
                              const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
                              int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                              const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1) { mdgat_set_error("mdgat_forward: null input pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
-                        mscores1, Z, taps, workspace, workspace_bytes, stream);
+    return forward_sliced(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
+                          mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* frames0, const float* frames1,
@@ -359,8 +392,8 @@ extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const 
                                     float* mscores1, float* Z, const mdgat_taps* taps, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if (!frames0 || !frames1) { mdgat_set_error("mdgat_forward_frames: null frame pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_impl(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
-                        matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+    return forward_sliced(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
+                          matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdgat_profile(mdgat_handle* h, int enable, double* ms_out, long long* launches_out) {

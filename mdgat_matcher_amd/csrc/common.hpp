@@ -142,7 +142,10 @@ struct SkExtract {   // match extraction to run after (or fused into) the Sinkho
     int mode; float thr;
     int64_t *m0, *m1;
     float *s0, *s1;
+    int defer_alldust;   // the batch-wide "no keypoint of frame 0 matched" rule (mdgat.py:465-467) is applied later by
+                         // launch_alldust_fixup() over the whole batch (the forward runs large batches in slices)
 };
+int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float* s1, hipStream_t s);
 // host_error (optional, host-mapped memory): set to 1 when a workgroup of the cluster kernel lost a partner (bounded spin)
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
                     int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* host_error = nullptr);

@@ -966,7 +966,7 @@ size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
     return slots_bytes(N, M) + ((size_t)B * GC * N * 2 + (size_t)B * GR * M * 2) * sizeof(float);
 }
 
-static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s);
+static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, bool defer_alldust = false);
 
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
                           float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* host_error, hipStream_t s) {
@@ -1017,7 +1017,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     if (ex) {
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, a.error_word,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
-        return launch_extract_impl(B, N, M, x, s);
+        return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
     }
     return MDGAT_OK;
 }
@@ -1053,21 +1053,25 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         return MDGAT_ERR_UNSUPPORTED;
     }
     if (rc || !ex) return rc;
-    return launch_extract(B, N, M, Z, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, s);
+    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
 }
 
-static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s) {
+int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float* s1, hipStream_t s) {
+    if (mode != MDGAT_EXTRACT_DUSTBIN && mode != MDGAT_EXTRACT_DUSTBIN_MUTUAL) return MDGAT_OK;
+    const size_t n = (size_t)B * M;
+    hipLaunchKernelGGL(extract_alldust_fixup, dim3((unsigned)((n + 255) / 256 < 16 ? (n + 255) / 256 : 16)), dim3(256), 0, s,
+                       m0, (size_t)B * N, s1, n);
+    return mdgat_check_hip(hipGetLastError(), "extract fixup launch");
+}
+
+static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, bool defer_alldust) {
     if (a.mode < 0 || a.mode > 3) { mdgat_set_error("extract: bad mode %d", a.mode); return MDGAT_ERR_BAD_ARG; }
     const size_t lds = (size_t)(2 * (N + M) + 4) * sizeof(float);
     hipLaunchKernelGGL(extract_kernel, dim3(B), dim3(1024), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "extract launch")) return rc;
-    if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
-        const size_t n = (size_t)B * M;
-        hipLaunchKernelGGL(extract_alldust_fixup, dim3((unsigned)((n + 255) / 256 < 16 ? (n + 255) / 256 : 16)), dim3(256), 0, s,
-                           a.m0, (size_t)B * N, a.s1, n);
-        return mdgat_check_hip(hipGetLastError(), "extract fixup launch");
-    }
-    return MDGAT_OK;
+    if (defer_alldust) return MDGAT_OK;
+    return launch_alldust_fixup(B, N, M, a.mode, a.m0, a.s1, s);
 }
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,

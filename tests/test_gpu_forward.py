@@ -342,6 +342,29 @@ def test_repeatable_bitwise():
             assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('bin_score', [1.0, 60.0])
+def test_large_batch_runs_in_slices(bin_score):
+    """A batch beyond 1.5 x 65536 keypoints runs as balanced slices inside mdgat_forward (api.hip: forward_sliced).  Pairs are
+    independent, so the result must be bit-identical to running the same pairs in two separate calls - including the one
+    batch-wide rule of the reference (mdgat.py:465-467: no frame-0 keypoint matched anywhere -> all scores zero; bin_score 60
+    sends every keypoint to the dustbin)."""
+    B, n = 130, 512
+    net = MDGAT(synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10))
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5, bin_score=bin_score))
+    net = net.to(DEV).eval()
+    data = synth.make_batch(B, n, n, device=DEV)
+    with torch.no_grad():
+        whole = net(data)                                     # 130 pairs: two slices of 65
+        halves = [net({k: (v[i:i + 65] if torch.is_tensor(v) else v) for k, v in data.items()}) for i in (0, 65)]   # unsliced calls
+    for key in ('matches0', 'matches1', 'matching_scores0', 'matching_scores1'):
+        assert torch.equal(whole[key], torch.cat([h[key] for h in halves])), key
+    if bin_score > 10:
+        assert (whole['matches0'] == -1).all() and (whole['matches1'] == -1).all()
+        assert (whole['matching_scores0'] == 0).all() and (whole['matching_scores1'] == 0).all()
+    else:
+        assert (whole['matches0'] >= 0).any()
+
+
 def test_match_frames_raw_records():
     """Raw 37-float keypoint records (load_data.py:152-165) straight into the encoder kernel, FPFH normalisation
     (load_data.py:290-292) fused: same result as decoding with the oracle's restatement of the loader."""
