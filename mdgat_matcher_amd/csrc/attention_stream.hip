@@ -299,7 +299,11 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
             // running maximum; sums and outputs follow it in the next chunk
             float mc = fmaxf(mxa, mxb);
             mc = max_halves(mc);
-            const float m_new = fmaxf(m_run, mc);
+            // the running maximum follows the chunk maximum only when that is more than 4 octaves above it: a reference up to 4
+            // octaves low keeps every p' = 2048 exp2(s - m) below 2^15 (an f16 holds it), costs no precision (the split is
+            // relative) and spares the rescale of the 16 output registers and the sums in nearly every chunk after the first
+            // (measured: 66.2 -> 65.2-66.2 us per launch - the rescale was not what the chunk waits for)
+            const float m_new = mc > m_run + 4.0f ? mc : m_run;
             sc = __builtin_amdgcn_exp2f(m_run - m_new);
             m_run = m_new;
         }
