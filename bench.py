@@ -80,7 +80,10 @@ def kernel_breakdown(net, dev, inputs, B, n, L, S, steps=5):
         for _ in range(steps):
             net._run(*inputs)
     prof = net.profile(dev, False)
-    work = class_work(B, n, L, S)
+    # a large batch runs as balanced slices inside the library (api.hip: forward_sliced; one Sinkhorn launch per slice):
+    # the work of ONE launch is that of a slice
+    slices = max(1, prof['sinkhorn'][1] // steps) if 'sinkhorn' in prof else 1
+    work = class_work(B / slices, n, L, S)
     rows = []
     for name, (ms, launches) in prof.items():
         if launches == 0:
@@ -226,6 +229,9 @@ def main():
         }
         if not args.no_breakdown:
             rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
+            nsl = next((r['launches_per_step'] for r in rows if r['kernel'] == 'sinkhorn'), 1)
+            if nsl > 1:
+                out['config']['batch_slices'] = f'{nsl} slices of {-(-B // nsl)} pairs per step inside the library (cache blocking; per-launch work below is a slice\'s)'
             dom = max(rows, key=lambda r: r['step_ms'])
             traffic, source = pmc_traffic(args.config if B == c['B'] and att == c['att'] else -1, dom['kernel'])
             if 'flops' in dom:
