@@ -13,12 +13,15 @@ the only collective is the one-time RCCL broadcast of the packed weights from ra
 `--config {0,2,3,4}` runs another BASELINE.json configuration instead (never the headline; configs[3] = the
 8-way sharded 4096 pairs is `--gpus 8 --config 3`, 512 pairs per GPU).
 
-Rank 0 prints ONE JSON line: metric keypoint-pairs/sec (whole job), plus
-  roofline     - the dominant kernel class of the step against the f16 MFMA roofline (or HBM for Sinkhorn), its
-                 average launch duration measured live with HIP events on the launch stream (mdgat_profile);
+The timed window (--steps steps between barrier + synchronize, max over ranks) is repeated --windows times (default 5) and
+the MEDIAN window is the reported value (`timing` lists them all).  Rank 0 prints ONE JSON line: metric keypoint-pairs/sec
+(whole job), plus
+  roofline     - the dominant kernel class of the step against the f16 MFMA roofline (or HBM for Sinkhorn): algorithmic
+                 FLOPs per launch over its average launch duration, measured live with HIP events on the launch stream
+                 (mdgat_profile); `frac_executed` = the 3x split-f16 MFMA work the matrix cores actually run;
   roofline_qk  - the Q K^T contraction of full attention (the north star's "QK^T roofline"): the phase in isolation
                  (same kernel, softmax and P.V knocked out; mdgat_attention_qk_probe) timed with HIP events on the
-                 launch stream, as executed and as useful fraction of the dense f16 MFMA peak;
+                 launch stream, as algorithmic (`frac`) and executed (`frac_executed`) fraction of the dense f16 MFMA peak;
   cpu_baseline - the CPU oracle (fp64 PyTorch restatement of the reference, "port") timed on this box's
                  host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -111,13 +114,14 @@ def qk_roofline(dev, B, n, reps=20):
     flops = B * 2 * 4 * (2.0 * n * n * 32)            # Q K^T only: half of an attention launch
     useful = flops / (ms * 1e-3) / 1e12
     sus = ops.mfma_sustained(dev)
-    return {'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'], 'frac_of_sustained': SPLIT_FACTOR * useful / sus['tflops'],
-            'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
+    return {'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
             'avg_launch_ms': ms, 'algorithmic_flops_per_launch': flops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-            'achieved': SPLIT_FACTOR * useful, 'frac': SPLIT_FACTOR * useful / PEAK_F16_MFMA_TFLOPS,
-            'useful_tflops': useful, 'frac_useful': useful / PEAK_F16_MFMA_TFLOPS,
-            'note': 'achieved/frac = f16 MFMA FLOP/s executed (3 MFMAs per fp32-class product: no term can be dropped at the '
-                    '1e-4 bar, profiles/precision_ablation_r2.txt); useful = fp32-equivalent'}
+            'achieved': useful, 'frac': useful / PEAK_F16_MFMA_TFLOPS,
+            'achieved_executed': SPLIT_FACTOR * useful, 'frac_executed': SPLIT_FACTOR * useful / PEAK_F16_MFMA_TFLOPS,
+            'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
+            'frac_executed_of_sustained': SPLIT_FACTOR * useful / sus['tflops'],
+            'note': 'achieved / frac = algorithmic (fp32-equivalent) Q K^T FLOP/s; *_executed = f16 MFMA FLOP/s executed (3 MFMAs '
+                    'per fp32-class product: no term can be dropped at the 1e-4 bar, profiles/precision_ablation_r2.txt)'}
 
 
 def cpu_baseline(n, L, S, budget_s=15.0, max_pairs=64):
@@ -158,6 +162,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='pairs per GPU per step (default: the configuration\'s)')
     ap.add_argument('--attention-dtype', default=None, choices=['fp32', 'f16'],
                     help="'f16': single-f16 attention products (BASELINE configs[2]; outside the parity bar, not the headline)")
+    ap.add_argument('--windows', type=int, default=5,
+                    help='the timed window of --steps steps is repeated this many times; value = the median window')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     args = ap.parse_args()
@@ -193,15 +199,20 @@ def main():
         torch.cuda.synchronize()
         for _ in range(args.warmup):
             step()
-        shard.barrier(world)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        torch.cuda.synchronize()
-        shard.barrier(world)
-        dt = time.perf_counter() - t0
-    dt = shard.max_over_ranks(dt, dev, world)
+        # EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks: one window.  A window at
+        # B = 64 is 20 x 3.3 ms = 67 ms - a single sample on a box whose clocks move - so the window is repeated and the
+        # MEDIAN window is reported (all windows are listed in the line).
+        windows = []
+        for _ in range(max(1, args.windows)):
+            shard.barrier(world)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            torch.cuda.synchronize()
+            shard.barrier(world)
+            windows.append(shard.max_over_ranks(time.perf_counter() - t0, dev, world))
+    dt = sorted(windows)[len(windows) // 2]
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -225,7 +236,10 @@ def main():
                                    f'{S} Sinkhorn iterations, ' + ('fp32' if parity else 'f16 attention / fp32 Sinkhorn') +
                                    f' (BASELINE.json {c["name"]}' + ('' if B == c['B'] else f' at batch {B}') + ')',
                        'baseline_config': args.config, 'pairs_per_gpu': B, 'keypoints': n, 'L': L, 'sinkhorn_iterations': S,
-                       'parallelism': f'pairs sharded {world}-way, no data-path collective'},
+                       'parallelism': f'pairs sharded {world}-way, no data-path collective',
+                       'collectives': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none'},
+            'timing': {'windows': len(windows), 'value_is': 'median window', 'window_ms': [round(1e3 * w, 3) for w in windows],
+                       'best_pairs_per_s': pairs / min(windows), 'worst_pairs_per_s': pairs / max(windows)},
         }
         if not args.no_breakdown:
             rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
@@ -237,14 +251,15 @@ def main():
             if 'flops' in dom:
                 alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
                 ach = (SPLIT_FACTOR if parity or not dom['kernel'].startswith('attention') else 1.0) * alg
-                roof = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F16_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': ach / PEAK_F16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
+                roof = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': alg, 'peak': PEAK_F16_MFMA_TFLOPS,
+                        'unit': 'TFLOP/s', 'frac': alg / PEAK_F16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
                         'avg_launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
-                        'algorithmic_tflops': alg, 'frac_useful': alg / PEAK_F16_MFMA_TFLOPS,
-                        'note': 'achieved = f16 MFMA FLOP/s executed = 3 x the fp32-equivalent algorithmic rate '
-                                '(every product is hi.hi + hi.lo + lo.hi on the f16 matrix cores); frac_useful = the '
-                                'fp32-equivalent rate over the same peak; traffic = HBM bytes per launch from the PMC '
-                                'passes of this command named in traffic_source (not measured in this run)'}
+                        'achieved_executed': ach, 'frac_executed': ach / PEAK_F16_MFMA_TFLOPS,
+                        'note': 'achieved / frac = ALGORITHMIC (fp32-equivalent) FLOPs of one launch (SURVEY 8d, DESIGN.md '
+                                'section 5) over its average duration, against the dense f16 MFMA peak; *_executed = the f16 '
+                                'MFMA FLOPs the matrix cores run for it = 3 x algorithmic (every product is hi.hi + hi.lo + '
+                                'lo.hi); traffic = HBM bytes per launch from the PMC passes of this command named in '
+                                'traffic_source (not measured in this run)'}
             else:
                 ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
                 roof = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
@@ -256,10 +271,10 @@ def main():
                 # clocks to its power budget: ~1.6 instead of 2.4 GHz on this pool), measured live (mdgat_mfma_probe)
                 sus = ops.mfma_sustained(dev)
                 roof.update({'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
-                             'frac_of_sustained': roof['achieved'] / sus['tflops'],
+                             'frac_executed_of_sustained': roof['achieved_executed'] / sus['tflops'],
                              'sustained_note': 'sustained_peak = f16 MFMA TFLOP/s of an MFMA-only loop on random operands on '
                                                'this device, measured in this run (mdgat_mfma_probe); frac stays against the '
-                                               'dense peak at 2.4 GHz'})
+                                               'dense peak at 2.4 GHz; frac_executed_of_sustained = executed rate over it'})
             out['roofline'] = roof
             if n % 64 == 0 and att == 'fp32':
                 out['roofline_qk'] = qk_roofline(dev, B, n)

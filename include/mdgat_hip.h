@@ -132,6 +132,15 @@ int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* fram
                          float* Z, const mdgat_taps* taps,
                          void* workspace, size_t workspace_bytes, void* stream);
 
+/* Asynchronous status of the handle's forwards since the last call with clear != 0 (read it after synchronising the
+ * stream: the forward itself never synchronises).  *range_violation != 0: an activation left the f16 operand range
+ * (|v| >= 6e4) or a non-finite value reached a kernel - every operand is carried as f16 head + f16 residual (DESIGN.md
+ * section 3), so the outputs of those calls are invalid; the function then returns MDGAT_ERR_UNSUPPORTED (and the next
+ * mdgat_forward on the handle does, if nobody asked before).  *sinkhorn_fallback != 0: informational - a Sinkhorn cluster
+ * launch lost a partner workgroup (device shared with other work) and was redone by the streaming kernel inside the same
+ * call; the results are valid.  The reference has no counterpart (ATen raises nothing either: it returns inf / NaN). */
+int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation);
+
 /* Per-kernel-class timing of mdgat_forward, measured with HIP events on the launch stream (bench.py's
  * roofline leg).  mdgat_profile(h, enable, ms, launches) returns the time (ms) and launch count
  * accumulated per class since the previous call in ms[MDGAT_PROF_CLASSES] / launches[...] (either may

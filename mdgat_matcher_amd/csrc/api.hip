@@ -60,7 +60,7 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
-    unsigned* host_error; // host-mapped word the Sinkhorn kernel sets when a partner workgroup never arrived (checked on the next call)
+    unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard
     // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream
     bool prof_on;
     std::vector<hipEvent_t> prof_ev;
@@ -106,8 +106,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMalloc(split weights)");
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMemset(split weights)");
-    if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(error word)");
-    if (!rc) *h->host_error = 0;
+    if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
+    if (!rc) for (int i = 0; i < MDGAT_STATUS_WORDS; ++i) h->host_error[i] = 0;
     (void)hipSetDevice(prev);
     if (rc) {
         if (h->weights) (void)hipFree(h->weights);
@@ -221,12 +221,13 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
                         const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0) {
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
-    if (*static_cast<volatile unsigned*>(h->host_error)) {
-        // the forward is asynchronous: a failure inside an earlier launch surfaces here (that call's outputs were poisoned:
-        // no matches, NaN scores / NaN in Z)
-        *h->host_error = 0;
-        mdgat_set_error("mdgat_forward: a previous call on this handle failed on the device (Sinkhorn: a partner workgroup never arrived); its outputs are invalid");
-        return MDGAT_ERR_HIP;
+    if (static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_RANGE]) {
+        // the forward is asynchronous: what an earlier launch found surfaces here unless the caller asked first
+        // (mdgat_async_status after its own synchronisation - MDGAT.forward does)
+        h->host_error[MDGAT_STATUS_RANGE] = 0;
+        mdgat_set_error("mdgat_forward: a previous call on this handle met activations outside the f16 operand range (|v| >= 6e4) or "
+                        "non-finite values; its outputs are invalid");
+        return MDGAT_ERR_UNSUPPORTED;
     }
     if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
     const bool arrays = kpts0 && sigma0 && fpfh0 && kpts1 && sigma1 && fpfh1;
@@ -252,6 +253,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     const int P = N + M;
     const int R = B * P;
     int rc;
+    unsigned* status_dev = nullptr;
+    if ((rc = mdgat_check_hip(hipHostGetDevicePointer(reinterpret_cast<void**>(&status_dev), h->host_error, 0), "hipHostGetDevicePointer"))) return rc;
 
     // profiling (off by default): an event after every launch; intervals are attributed to kernel classes after
     // the forward, which then ends with a stream synchronisation
@@ -291,7 +294,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     const _Float16* wfinal = h->wsplit + WS_LAYER * (size_t)L2;
     {
         LayerLaunch p{};
-        p.x = ws.x; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 0;
+        p.x = ws.x; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 0; p.guard = status_dev + MDGAT_STATUS_RANGE;
         if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
@@ -305,7 +308,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s, h->cfg.attention_mode, sel))) return rc;
         mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
-        p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1;
+        p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1; p.guard = status_dev + MDGAT_STATUS_RANGE;
         p.w1s = ls + WS_W1; p.b1 = lw + bl.mlp1_b; p.w2s = ls + WS_W2; p.b2 = lw + bl.mlp2_b;
         if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
@@ -328,9 +331,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     const bool fused = ws.sk_bytes != 0;   // N, M <= 2048: the cluster kernel, arg-maxes fused
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
     const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust};
-    unsigned* host_error_dev = nullptr;
-    if ((rc = mdgat_check_hip(hipHostGetDevicePointer(reinterpret_cast<void**>(&host_error_dev), h->host_error, 0), "hipHostGetDevicePointer"))) return rc;
-    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, host_error_dev))) return rc;
+    if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, status_dev,
+                              Z ? Z : ws.Z))) return rc;
     mark(MDGAT_PROF_SINKHORN);
     if (h->prof_on && prof_n > 1) {
         if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;
@@ -394,6 +396,21 @@ extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const 
     if (!frames0 || !frames1) { mdgat_set_error("mdgat_forward_frames: null frame pointer"); return MDGAT_ERR_BAD_ARG; }
     return forward_sliced(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
                           matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation) {
+    if (!h) { mdgat_set_error("mdgat_async_status: null handle"); return MDGAT_ERR_BAD_ARG; }
+    volatile unsigned* st = h->host_error;
+    const unsigned fb = st[MDGAT_STATUS_SK_FALLBACK], rg = st[MDGAT_STATUS_RANGE];
+    if (sinkhorn_fallback) *sinkhorn_fallback = fb;
+    if (range_violation) *range_violation = rg;
+    if (clear) { st[MDGAT_STATUS_SK_FALLBACK] = 0; st[MDGAT_STATUS_RANGE] = 0; }
+    if (rg) {
+        mdgat_set_error("activations outside the f16 operand range (|v| >= 6e4) or non-finite values reached a kernel: the outputs of "
+                        "the calls since the last check are invalid (this checkpoint / input does not fit the split-f16 arithmetic)");
+        return MDGAT_ERR_UNSUPPORTED;
+    }
+    return MDGAT_OK;
 }
 
 extern "C" int mdgat_profile(mdgat_handle* h, int enable, double* ms_out, long long* launches_out) {

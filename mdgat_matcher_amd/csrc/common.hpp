@@ -133,6 +133,8 @@ struct LayerLaunch {
     int R, N, M;
     int do_mlp;                        // 0: projection only
     int mode3;                         // 1: q|k|v, 2: final_proj
+    unsigned* guard;                   // optional (host-mapped): set to 1 when an input row holds a value outside the f16
+                                       // operand range (|v| >= MDGAT_F16_GUARD) or a non-finite one
 };
 int launch_layer(const LayerLaunch& p, hipStream_t s);
 // rowh >= 2 K: row pitch (halves); the first nperm rows are written in the P/Q row order of layer.hip
@@ -146,9 +148,16 @@ struct SkExtract {   // match extraction to run after (or fused into) the Sinkho
                          // launch_alldust_fixup() over the whole batch (the forward runs large batches in slices)
 };
 int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float* s1, hipStream_t s);
-// host_error (optional, host-mapped memory): set to 1 when a workgroup of the cluster kernel lost a partner (bounded spin)
+// Asynchronous status words of a handle (host-mapped memory the kernels write; read by the host after a synchronisation).
+constexpr int MDGAT_STATUS_SK_FALLBACK = 0;   // the Sinkhorn cluster kernel lost a partner workgroup: the launch was redone by the streaming kernel
+constexpr int MDGAT_STATUS_RANGE = 1;         // an activation left the f16 operand range or is not finite: the outputs are invalid
+constexpr int MDGAT_STATUS_WORDS = 4;
+constexpr float MDGAT_F16_GUARD = 6.0e4f;     // f16 max is 65504; the split's hi plane must stay finite
+// status (optional, device pointer to MDGAT_STATUS_WORDS host-mapped words).  Zfb: where the streaming fallback puts Z when
+// the cluster kernel lost a partner and the caller wanted no Z (NULL: the cluster launch is cooperative instead).
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* host_error = nullptr);
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status = nullptr,
+                    float* Zfb = nullptr);
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,

@@ -102,6 +102,7 @@ struct LayerArgs {
     _Float16* vt16;
     float* mdesc;           // [R][128] output of phase 3 (mode 2)
     int R, N, M, Npad, PP;
+    unsigned* guard;        // optional, host-mapped: set when an input value is outside the f16 operand range or not finite
 };
 
 // One stage: chunk c (1 KB) is moved by wave c & 7; the LDS address comes from M0, the lanes supply consecutive
@@ -283,6 +284,23 @@ __global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
             t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gp * 128 + l31 * 4);
 #endif
         }
+    };
+    // f16 operand range guard: every activation becomes an f16 head + residual; a head beyond 65504 is
+    // inf and everything after it NaN - which a ReLU (v_max) can swallow again.  The rows of x and msg pass through here
+    // on their way to the split: the largest magnitude of the 64 values of a lane, compared as an unsigned integer (NaN and
+    // inf have the largest images), flags the handle's status word.  msg carries what the attention kernels made of q, k, v
+    // (an overflow there is inf - inf = NaN in the softmax), x the residual stream and, in the first launch, the encoders.
+    auto rows_guard = [&](const f32x4 (&t)[8], unsigned acc) __attribute__((always_inline)) -> unsigned {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; c += 2)
+                acc = max(acc, max(__builtin_bit_cast(unsigned, t[i][c]) & 0x7fffffffu, __builtin_bit_cast(unsigned, t[i][c + 1]) & 0x7fffffffu));
+        return acc;
+    };
+    auto guard_report = [&](unsigned acc) __attribute__((always_inline)) {
+        if (a.guard && acc >= __builtin_bit_cast(unsigned, MDGAT_F16_GUARD))
+            __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     };
     auto rows_to_tile = [&](const f32x4 (&t)[8]) __attribute__((always_inline)) {
 #pragma unroll
@@ -500,8 +518,10 @@ __global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
             rows_load(a.x, tx);
             for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma<NW>(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tm);
+            const unsigned gm = rows_guard(tm, 0u);
             for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[4 + ks], al[4 + ks]); });
             rows_to_tile(tx);                    // stays in the tile: residual of phase 2
+            guard_report(rows_guard(tx, gm));
         }
         for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, ah[ks], al[ks]); });
         TR(1);
@@ -584,6 +604,7 @@ __global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
             rows_load(a.x, tx);
             for_units<LOOKAHEAD>([&](int h) __attribute__((always_inline)) { stage_dma<NW>(stage_src(h), ldsb(h), wave, lane); });
             rows_to_tile(tx);
+            guard_report(rows_guard(tx, 0u));
         }
         for_units<4>([&](int ks) __attribute__((always_inline)) { tile_fragment(ks, xnh[ks], xnl[ks]); });
         stage_wait<DMA_SLICES>();
@@ -669,7 +690,7 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     a.x = p.x; a.msg = p.msg;
     a.w1s = p.w1s; a.b1 = p.b1; a.w2s = p.w2s; a.b2 = p.b2; a.w3s = p.w3s; a.b3 = p.b3;
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
-    a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP;
+    a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP; a.guard = p.guard;
     // small launches (fewer 128-keypoint tiles than half the CUs of the part): 64-keypoint workgroups, one wave per SIMD
     static const int small_tiles = [] { const char* e = getenv("MDGAT_LAYER_SMALL_TILES"); return e ? atoi(e) : 128; }();
     if ((p.R + 127) / 128 <= small_tiles) {

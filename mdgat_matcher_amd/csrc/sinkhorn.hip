@@ -38,6 +38,10 @@ struct SkArgs {
     float alpha_host;
     float* Z;                 // [B][N+1][M+1]
     int N, M, iters;
+    // fallback use: run only if *only_if != 0 (the cluster kernel's error word: it lost a partner workgroup); workgroup 0
+    // then raises status_fallback (host-mapped, optional)
+    const unsigned* only_if;
+    unsigned* status_fallback;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -70,6 +74,10 @@ __global__ __launch_bounds__(NW * 64) void sinkhorn_kernel(SkArgs a) {
     const int N = a.N, M = a.M;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (a.only_if) {
+        if (__hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
+        if (blockIdx.x == 0 && tid == 0 && a.status_fallback) __hip_atomic_store(a.status_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     const float* S = a.scores + (size_t)blockIdx.x * N * M;
     float* Z = a.Z + (size_t)blockIdx.x * (N + 1) * (M + 1);
 
@@ -259,8 +267,10 @@ typedef __attribute__((address_space(1))) unsigned long long gu64;
 // sums: in-lane over the wave's 16 rows, the 8 waves merged through LDS, the G workgroups through L2 as 8-byte
 // {epoch, value} granules (the data is the flag, two slot sets alternate by epoch parity; relaxed agent-scope atomics,
 // or non-temporal accesses once the partners have agreed that they share an XCD; partners are placed on one XCD for
-// speed only; bounded spins, a timeout poisons the outputs with NaN and is reported by the handle's next call).  The
-// launch is a plain one when every workgroup has a CU of its own (launch_scaling), cooperative otherwise.
+// speed only; spins are bounded: a timeout raises the launch's error word, and the one-workgroup-per-pair streaming kernel
+// that follows every cluster launch - it leaves at once otherwise - then redoes the whole launch: the result is correct
+// whatever else occupies the device, only late).  The launch is a plain one when every workgroup has a CU of its own
+// (launch_scaling), cooperative otherwise.
 struct SksArgs {
     const float* scores;
     const float* alpha_dev;
@@ -268,7 +278,7 @@ struct SksArgs {
     float* Z;
     unsigned long long* slots;   // per group: column slots [2][GC][GR][SLOT_STRIDE], then row slots [2][GR][GC][ROW_STRIDE]; zeroed per launch
     unsigned* error_word;
-    unsigned* host_error;        // optional, host-mapped: set together with error_word so that the owner of a handle learns of it
+    unsigned* range_guard;       // optional, host-mapped: set when a score is not finite (an activation upstream left the f16 range)
     int B, N, M, iters, ngroups, GR, GC;
     int xcd_map;         // workgroup blockIdx = (slot * P + partner) * 8 + xcd: the partners of a pair share blockIdx % 8 (launch_scaling)
     // fused arg-max of the match extraction (mdgat.py:441-483): per row over this workgroup's columns, per column over
@@ -403,6 +413,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         // ---- this lane's RPW x 8 block of scores (base-2 log units); invalid entries -> exp2 gives 0 ----
         float K[RPW][8];
         const bool vec_ok = (M & 3) == 0 && gcol0 + 8 <= M;
+        unsigned gmax = 0;                // largest |score| of this lane as an integer image: NaN / inf on top
 #pragma unroll
         for (int r = 0; r < RPW; ++r) {
             const int i = row0 + r;
@@ -412,6 +423,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + gcol0 + 4);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
+                    gmax = max(gmax, max(__builtin_bit_cast(unsigned, x0[c]) & 0x7fffffffu, __builtin_bit_cast(unsigned, x1[c]) & 0x7fffffffu));
                     K[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
                     K[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
                 }
@@ -419,10 +431,12 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
                     const float x = row[min(gcol0 + c, M - 1)];
+                    gmax = max(gmax, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
                     K[r][c] = (i < N && gcol0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
                 }
             }
         }
+        if (a.range_guard && gmax >= 0x7f800000u) __hip_atomic_store(a.range_guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         // ---- absorb the row maximum (all column slabs, dustbin column included): every row of K has largest entry <= 1 ----
         float u0r = 0.f, kbr = 0.f, ar = 0.f;     // lane r: absorbed potential, dustbin-column entry, scaling of row r
         {
@@ -661,8 +675,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
         const bool partner_lost = P > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const float poison = partner_lost ? __builtin_nanf("") : 0.f;   // a partner never arrived: make the failure loud
-        if (partner_lost && a.host_error && tid == 0) __hip_atomic_store(a.host_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const float poison = partner_lost ? __builtin_nanf("") : 0.f;   // a partner never arrived: whatever this launch writes is
+                                                                       // overwritten by the gated streaming kernel that follows
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
         const float VM = ran ? v0M + lg2(bM) + poison : 0.f;
         const float Ur = (ran && my_row_valid) ? u0r + lg2(ar) : 0.f;    // lane r: potential of row r
@@ -787,7 +801,8 @@ struct ExArgs {
     float thr;
     int64_t* m0; int64_t* m1;
     float* s0; float* s1;
-    const unsigned* sk_error;   // optional: error word of the Sinkhorn kernel that produced the arg-maxes (a lost partner)
+    const unsigned* sk_error;   // optional: error word of the cluster kernel that produced the arg-maxes (a lost partner) ...
+    const float* Zfb;           // ... in which case the streaming fallback has written Z here: scan it instead
     // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
     // per row slab [B][GR][M])
     const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int GR, GC;
@@ -797,7 +812,10 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int N = a.N, M = a.M;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* Z = a.Z + (size_t)blockIdx.x * (N + 1) * (M + 1);
+    // the cluster kernel lost a partner workgroup (bounded spin ran out): its fused arg-maxes are garbage; the gated streaming
+    // kernel has recomputed Z since
+    const float* Zsrc = (a.sk_error && __hip_atomic_load(a.sk_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? a.Zfb : a.Z;
+    const float* Z = Zsrc + (size_t)blockIdx.x * (N + 1) * (M + 1);
     int* idx0 = reinterpret_cast<int*>(smem);   // [N]
     int* idx1 = idx0 + N;                       // [M]
     float* val0 = reinterpret_cast<float*>(idx1 + M);   // [N]
@@ -805,16 +823,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     const bool inner = a.mode >= MDGAT_EXTRACT_THRESHOLD;   // arg-max over the inner N x M block only
     const int ncol = inner ? M : M + 1;   // columns scanned per row
     const int nrow = inner ? N : N + 1;   // rows scanned per column
-    if (a.sk_error && *a.sk_error) {
-        // the Sinkhorn kernel lost a partner workgroup (bounded spin ran out): its potentials are garbage.  Z is poisoned
-        // with NaN there; without Z the failure must be just as loud: no matches, NaN scores (and the handle reports
-        // MDGAT_ERR_HIP on its next call)
-        for (int i = tid; i < N; i += 1024) { a.m0[(size_t)blockIdx.x * N + i] = -1; a.s0[(size_t)blockIdx.x * N + i] = __builtin_nanf(""); }
-        for (int j = tid; j < M; j += 1024) { a.m1[(size_t)blockIdx.x * M + j] = -1; a.s1[(size_t)blockIdx.x * M + j] = __builtin_nanf(""); }
-        return;
-    }
-
-    if (!a.Z) {
+    if (!Zsrc) {
         for (int i = tid; i < N; i += 1024) {
             const size_t base = (size_t)blockIdx.x * a.GC * N + i;
             float bv = a.rbest_val[base];
@@ -968,8 +977,22 @@ size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
 
 static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, bool defer_alldust = false);
 
+// the one-workgroup-per-pair streaming kernel: any shape up to M = 2048, no workspace
+static bool streaming_supported(int N, int M) { return M <= 512 || (M <= 2048 && N <= 4096); }
+static int launch_streaming(const SkArgs& a, int B, hipStream_t s) {
+    const int N = a.N, M = a.M;
+    if (M <= 64) return launch_sk<1, 16>(a, B, s);
+    if (M <= 128) return launch_sk<2, 16>(a, B, s);
+    if (M <= 256) return launch_sk<4, 16>(a, B, s);
+    if (M <= 512) return launch_sk<8, 16>(a, B, s);
+    if (M <= 1024 && N <= 4096) return launch_sk<16, 8>(a, B, s);
+    if (M <= 2048 && N <= 4096) return launch_sk<32, 8>(a, B, s);
+    mdgat_set_error("sinkhorn: M=%d > 2048 unsupported", M);
+    return MDGAT_ERR_UNSUPPORTED;
+}
+
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
-                          float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* host_error, hipStream_t s) {
+                          float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* status, float* Zfb, hipStream_t s) {
     constexpr int RPW = 16;
     int GR, GC;
     sk_tiling(N, M, GR, GC);
@@ -989,8 +1012,12 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     if (ngroups < 1) { mdgat_set_error("sinkhorn: %d workgroups per pair do not fit the device", P); return MDGAT_ERR_UNSUPPORTED; }
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
     if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
+    // test hook (tests/test_gpu_ops.py): pretend a partner was lost - the launch's error word starts out set, so the gated
+    // streaming kernel and the extraction from its Z run for real
+    if (const char* f = getenv("MDGAT_SK_FORCE_FALLBACK"); f && *f == '1')
+        if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 1, sizeof(unsigned), s), "memset(sinkhorn error word)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), host_error, B, N, M, iters, ngroups, GR, GC, xcd_map ? 1 : 0, -1, nullptr, nullptr, nullptr, nullptr};
+              static_cast<unsigned*>(ws), status ? status + MDGAT_STATUS_RANGE : nullptr, B, N, M, iters, ngroups, GR, GC, xcd_map ? 1 : 0, -1, nullptr, nullptr, nullptr, nullptr};
     if (ex) {
         char* p = static_cast<char*>(ws) + slots_bytes(N, M);
         a.ext_mode = ex->mode;
@@ -1005,17 +1032,27 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
                               : reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 4>);
     // The workgroups of a pair wait for each other, so all of them must become resident.  A workgroup takes a whole CU
     // (512 threads x 256 registers), and ngroups * P <= num_cu by construction: every workgroup gets a CU as soon as the
-    // stragglers of earlier launches leave - whatever else runs on the device is finite, and resident workgroups spinning on
-    // their partners do not keep others from being dispatched.  A plain launch therefore suffices, and it starts 20-30 us
-    // sooner than hipLaunchCooperativeKernel (measured at B = 64: 430 -> 397 us for launch + 100 iterations).  The bounded
-    // spins stay as the safety net (a partner that never arrives poisons the outputs and is reported on the next call);
-    // MDGAT_SK_COOPERATIVE=1 selects the cooperative launch, which makes the runtime check co-residency.
+    // stragglers of earlier launches leave.  A plain launch therefore suffices when this launch has the device to itself, and
+    // it starts 20-30 us sooner than hipLaunchCooperativeKernel (measured at B = 64: 430 -> 397 us for launch + 100
+    // iterations).  It is NOT assumed: workgroups are dispatched in order (per XCD), so of every concurrent cluster launch at
+    // most one pair per XCD is incomplete and the complete ones finish and make room - but enough concurrent launches (other
+    // streams, other processes) could leave every CU with a workgroup whose partners cannot be dispatched.  The spins are
+    // therefore bounded, a workgroup that gives up raises the launch's error word, and the streaming kernel launched right
+    // behind (gated on that word: it leaves at once otherwise, ~3 us) redoes the launch one workgroup per pair - slow, never
+    // wrong.  Without a fallback buffer (no Z and none lent) or with MDGAT_SK_COOPERATIVE=1 the launch is cooperative: the
+    // runtime then checks co-residency.
+    float* zfb = Z ? Z : Zfb;
+    const bool can_fall_back = zfb != nullptr && streaming_supported(N, M);
     hipError_t e;
-    if (cooperative || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
+    if (cooperative || !can_fall_back || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     else e = hipLaunchKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
+    if (can_fall_back && P > 1) {
+        SkArgs f{scores, alpha_dev, alpha_host, zfb, N, M, iters, a.error_word, status ? status + MDGAT_STATUS_SK_FALLBACK : nullptr};
+        if (int rc = launch_streaming(f, B, s)) return rc;
+    }
     if (ex) {
-        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, a.error_word,
+        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
     }
@@ -1027,7 +1064,7 @@ size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_clust
 // ex != NULL: also extract the matches.  With the cluster kernel the arg-maxes are fused into its epilogue and Z may
 // be NULL; otherwise Z must be given and is scanned by the extraction kernel.
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* host_error) {
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status, float* Zfb) {
     if (B <= 0) return MDGAT_OK;
     if (!Z && !ex) { mdgat_set_error("sinkhorn: nothing to compute (no Z, no extraction)"); return MDGAT_ERR_BAD_ARG; }
     if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("sinkhorn: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
@@ -1036,24 +1073,13 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, host_error, s);
+        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, s);
     }
     if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
-    // streaming kernel: any shape up to M = 2048, no workspace
-    SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters};
-    int rc;
-    if (M <= 64) rc = launch_sk<1, 16>(a, B, s);
-    else if (M <= 128) rc = launch_sk<2, 16>(a, B, s);
-    else if (M <= 256) rc = launch_sk<4, 16>(a, B, s);
-    else if (M <= 512) rc = launch_sk<8, 16>(a, B, s);
-    else if (M <= 1024 && N <= 4096) rc = launch_sk<16, 8>(a, B, s);
-    else if (M <= 2048 && N <= 4096) rc = launch_sk<32, 8>(a, B, s);
-    else {
-        mdgat_set_error("sinkhorn: M=%d > 2048 unsupported", M);
-        return MDGAT_ERR_UNSUPPORTED;
-    }
+    SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr};
+    const int rc = launch_streaming(a, B, s);
     if (rc || !ex) return rc;
-    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
 }
 
@@ -1077,6 +1103,6 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, boo
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, a, s);
 }

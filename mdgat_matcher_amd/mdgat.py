@@ -72,13 +72,21 @@ class _GNN(nn.Module):
 
 
 class _DeviceState:
-    """Per-device library handle + packed weights + scratch (one per (module, device))."""
+    """Per-device library handle + packed weights + scratch (one per (module, device)).  The scratch is per STREAM: the
+    library only enqueues, so forwards issued on two streams run concurrently on the device and must not share it."""
 
     def __init__(self, handle, device):
         self.handle = handle
         self.device = device
-        self.workspace = None
+        self.workspaces = {}            # stream handle -> uint8 tensor
         self.lock = threading.Lock()
+
+    def workspace_for(self, stream: int, need: int, dev):
+        ws = self.workspaces.get(stream)
+        if ws is None or ws.numel() < need:
+            self.workspaces.pop(stream, None)
+            ws = self.workspaces[stream] = torch.empty(need, dtype=torch.uint8, device=dev)
+        return ws
 
     def close(self):
         if self.handle:
@@ -265,9 +273,13 @@ class MDGAT(nn.Module):
             old = self._states.pop(idx, None)
             if old is not None:
                 old.close()
-            self._blob_holder[0] = None
+            # a host copy as well: any other device of this process (DataParallel replicas, a later .to()) loads the SAME
+            # weights from it - never this module's own parameters, which are random init on a rank that received a blob
+            self._blob_holder[0] = blob.detach().cpu().numpy().copy()
             self._blob_holder[1] = True     # stands until load_state_dict() / repack(): see _invalidate_if_changed
             self._sig_holder[0] = self._signature()
+            for other in [i for i in self._states if i != idx]:
+                self._states.pop(other).close()
             return self._state_for(blob.device, blob)
 
     # ------------------------------------------------------------------ forward
@@ -288,38 +300,70 @@ class MDGAT(nn.Module):
                                       'losses of mdgat.py:486-594 and backward are out of scope)')
         res = self._run(kpts0, data['scores0'], data['descriptors0'], kpts1, data['scores1'], data['descriptors1'])
         m0, m1, s0, s1 = res[:4]
+        s0, s1 = s0.to(out_dtype), s1.to(out_dtype)
+        if self.loss_method != 'superglue':
+            # mdgat.py:464-467: `if valid0.sum() == 0` - a host-side test in the reference too (it synchronises) - returns
+            # INTEGER zero scores (torch.zeros_like(indices)) when no frame-0 keypoint of the whole batch is matched.  The
+            # kernels have already zeroed the scores; the dtype follows here.
+            nothing_matched = not bool((m0 >= 0).any())
+            self.check(m0.device, synchronize=False)        # (the .any() above synchronised: report this call's status now)
+            if nothing_matched:
+                s0, s1 = torch.zeros_like(m0), torch.zeros_like(m1)
         return {
             'matches0': m0,
             'matches1': m1,
-            'matching_scores0': s0.to(out_dtype),
-            'matching_scores1': s1.to(out_dtype),
-            'loss': s0.new_zeros((), dtype=out_dtype),     # losses are training-only: not computed
+            'matching_scores0': s0,
+            'matching_scores1': s1,
+            'loss': m0.new_zeros((), dtype=out_dtype),     # losses are training-only: not computed
         }
+
+    def check(self, device=None, synchronize=True):
+        """Status of the asynchronous forwards on ``device`` since the last check.  Raises ``RuntimeError`` if an
+        activation left the f16 operand range (|v| >= 6e4) or a non-finite value reached a kernel - the outputs of those
+        calls are invalid (``mdgat_async_status``); returns ``{'sinkhorn_fallback': bool}`` otherwise (informational: a
+        Sinkhorn launch that lost a partner workgroup was redone by the streaming kernel, results valid).  ``forward``
+        (the dict API of the reference) calls this itself; after ``match()`` / ``match_frames()`` - which never
+        synchronise - call it once the results are needed."""
+        dev = torch.device(device) if device is not None else self.bin_score.device
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        with self._states_lock:
+            st = self._states.get(idx)
+        if st is None:
+            return {'sinkhorn_fallback': False}
+        if synchronize:
+            torch.cuda.synchronize(dev)
+        fb, rg = C.c_uint(0), C.c_uint(0)
+        _lib.check(_lib.load().mdgat_async_status(st.handle, 1, C.byref(fb), C.byref(rg)), 'mdgat_matcher_amd')
+        return {'sinkhorn_fallback': bool(fb.value)}
 
     @staticmethod
     def _f32(t, device):
         return t.to(device=device, dtype=torch.float32).contiguous()
 
     def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True):
-        if frames is not None:
-            return self._run_frames(frames[0], frames[1], normalize, want_Z, taps)
-        if not kpts0.is_cuda:
+        """One forward through the library on the current stream.  Either six arrays (keypoints / saliency / FPFH per
+        frame) or ``frames=(records0, records1)`` raw [B, N, 37] loader records.  Asynchronous; returns device tensors
+        ``(matches0, matches1, mscores0, mscores1, Z or None)``."""
+        probe = frames[0] if frames is not None else kpts0
+        if not probe.is_cuda:
             raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
                                'device; there is no CPU fallback')
-        dev = kpts0.device
-        B, N = kpts0.shape[0], kpts0.shape[1]
-        M = kpts1.shape[1]
-        if fpfh0.shape[-1] != 33 or fpfh1.shape[-1] != 33 or kpts0.shape[-1] != 3 or kpts1.shape[-1] != 3:
-            raise ValueError('expected keypoints [B, N, 3] and 33-D FPFH descriptors [B, N, 33]')
-        k0, g0, f0 = self._f32(kpts0, dev), self._f32(sigma0, dev), self._f32(fpfh0, dev)
-        k1, g1, f1 = self._f32(kpts1, dev), self._f32(sigma1, dev), self._f32(fpfh1, dev)
+        dev = probe.device
+        if frames is not None:
+            if frames[0].shape[-1] != 37 or frames[1].shape[-1] != 37 or frames[0].dim() != 3:
+                raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
+            ins = [self._f32(frames[0], dev), self._f32(frames[1], dev)]
+            B, N, M = ins[0].shape[0], ins[0].shape[1], ins[1].shape[1]
+        else:
+            if fpfh0.shape[-1] != 33 or fpfh1.shape[-1] != 33 or kpts0.shape[-1] != 3 or kpts1.shape[-1] != 3:
+                raise ValueError('expected keypoints [B, N, 3] and 33-D FPFH descriptors [B, N, 33]')
+            ins = [self._f32(t, dev) for t in (kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1)]
+            B, N, M = kpts0.shape[0], kpts0.shape[1], kpts1.shape[1]
         st = self._state_for(dev)
         lib = _lib.load()
         with torch.cuda.device(dev), st.lock:
-            need = lib.mdgat_workspace_bytes(st.handle, B, N, M)
-            if st.workspace is None or st.workspace.numel() < need:
-                st.workspace = None
-                st.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            ws = st.workspace_for(stream, lib.mdgat_workspace_bytes(st.handle, B, N, M), dev)
             m0 = torch.empty((B, N), dtype=torch.int64, device=dev)
             m1 = torch.empty((B, M), dtype=torch.int64, device=dev)
             s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
@@ -331,15 +375,13 @@ class MDGAT(nn.Module):
                 for name in _lib.TAP_NAMES:
                     t = taps.get(name)
                     setattr(tap_struct, name, t.data_ptr() if t is not None else None)
-            stream = torch.cuda.current_stream(dev).cuda_stream
-            rc = lib.mdgat_forward(
-                st.handle, B, N, M,
-                k0.data_ptr(), g0.data_ptr(), f0.data_ptr(), k1.data_ptr(), g1.data_ptr(), f1.data_ptr(),
-                m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(),
-                Z.data_ptr() if Z is not None else None,
-                C.byref(tap_struct) if tap_struct is not None else None,
-                st.workspace.data_ptr(), st.workspace.numel(), stream)
-            _lib.check(rc, 'mdgat_forward')
+            outs = (m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), Z.data_ptr() if Z is not None else None,
+                    C.byref(tap_struct) if tap_struct is not None else None, ws.data_ptr(), ws.numel(), stream)
+            if frames is not None:
+                rc = lib.mdgat_forward_frames(st.handle, B, N, M, ins[0].data_ptr(), ins[1].data_ptr(), int(bool(normalize)), *outs)
+            else:
+                rc = lib.mdgat_forward(st.handle, B, N, M, *[t.data_ptr() for t in ins], *outs)
+            _lib.check(rc, 'mdgat_forward_frames' if frames is not None else 'mdgat_forward')
         return m0, m1, s0, s1, Z
 
     def profile(self, device, enable: bool):
@@ -352,42 +394,6 @@ class MDGAT(nn.Module):
             _lib.check(_lib.load().mdgat_profile(st.handle, int(bool(enable)), ms, n), 'mdgat_profile')
         return {name: (ms[i], n[i]) for i, name in enumerate(_lib.PROF_CLASSES)}
 
-    def _run_frames(self, frames0, frames1, normalize, want_Z=False, taps=None):
-        if not frames0.is_cuda:
-            raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
-                               'device; there is no CPU fallback')
-        if frames0.shape[-1] != 37 or frames1.shape[-1] != 37 or frames0.dim() != 3:
-            raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
-        dev = frames0.device
-        B, N, M = frames0.shape[0], frames0.shape[1], frames1.shape[1]
-        r0, r1 = self._f32(frames0, dev), self._f32(frames1, dev)
-        st = self._state_for(dev)
-        lib = _lib.load()
-        with torch.cuda.device(dev), st.lock:
-            need = lib.mdgat_workspace_bytes(st.handle, B, N, M)
-            if st.workspace is None or st.workspace.numel() < need:
-                st.workspace = None
-                st.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
-            m0 = torch.empty((B, N), dtype=torch.int64, device=dev)
-            m1 = torch.empty((B, M), dtype=torch.int64, device=dev)
-            s0 = torch.empty((B, N), dtype=torch.float32, device=dev)
-            s1 = torch.empty((B, M), dtype=torch.float32, device=dev)
-            Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=dev) if want_Z else None
-            tap_struct = None
-            if taps is not None:
-                tap_struct = _lib.MdgatTaps()
-                for name in _lib.TAP_NAMES:
-                    t = taps.get(name)
-                    setattr(tap_struct, name, t.data_ptr() if t is not None else None)
-            rc = lib.mdgat_forward_frames(
-                st.handle, B, N, M, r0.data_ptr(), r1.data_ptr(), int(bool(normalize)),
-                m0.data_ptr(), m1.data_ptr(), s0.data_ptr(), s1.data_ptr(),
-                Z.data_ptr() if Z is not None else None,
-                C.byref(tap_struct) if tap_struct is not None else None,
-                st.workspace.data_ptr(), st.workspace.numel(), torch.cuda.current_stream(dev).cuda_stream)
-            _lib.check(rc, 'mdgat_forward_frames')
-        return m0, m1, s0, s1, Z
-
     @torch.no_grad()
     def match_frames(self, frames0, frames1, normalize=True, return_scores=False):
         """Match straight from the loader's raw keypoint records (``load_data.py:146-165``): ``frames`` are
@@ -397,7 +403,8 @@ class MDGAT(nn.Module):
         single = frames0.dim() == 2
         if single:
             frames0, frames1 = frames0[None], frames1[None]
-        m0, m1, s0, s1, Z = self._run_frames(frames0, frames1, normalize, want_Z=return_scores)
+        m0, m1, s0, s1, Z = self._run(None, None, None, None, None, None, want_Z=return_scores, frames=(frames0, frames1),
+                                      normalize=normalize)
         outs = [m0, m1, s0, s1] + ([Z] if return_scores else [])
         if single:
             outs = [o[0] for o in outs]

@@ -16,17 +16,36 @@ import torch
 import torch.distributed as dist
 
 
-def init_distributed(n_gpus_requested: int = 1, backend: str | None = None):
-    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local)."""
+def _group_active() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
+def init_distributed(n_gpus_requested: int = 1, backend: str | None = None, share_device: bool | None = None):
+    """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local).
+
+    A process group is created whenever the process was started by a launcher (RANK and MASTER_ADDR in the environment),
+    also with ONE rank: `python -m torch.distributed.run --nproc-per-node 1 bench.py` then runs the same RCCL
+    communicator set-up, broadcast, barriers and reduction as an 8-GPU job (tests/test_gpu_rccl.py), and the helpers
+    below run their collective whenever a group exists.  Started without a launcher there is no group and no collective.
+
+    ``share_device`` (tests only; the environment variable MDGAT_SHARE_DEVICE stands for it when the argument is None):
+    every rank drives device 0 and the collectives run on gloo - the N > 1 control flow on a box with a single GPU, where
+    RCCL refuses two ranks on one device.  It is refused on a box with more than one GPU and announced on stderr."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
-    if os.environ.get('MDGAT_SHARE_DEVICE'):
-        # test hook (tests/test_gpu_forward.py::test_bench_two_ranks_one_gpu): every rank drives device 0 and the
-        # collectives run on gloo - the N > 1 control flow of bench.py on a box with a single GPU (RCCL refuses two ranks
-        # on one device)
+    if share_device is None:
+        share_device = bool(os.environ.get('MDGAT_SHARE_DEVICE'))
+    if share_device:
+        if torch.cuda.is_available() and torch.cuda.device_count() > 1:
+            raise RuntimeError('MDGAT_SHARE_DEVICE / share_device is a single-GPU test hook: this box has '
+                               f'{torch.cuda.device_count()} GPUs, every rank must drive its own')
+        import sys
+        print(f'[mdgat shard] rank {rank}: share_device test hook active - all {world} ranks on device 0, gloo collectives',
+              file=sys.stderr, flush=True)
         local, backend = 0, 'gloo'
-    if world > 1 and not dist.is_initialized():
+    launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
+    if (world > 1 or launched) and not _group_active():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29531')
         if backend is None:
@@ -46,7 +65,7 @@ def partition(n_pairs: int, rank: int, world: int):
 
 
 def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _group_active():
         if blob.is_cuda and dist.get_backend() != 'nccl':      # gloo: through host memory
             host = blob.cpu()
             dist.broadcast(host, src=src)
@@ -58,8 +77,8 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
 
 def broadcast_weights(net, device, rank: int, world: int):
     """Rank 0 packs its parameters (BN fold etc., pack.py); the packed blob travels once by RCCL broadcast
-    and every rank installs it into its library handle.  At world 1 the module just packs lazily."""
-    if world == 1:
+    and every rank installs it into its library handle.  Without a process group the module just packs lazily."""
+    if world == 1 and not _group_active():
         return None
     from . import pack
     n = pack.blob_layout(net.config['L'])['total']
@@ -74,12 +93,15 @@ def broadcast_weights(net, device, rank: int, world: int):
 
 
 def barrier(world: int):
-    if world > 1:
-        dist.barrier()
+    if world > 1 or _group_active():
+        if dist.get_backend() == 'nccl':
+            dist.barrier(device_ids=[torch.cuda.current_device()])
+        else:
+            dist.barrier()
 
 
 def max_over_ranks(value: float, device, world: int) -> float:
-    if world == 1:
+    if world == 1 and not _group_active():
         return value
     t = torch.tensor([value], dtype=torch.float64, device=device if dist.get_backend() == 'nccl' else 'cpu')
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -88,7 +110,7 @@ def max_over_ranks(value: float, device, world: int) -> float:
 
 def gather_matches(local: torch.Tensor, world: int):
     """Optional: concatenate per-rank results on every rank (equal shard sizes)."""
-    if world == 1:
+    if world == 1 and not _group_active():
         return local
     outs = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(outs, local)
@@ -96,5 +118,5 @@ def gather_matches(local: torch.Tensor, world: int):
 
 
 def finalize(world: int):
-    if world > 1 and dist.is_initialized():
+    if _group_active():
         dist.destroy_process_group()

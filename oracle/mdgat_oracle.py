@@ -93,9 +93,9 @@ def dynamic_attention(q, k, v, topk: int, forced=None, report=None):
     [B, H, N, M] of the keys ANOTHER implementation kept for the same layer; the softmax then runs over that
     selection instead of this function's own ``topk`` (softmax over a gathered set == masked softmax, 205-209), and
     ``report`` (a list) receives one dict per call describing every row where the two selections differ:
-    ``rows`` = number of such rows, ``max_gap`` = largest |logit - k-th largest logit| over the keys in the symmetric
-    difference (how far from a tie the disagreement is, in the units of the logits), ``bad_count`` = rows whose forced
-    selection does not hold exactly ``topk`` keys."""
+    ``rows`` = number of such rows (``rows_per_pair``: the same count per batch element), ``max_gap`` = largest
+    |logit - k-th largest logit| over the keys in the symmetric difference (how far from a tie the disagreement is, in
+    the units of the logits), ``bad_count`` = rows whose forced selection does not hold exactly ``topk`` keys."""
     dh = q.shape[1]
     m = k.shape[3]
     if topk > m:
@@ -118,6 +118,7 @@ def dynamic_attention(q, k, v, topk: int, forced=None, report=None):
             kth = top.values[..., -1:]
             gap = torch.where(diff, (logits - kth).abs(), torch.zeros_like(logits))
             report.append({'rows': int(diff.any(-1).sum()), 'total_rows': diff[..., 0].numel(),
+                           'rows_per_pair': diff.any(-1).sum(dim=(1, 2)),
                            'max_gap': float(gap.max()), 'bad_count': int((forced.sum(-1) != topk).sum()),
                            'row_gaps': gap.amax(-1)[diff.any(-1)]})
     return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob

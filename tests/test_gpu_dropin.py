@@ -1,0 +1,137 @@
+"""The unchanged-caller path: `from models.mdgat import MDGAT` (test.py:12, test_registration_metric.py:12) resolved by the
+import-path shim under integration/, then the call sequence of test.py:134-214 - checkpoint dict saved by train.py:288-294
+loaded with torch.load, DataParallel wrapper and its `module.` keys, net.double().eval() before every forward, the
+collated loader dict (load_data.py:299-321: tensors plus the non-tensor `sequence`, the index tensor `idx0`, gt matches,
+T_gt, rep) moved with .cuda() the way test.py:194-199 does, `pred = {**pred, **data}` and the per-pair numpy reads."""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture()
+def models_mdgat():
+    """`import models.mdgat` the way the reference's scripts do, with <repo>/integration ahead on sys.path."""
+    shim = os.path.join(ROOT, 'integration')
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'models' or k.startswith('models.')}
+    sys.path.insert(0, shim)
+    try:
+        yield importlib.import_module('models.mdgat')
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+def _loader_batch(B, n, m, first_pair):
+    """What DataLoader(SparseDataset) yields (load_data.py:299-321 after default collation), synthetic content."""
+    from mdgat_matcher_amd import synth
+    d = synth.make_batch(B, n, m, first_pair=first_pair)
+    d['sequence'] = ['00'] * B                                   # strings: collated into a list
+    d['idx0'] = torch.arange(first_pair, first_pair + B)         # ints: collated into an int64 tensor
+    d['T_gt'] = torch.eye(4, dtype=torch.float64)[None].repeat(B, 1, 1)
+    d['rep'] = torch.full((B,), n // 2, dtype=torch.int64)
+    return d
+
+
+def test_unchanged_caller_sequence_of_test_py(models_mdgat, golden_dir, tmp_path):
+    from torch.autograd import Variable
+    from mdgat_matcher_amd import synth
+    MDGAT = models_mdgat.MDGAT                                   # test.py:12
+    g = np.load(os.path.join(golden_dir, 'fwd_n64_L4_S20.npz'))
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    # the checkpoint train.py:288-294 writes: DataParallel state dict + bookkeeping
+    ckpt = {'net': {'module.' + kk: v for kk, v in synth.make_state_dict(L=L, seed=seed).items()}, 'optimizer': {}, 'epoch': 3,
+            'lr_schedule': 1e-4, 'loss': 0.5}
+    path = os.path.join(tmp_path, 'best_model.pth')
+    torch.save(ckpt, path)
+    checkpoint = torch.load(path, map_location={'cuda:2': 'cuda:0'})          # test.py:135
+    config = {'net': {'sinkhorn_iterations': S, 'match_threshold': 0.2, 'lr': 1e-4, 'loss_method': 'triplet_loss', 'k': k,
+                      'descriptor': 'FPFH', 'mutual_check': False, 'triplet_loss_gamma': 0.5, 'train_step': 3, 'L': L}}
+    net = MDGAT(config.get('net', {}))                                         # test.py:156
+    torch.optim.Adam(net.parameters(), lr=config.get('net', {}).get('lr'))     # test.py:157 (parameters must be real leaves)
+    net = torch.nn.DataParallel(net)                                           # test.py:158
+    net.load_state_dict(checkpoint['net'])                                     # test.py:159
+    device = torch.device('cuda:{}'.format(0))
+    net.to(device)                                                             # test.py:172
+    with torch.no_grad():
+        for it in range(2):
+            pred = _loader_batch(B, n, m, first_pair)
+            net.double().eval()                                                # test.py:193
+            for kk in pred:                                                    # test.py:194-199
+                if kk != 'idx0' and kk != 'idx1' and kk != 'sequence':
+                    if type(pred[kk]) == torch.Tensor:
+                        pred[kk] = Variable(pred[kk].cuda().detach())
+                    else:
+                        pred[kk] = Variable(torch.stack(pred[kk]).cuda().detach())
+            data = net(pred)                                                   # test.py:201
+            pred = {**pred, **data}
+            for b in range(len(pred['idx0'])):                                 # test.py:204-217
+                kpts0, kpts1 = pred['keypoints0'][b].cpu().numpy(), pred['keypoints1'][b].cpu().numpy()
+                matches, matches1, conf = (pred['matches0'][b].cpu().detach().numpy(), pred['matches1'][b].cpu().detach().numpy(),
+                                           pred['matching_scores0'][b].cpu().detach().numpy())
+                valid = matches > -1
+                mkpts0, mkpts1, mconf = kpts0[valid], kpts1[matches[valid]], conf[valid]
+                assert mkpts0.shape == mkpts1.shape and mconf.shape[0] == valid.sum()
+                np.testing.assert_array_equal(matches, g['default_matches0'][b])
+                np.testing.assert_array_equal(matches1, g['default_matches1'][b])
+                assert np.abs(conf - g['default_mscores0'][b]).max() < 1e-4
+                assert conf.dtype == np.float64
+            assert float(pred['loss'].mean()) == 0.0                           # (train.py:245 takes the mean; inference: zero)
+
+
+def test_all_dustbin_batch_returns_integer_zero_scores(models_mdgat, golden_dir):
+    """mdgat.py:465-467: when no frame-0 keypoint of the batch is matched the reference returns torch.zeros_like(indices) -
+    INT64 zeros - for both score vectors (tests/golden/edge_cases.npz holds the reference's output)."""
+    from mdgat_matcher_amd import synth
+    g = np.load(os.path.join(golden_dir, 'edge_cases.npz'))
+    assert bool(g['alldust_mscores_is_int'])
+    net = models_mdgat.MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=10))
+    net.load_state_dict(synth.make_state_dict(L=1, seed=3, bin_score=50.0))
+    net = net.double().eval().to('cuda:0')
+    with torch.no_grad():
+        out = net(synth.make_batch(1, 32, 32, device='cuda:0'))
+    np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g['alldust_matches0'])
+    np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g['alldust_matches1'])
+    for key in ('matching_scores0', 'matching_scores1'):
+        assert out[key].dtype == torch.int64 and not out[key].any()
+    # with a match anywhere in the batch the scores are floating point again (module dtype)
+    net.load_state_dict(synth.make_state_dict(L=1, seed=3, bin_score=1.0))
+    with torch.no_grad():
+        out = net.double().eval()(synth.make_batch(1, 32, 32, device='cuda:0'))
+    assert out['matching_scores0'].dtype == torch.float64 and (out['matches0'] >= 0).any()
+
+
+def test_free_functions_of_models_mdgat(models_mdgat, golden_dir):
+    """attention / dynamic_attention / log_optimal_transport / knn / get_graph_feature under their reference names and
+    signatures (mdgat.py:8-32, 190-210, 288-308), against the reference's outputs in tests/golden/op_vectors.npz."""
+    g = np.load(os.path.join(golden_dir, 'op_vectors.npz'))
+    dev = 'cuda:0'
+    q, k, v = (torch.from_numpy(g[x]).to(dev) for x in ('att_q', 'att_k', 'att_v'))
+    msg, prob = models_mdgat.attention(q, k, v)
+    assert prob is None and msg.dtype == q.dtype and tuple(msg.shape) == tuple(g['att_full'].shape)
+    assert np.abs(msg.cpu().numpy() - g['att_full']).max() < 1e-5
+    for kk in (1, 8, 56):                                          # 56 = all keys, more than the 40 queries
+        dyn, _ = models_mdgat.dynamic_attention(q, k, v, kk)
+        assert np.abs(dyn.cpu().numpy() - g[f'att_dyn{kk}']).max() < 1e-5, kk
+    with pytest.raises(RuntimeError):
+        models_mdgat.dynamic_attention(q, k, v, 57)                # torch.topk raises there
+    s = torch.from_numpy(g['sk_64x64_scores']).to(dev)
+    iters, alpha = g['sk_64x64_meta']
+    Z = models_mdgat.log_optimal_transport(s, torch.tensor(alpha, dtype=torch.float64), int(iters))
+    assert Z.dtype == s.dtype and np.abs(Z.cpu().numpy() - g['sk_64x64_Z']).max() < 1e-5
+    for Cc in (3, 128):
+        x, src = torch.from_numpy(g[f'knn{Cc}_x']).to(dev), torch.from_numpy(g[f'knn{Cc}_s']).to(dev)
+        np.testing.assert_array_equal(models_mdgat.knn(x, src, 9).cpu().numpy(), g[f'knn{Cc}_idx'])
+        np.testing.assert_array_equal(models_mdgat.get_graph_feature(x, src, 9).cpu().numpy(), g[f'knn{Cc}_adj'])
+    mlp = models_mdgat.MLP([4, 32, 64])
+    assert [type(mm).__name__ for mm in mlp] == ['Conv1d', 'BatchNorm1d', 'ReLU', 'Conv1d']

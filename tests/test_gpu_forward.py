@@ -11,14 +11,16 @@ pytestmark = pytest.mark.gpu
 from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
 
-from parity_util import assert_attributed, attributed_parity  # noqa: E402
+from parity_util import assert_attributed, assert_plain, assert_plain_vs_oracle, attributed_parity  # noqa: E402
 
 DEV = 'cuda:0'
 Z_TOL = 1e-4        # north star: soft-assignment matrix within 1e-4 (fp32-class kernels vs fp64 reference)
 # Dynamic (top-k) layers are discontinuous in their logits.  Configurations that have them are held to the bar in the
 # two-statement form of tests/parity_util.py: Z within 1e-4 everywhere and identical matches against the fp64 oracle
 # run with the HIP path's own top-k selections, and every selection that differs from the oracle's is a near-tie
-# below GAP_EPS.  Where no selection differs, the plain comparison with the reference's golden output is asserted too.
+# below GAP_EPS.  On top of that, ALWAYS (assert_plain): matches bit-identical to the unforced fp64 result (the
+# reference's golden output where one is held), plain max|dZ| < 2e-3, at most 1e-3 of the entries beyond 1e-4, and the
+# literal 1e-4 on every pair in which no selection flipped.
 
 
 def _g(golden_dir, name):
@@ -94,8 +96,9 @@ def test_forward_dict_contract_and_variants(golden_dir, name):
 
 @pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100'])
 def test_config_shapes_golden(golden_dir, name):
-    """BASELINE configs[0] / configs[1] shapes with the default dynamic schedule, against the REFERENCE's own fp64
-    output (tests/golden/cfg_*.npz) and against the oracle with the HIP selections forced."""
+    """BASELINE configs[0] / configs[1] shapes (8 pairs each) with the default dynamic schedule, against the REFERENCE's
+    own fp64 output (tests/golden/cfg_*.npz) - unconditionally: matches bit-identical, plain |dZ| bounded, the literal
+    1e-4 on every pair without a flipped selection - and against the oracle with the HIP selections forced."""
     g = _g(golden_dir, name)
     net, _, (B, n, m, L) = _build(g)
     seed, first_pair = int(g['meta'][5]), int(g['meta'][6])
@@ -104,20 +107,13 @@ def test_config_shapes_golden(golden_dir, name):
     sd = synth.make_state_dict(L=L, seed=seed, bin_score=float(g['bin_score']) if 'bin_score' in g else 1.0)
     res = attributed_parity(net, cfg, sd, synth.make_batch(B, n, m, first_pair=first_pair), DEV)
     assert_attributed(res, name)
-    m0, m1, s0, s1, Z = res['out']
+    Z = res['out'][4]
     # column marginals are exact by construction and independent of the top-k selections
     assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
-    Zc = Z.cpu().double().numpy()
-    errs = np.concatenate([np.abs(Zc[:, ::8, ::8] - g['Z_sub']).ravel(), np.abs(Zc[:, -1, :] - g['Z_lastrow']).ravel(),
-                           np.abs(Zc[:, :, -1] - g['Z_lastcol']).ravel()])
-    mm = (m0.cpu().numpy() != g['default_matches0']).sum() + (m1.cpu().numpy() != g['default_matches1']).sum()
-    print(f'[parity] {name} vs the reference golden: max|dZ| {errs.max():.3e}, entries > 1e-4: {(errs > Z_TOL).mean():.2e}, '
-          f'matches differing {mm}')
-    if res['flip_rows'] == 0:       # same selections as the reference: the plain bar applies
-        assert errs.max() < Z_TOL
-        np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
-        np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
-        assert np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max() < Z_TOL
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    assert_plain(res, ref_Z, g['default_matches0'], g['default_matches1'], g['default_mscores0'], g['default_mscores1'],
+                 name + ' (reference golden)',
+                 z_index=lambda Zc: np.concatenate([Zc[:, ::8, ::8].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1))
 
 
 def test_dataparallel_dropin_like_test_py(golden_dir):
@@ -210,7 +206,8 @@ def test_bench_shape_properties():
     cpu = {k: v[:2].cpu().double() for k, v in data.items()}
     res = attributed_parity(net, synth.default_config(L=L), sd, cpu, DEV)
     assert_attributed(res, 'bench shape, pairs 0-1')
-    assert torch.equal(res['out'][4], Z[:2])
+    assert torch.equal(res['out'][0], m0[:2]) and (res['out'][4] - Z[:2]).abs().max() <= 5e-6       # (tapped kernels: parity_util)
+    assert_plain_vs_oracle(res, synth.default_config(L=L), sd, cpu, 'bench shape, pairs 0-1')
 
 
 @pytest.mark.parametrize('n,L,S', [(256, 4, 20), (512, 9, 100)])
@@ -235,15 +232,49 @@ def test_full_attention_configs_strict(n, L, S):
     assert (s0.cpu().double() - ref['matching_scores0']).abs().max() < Z_TOL
 
 
-def test_f16_attention_mode_configs2():
-    """BASELINE configs[2]: q, k, v and the probabilities as single f16 values in the attention products (fp32
-    accumulation, softmax statistics and Sinkhorn).  A throughput mode OUTSIDE the parity bar: the test pins what it is -
-    engaged (results differ from the fp32 path), close (max|dZ| < 2e-2 against the fp64 oracle where the fp32 path
-    has 1e-4) and nearly the same assignment (>= 97 % of the matches identical)."""
-    L, S, n = 9, 100, 512
+def test_configs3_per_gpu_workload():
+    """BASELINE configs[3]: 4096 pairs sharded 8-way = 512 pairs per GPU (N=M=512, L=9, S=100, fp32).  One rank's
+    workload runs as 8 slices of 64 pairs inside mdgat_forward (api.hip: forward_sliced): deterministic, every pair
+    independent of its batch and of the slice it lands in (pairs either side of a slice boundary and the last one,
+    alone vs in the batch: bit-identical), and sampled pairs against the fp64 oracle in both forms of parity_util.py."""
+    B, n, L, S = 512, 512, 9, 100
     cfg = synth.default_config(L=L, sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=0)
-    data = synth.make_batch(2, n, n, first_pair=5)
+    net = MDGAT(cfg)
+    net.load_state_dict(sd)
+    net = net.eval().to(DEV)
+    data = synth.make_batch(B, n, n, device=DEV, dtype=torch.float32)
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
+    again = net.match(*args, return_scores=True)
+    for a, b in zip((m0, m1, s0, s1, Z), again):
+        assert torch.equal(a, b)                                    # determinism
+    for p in (0, 63, 64, 300, 511):                                 # 63 | 64: the first slice boundary
+        alone = net.match(*[a[p:p + 1] for a in args], return_scores=True)
+        for a, b in zip((m0, m1, s0, s1, Z), alone):
+            assert torch.equal(a[p], b[0]), p
+    col = torch.logsumexp(Z.double(), dim=1)                        # exact column marginals, all 512 pairs
+    assert col[:, :n].abs().max() < 1e-4 and (col[:, n] - np.log(n)).abs().max() < 1e-4
+    assert (m0 >= 0).any(dim=1).all()                               # every pair found matches (half of its keypoints are shared)
+    idx = [63, 64, 300, 511]
+    cpu = {k: v[idx].cpu().double() for k, v in data.items()}
+    res = attributed_parity(net, cfg, sd, cpu, DEV)
+    assert_attributed(res, 'configs[3], pairs 63 / 64 / 300 / 511')
+    assert torch.equal(res['out'][0], m0[idx]) and (res['out'][4] - Z[idx]).abs().max() <= 5e-6     # (tapped kernels: parity_util)
+    assert_plain_vs_oracle(res, cfg, sd, cpu, 'configs[3], pairs 63 / 64 / 300 / 511')
+
+
+def test_f16_attention_mode_configs2():
+    """BASELINE configs[2]: q, k, v and the probabilities as single f16 values in the attention products (fp32
+    accumulation, softmax statistics and Sinkhorn).  A throughput mode OUTSIDE the 1e-4 bar; the test pins what it is on
+    8 pairs: engaged (results differ from the fp32 path), close (max|dZ| against the fp64 oracle bounded), and how far the
+    ASSIGNMENT is from the reference's: SURVEY section 7 expected the argmax to survive reduced-precision attention - it
+    does on most pairs but not bit-exactly (a handful of keypoints per 1024 change their match, near-ties between an
+    inner column and the dustbin), so the bound is the measured identity rate with margin, not equality."""
+    L, S, n, B = 9, 100, 512, 8
+    cfg = synth.default_config(L=L, sinkhorn_iterations=S)
+    sd = synth.make_state_dict(L=L, seed=0)
+    data = synth.make_batch(B, n, n, first_pair=5)
     cap = {}
     ref = O.mdgat_forward(sd, cfg, data, cap)
     d = {k: v.to(DEV) for k, v in data.items()}
@@ -255,13 +286,29 @@ def test_f16_attention_mode_configs2():
         out[dt] = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
                             d['scores0'], d['scores1'], return_scores=True)
     e32 = (out['fp32'][4].cpu().double() - cap['Z']).abs().max().item()
-    e16 = (out['f16'][4].cpu().double() - cap['Z']).abs().max().item()
-    agree = (out['f16'][0].cpu() == ref['matches0']).double().mean().item()
-    print('attention_dtype f16: max|dZ|', e16, '(fp32 path', e32, ') matches identical', agree)
+    e16 = (out['f16'][4].cpu().double() - cap['Z']).abs().amax(dim=(1, 2))
+    same0 = (out['f16'][0].cpu() == ref['matches0']).double().mean(dim=1)
+    same1 = (out['f16'][1].cpu() == ref['matches1']).double().mean(dim=1)
+    agree = torch.minimum(same0, same1)
+    exact = int(((same0 == 1) & (same1 == 1)).sum())
+    print('attention_dtype f16, 8 pairs: max|dZ| per pair', [f'{x:.2e}' for x in e16.tolist()], '(fp32 path', f'{e32:.2e})',
+          'matches identical per pair', [f'{x:.4f}' for x in agree.tolist()], 'pairs with bit-identical matches', exact, 'of', B)
     assert not torch.equal(out['f16'][4], out['fp32'][4])
-    assert e16 < 2e-2 and agree >= 0.97
+    assert e16.max() < 2e-2
+    assert agree.min() >= 0.995 and agree.mean() >= 0.998       # measured: 6 of 8 pairs bit-identical, the other two 0.998
+    # the fp32 path on the same pairs: matches identical to the reference (the argmax bar is the fp32 path's)
+    assert torch.equal(out['fp32'][0].cpu(), ref['matches0']) and torch.equal(out['fp32'][1].cpu(), ref['matches1'])
     with pytest.raises(ValueError):
         MDGAT(dict(cfg, attention_dtype='int8'))
+    # a configs[2]-sized batch (512 pairs, sliced) in f16 mode: deterministic, batch-independent across a slice boundary
+    big = synth.make_batch(512, n, n, device=DEV, dtype=torch.float32)
+    bargs = (big['keypoints0'], big['descriptors0'], big['keypoints1'], big['descriptors1'], big['scores0'], big['scores1'])
+    r1 = net.match(*bargs)
+    r2 = net.match(*bargs)
+    assert all(torch.equal(a, b) for a, b in zip(r1, r2))
+    for p in (63, 64, 511):
+        alone = net.match(*[a[p:p + 1] for a in bargs])
+        assert all(torch.equal(a[p], b[0]) for a, b in zip(r1, alone)), p
     # shapes no f16 kernel covers ignore the flag: bit-identical to the default path
     small = synth.make_batch(2, 100, 75, first_pair=9)
     ds = {k: v.to(DEV) for k, v in small.items()}
@@ -298,7 +345,9 @@ def test_large_frames(n, m, L, S, k):
         assert err.max() < Z_TOL
         assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
     else:
-        assert_attributed(attributed_parity(net, cfg, sd, data, DEV), f'large {n}x{m} L={L} S={S}')
+        res = attributed_parity(net, cfg, sd, data, DEV)
+        assert_attributed(res, f'large {n}x{m} L={L} S={S}')
+        assert_plain_vs_oracle(res, cfg, sd, data, f'large {n}x{m} L={L} S={S}')
 
 
 @pytest.mark.parametrize('B,n,m,k', [(3, 37, 53, []), (2, 130, 75, []), (5, 20, 44, [8, None]), (1, 1, 9, []), (2, 128, 256, [])])
@@ -314,7 +363,9 @@ def test_ragged_shapes_vs_oracle(B, n, m, k):
     net = net.double().eval().to(DEV)
     data = synth.make_batch(B, n, m, first_pair=2)
     if k != []:
-        assert_attributed(attributed_parity(net, cfg, sd, data, DEV), f'ragged {B}x{n}x{m}')
+        res = attributed_parity(net, cfg, sd, data, DEV)
+        assert_attributed(res, f'ragged {B}x{n}x{m}')
+        assert_plain_vs_oracle(res, cfg, sd, data, f'ragged {B}x{n}x{m}')
         return
     cap = {}
     ref = O.mdgat_forward(sd, cfg, data, cap)
@@ -324,6 +375,102 @@ def test_ragged_shapes_vs_oracle(B, n, m, k):
     err = (Z.cpu().double() - cap['Z']).abs()
     assert err.max() < Z_TOL, err.max()
     assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
+
+
+def test_forward_falls_back_when_sinkhorn_loses_a_partner(monkeypatch):
+    """Whole forward with the Sinkhorn fallback forced (MDGAT_SK_FORCE_FALLBACK, see test_gpu_ops.py): the matches come
+    from the streaming kernel's Z inside the same call - with and without a Z requested, sliced batches included - are
+    identical to the normal path's, the handle reports the fallback as information and stays usable."""
+    cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=40)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    net = net.eval().to(DEV)
+    d = synth.make_batch(100, 512, 512, device=DEV, dtype=torch.float32)          # 100 pairs: two slices of 50
+    args = (d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1'])
+    ref = net.match(*args, return_scores=True)
+    assert net.check(DEV) == {'sinkhorn_fallback': False}
+    monkeypatch.setenv('MDGAT_SK_FORCE_FALLBACK', '1')
+    with_z = net.match(*args, return_scores=True)
+    without_z = net.match(*args)
+    status = net.check(DEV)
+    monkeypatch.delenv('MDGAT_SK_FORCE_FALLBACK')
+    assert status == {'sinkhorn_fallback': True}
+    assert torch.isfinite(with_z[4]).all() and (with_z[4] - ref[4]).abs().max() < 1e-4
+    for a, b, c in zip(ref[:2], with_z[:2], without_z[:2]):
+        assert torch.equal(a, b) and torch.equal(a, c)
+    for a, b, c in zip(ref[2:4], with_z[2:4], without_z[2:4]):
+        assert (a - b).abs().max() < 1e-4 and torch.equal(b, c)
+    again = net.match(*args, return_scores=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, again)) and net.check(DEV) == {'sinkhorn_fallback': False}
+
+
+def test_two_streams_run_forwards_concurrently():
+    """Two B=64 forwards of BASELINE configs[1] in flight at once on two streams of one device (each stream has its own
+    workspace; the Sinkhorn cluster kernels of both are on the device together, every workgroup of which waits for its
+    partners): both must return what they return alone, bit for bit - finite, oracle-consistent (the serial results are
+    held to the oracle by the tests above) - whichever path the Sinkhorn launches took."""
+    L = 9
+    net = MDGAT(synth.default_config(L=L))
+    net.load_state_dict(synth.make_state_dict(L=L, seed=0))
+    net = net.eval().to(DEV)
+    batches = [synth.make_batch(64, 512, 512, first_pair=64 * i, device=DEV, dtype=torch.float32) for i in range(2)]
+    args = [(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1']) for d in batches]
+    serial = [net.match(*a, return_scores=True) for a in args]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV) for _ in range(2)]
+    for rounds in range(3):
+        outs = [None, None]
+        for _ in range(4):                                   # several forwards per stream back to back: the launches interleave
+            for i, st in enumerate(streams):
+                with torch.cuda.stream(st):
+                    outs[i] = net.match(*args[i], return_scores=True)
+        torch.cuda.synchronize()
+        status = net.check(DEV)
+        for i in range(2):
+            assert torch.isfinite(outs[i][4]).all()
+            if status['sinkhorn_fallback']:                  # a launch was redone by the streaming kernel: same matches, Z to round-off
+                assert torch.equal(outs[i][0], serial[i][0]) and torch.equal(outs[i][1], serial[i][1])
+                assert (outs[i][4] - serial[i][4]).abs().max() < 1e-4
+            else:
+                for a, b in zip(outs[i], serial[i]):
+                    assert torch.equal(a, b)
+    print('two-stream forwards: sinkhorn fallback taken in the last round:', status['sinkhorn_fallback'])
+
+
+def test_f16_operand_range_is_guarded():
+    """Every operand of the matrix products is an f16 head + f16 residual: |activation| must stay
+    below 65504.  Synthetic weights keep activations at O(1-10); a checkpoint that does not is NOT silently turned into
+    inf / NaN: the kernels flag values >= 6e4 or non-finite ones where the activations pass (layer inputs, scores) and
+    the failing call raises in forward(); match() - asynchronous - reports through check() or the handle's next call."""
+    L = 2
+    cfg = synth.default_config(L=L, k=[16, None, 16, None], sinkhorn_iterations=10)
+    data = synth.make_batch(2, 64, 64, device=DEV)
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    for key, factor in (('kenc.encoder.9.weight', 3e5), ('gnn.layers.1.mlp.3.weight', 1e6), ('gnn.layers.2.attn.proj.2.weight', 1e6),
+                        ('gnn.layers.0.attn.proj.0.weight', 1e5)):
+        sd = synth.make_state_dict(L=L, seed=1)
+        sd[key] = sd[key] * factor
+        net = MDGAT(cfg)
+        net.load_state_dict(sd)
+        net = net.double().eval().to(DEV)
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            with torch.no_grad():
+                net(data)
+        net.match(*args)                                     # asynchronous: no error yet ...
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            net.check(DEV)                                   # ... until the caller asks
+        net.match(*args)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            net.match(*args)                                 # ... or the next call on the handle finds it
+        net.check(DEV)                                       # (reported once: the status is clear again)
+    sd = synth.make_state_dict(L=L, seed=1)                  # the unscaled weights pass
+    net = MDGAT(cfg)
+    net.load_state_dict(sd)
+    net = net.double().eval().to(DEV)
+    with torch.no_grad():
+        out = net(data)
+    assert torch.isfinite(out['matching_scores0']).all() and net.check(DEV) == {'sinkhorn_fallback': False}
 
 
 def test_repeatable_bitwise():

@@ -78,6 +78,38 @@ def test_attention_full(N, M, cross):
         assert err < 1e-5, (side, err)
 
 
+@pytest.mark.parametrize('N,topk', [(512, 0), (512, 128), (320, 0), (100, 30), (1024, 0), (1024, 128)])
+@pytest.mark.parametrize('case', ['small_q_large_k', 'small_v', 'small_everything', 'large'])
+def test_attention_mismatched_magnitudes(N, topk, case):
+    """The q / k / v planes carry an UNSCALED residual, lo = f16(x - hi) (common.hpp): its rounding is absolute (2^-25),
+    an f16 denormal below |x| = 0.25, so the fp32-class guarantee of the products is relative to operands of order one.
+    Trained checkpoints need not be there: queries ~1e-3 against keys ~30, values ~1e-3, everything ~1e-3, operands of
+    order 100.  Messages must agree with the fp64 oracle to 1e-5 RELATIVE to the magnitude of the values (and the
+    selection of a dynamic layer, where the logits are resolved at all, up to near-ties)."""
+    rs = np.random.RandomState(N + topk + len(case))
+    qkv = rs.standard_normal((2, 2 * N, 3, 4, 32))
+    sq, sk, sv = {'small_q_large_k': (1e-3 * 32 ** 0.5, 30.0, 1.0), 'small_v': (1.3, 1.3, 1e-3),
+                  'small_everything': (2e-2, 2e-2, 1e-3), 'large': (8.0, 8.0, 100.0)}[case]
+    qkv[:, :, 0] *= sq
+    qkv[:, :, 1] *= sk
+    qkv[:, :, 2] *= sv
+    qkv = torch.from_numpy(qkv)
+    out = ops.attention(qkv.to(DEV), N, N, False, topk=topk).cpu().double()
+    for lo, hi in ((0, N), (N, 2 * N)):
+        q, kk, v = (qkv[:, lo:hi, i].permute(0, 3, 2, 1) for i in range(3))
+        if topk:
+            ref, _ = O.dynamic_attention(q, kk, v, topk)
+            logits = torch.einsum('bdhn,bdhm->bhnm', q, kk) / 32 ** 0.5
+            top = logits.topk(topk + 1, dim=3).values
+            ok = ((top[..., topk - 1] - top[..., topk]) >= 5e-6 * max(1.0, float(logits.abs().max()) / 10)).permute(0, 2, 1)   # [B, n, H]
+            assert ok.double().mean() > 0.99
+        else:
+            ref, _ = O.attention(q, kk, v)
+            ok = torch.ones(2, N, 4, dtype=torch.bool)
+        err = (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().reshape(2, N, 4, 32).amax(3)
+        assert err[ok].max() < 1e-5 * sv, (case, float(err[ok].max()), sv)
+
+
 @pytest.mark.parametrize('N,M,k', [(64, 64, 16), (64, 64, 1), (64, 64, 63), (40, 56, 8), (512, 512, 128), (512, 512, 64),
                                    (256, 256, 128), (100, 70, 70), (48, 64, 16), (300, 500, 64), (1024, 1024, 128),
                                    (2048, 2048, 64), (700, 600, 100), (1500, 520, 64), (513, 513, 512)])
@@ -317,6 +349,28 @@ def test_sinkhorn_vs_oracle(N, M, iters):
     for streaming in (False, True):     # cluster kernel (N, M <= 512) and streaming kernel
         Z = ops.sinkhorn(s.to(DEV), 0.7, iters, streaming=streaming).cpu().double()
         assert (Z - ref).abs().max() < 1e-4, streaming
+
+
+@pytest.mark.parametrize('B,N,M', [(3, 512, 512), (70, 300, 512), (2, 1024, 700), (1, 2048, 2048)])
+def test_sinkhorn_fallback_after_a_lost_partner(B, N, M, monkeypatch):
+    """The cluster kernel's workgroups wait for their partners with bounded spins; a workgroup that gives up raises the
+    launch's error word and the gated streaming kernel launched behind every cluster launch redoes the launch.  The hook
+    MDGAT_SK_FORCE_FALLBACK=1 sets that word up front, so the gated kernel and - through mdgat_forward - the extraction
+    from its Z run for real: same Z as the streaming kernel on its own (bit for bit: it IS that kernel), 1e-4 from the
+    oracle, and the cluster path again once the hook is off."""
+    s = torch.randn(B, N, M, device=DEV, generator=torch.Generator(DEV).manual_seed(N + M)) * 3
+    Zs = ops.sinkhorn(s, 0.8, 25, streaming=True)
+    Zc = ops.sinkhorn(s, 0.8, 25)
+    monkeypatch.setenv('MDGAT_SK_FORCE_FALLBACK', '1')
+    Zf = ops.sinkhorn(s, 0.8, 25)
+    torch.cuda.synchronize()
+    monkeypatch.delenv('MDGAT_SK_FORCE_FALLBACK')
+    assert torch.equal(Zf, Zs)
+    assert not torch.equal(Zc, Zs) and (Zc - Zs).abs().max() < 1e-4
+    assert torch.equal(ops.sinkhorn(s, 0.8, 25), Zc)
+    if N <= 1024:
+        ref = O.log_optimal_transport(s.cpu().double(), 0.8, 25)
+        assert (Zf.cpu().double() - ref).abs().max() < 1e-4
 
 
 @pytest.mark.parametrize('B,N,M', [(1, 512, 512), (70, 512, 512), (5, 200, 300), (9, 500, 37), (3, 128, 512), (130, 129, 64),

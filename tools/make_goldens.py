@@ -260,8 +260,9 @@ def main():
     gen_forward(M, 'fwd_n64_L4_S20', 1, 64, 64, 4, 20, small_k)
     gen_forward(M, 'fwd_n64_L5_S20', 2, 64, 64, 5, 20, small_k)
     gen_forward(M, 'fwd_n48m64_L4_S20', 1, 48, 64, 4, 20, small_k, bin_score=0.37, first_pair=5)
-    gen_config(M, 'cfg_n256_L4_S20', 1, 256, 256, 4, 20, synth.DEFAULT_K)
-    gen_config(M, 'cfg_n512_L9_S100', 2, 512, 512, 9, 100, synth.DEFAULT_K)
+    # BASELINE configs[0] / configs[1] shapes, 8 reference-held pairs each (round 3: the headline shape had 2)
+    gen_config(M, 'cfg_n256_L4_S20', 8, 256, 256, 4, 20, synth.DEFAULT_K)
+    gen_config(M, 'cfg_n512_L9_S100', 8, 512, 512, 9, 100, synth.DEFAULT_K)
     gen_ops(M)
     gen_edges(M)
 

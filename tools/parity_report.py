@@ -5,7 +5,13 @@ Per configuration and pair: max|dZ| of the HIP path against the fp64 oracle run 
 whether the matches are identical, the number of dynamic-attention rows whose selection differs from the oracle's own
 top-k and the largest distance of a disagreeing key from the k-th logit (tests/parity_util.py states the bar), then
 the same pair against the PLAIN fp64 oracle (what a flip costs), and - as a yardstick for the arithmetic - the flips
-a plain fp32 PyTorch run of the oracle makes against fp64 on the same pairs."""
+a plain fp32 PyTorch run of the oracle makes against fp64 on the same pairs.
+
+Round 3 adds the CAUSE of the flips: the HIP path's own fp32 descriptors entering every dynamic layer (taps) are fed to
+an fp64 q/k projection and an fp64 q.k - the selection that exact arithmetic makes of the HIP path's INPUT.  Rows where
+the HIP selection differs from that one are caused inside the layer (projection + split-f16 q.k products, what an fp64
+re-evaluation of the near-threshold logits could repair); the remaining flips against the fp64 trajectory come with the
+input (error accumulated by the layers before) and no local re-evaluation reaches them."""
 import os
 import sys
 import time
@@ -33,6 +39,40 @@ def fp32_flips(sd, cfg, data, own64):
     return rows, cap['Z'].double()
 
 
+def local_flips(net, sd, data, L):
+    """{dynamic layer: rows whose HIP selection differs from the fp64 top-k of the HIP path's OWN fp32 layer input}."""
+    from mdgat_matcher_amd import ops
+    dev = {k: v.to('cuda:0') for k, v in data.items()}
+    k0 = dev['keypoints0']
+    B, N, M = k0.shape[0], k0.shape[1], dev['keypoints1'].shape[1]
+    sched = net._topk_schedule()
+    words = ops.topk_sel_words(B, N, M)
+    sel = torch.zeros(len(sched) * words, dtype=torch.int32, device=k0.device)
+    xl = torch.empty(2 * L, B, N + M, 128, device=k0.device)
+    net._run(k0, dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=False,
+             taps={'topk_sel': sel, 'x_layers': xl})
+    torch.cuda.synchronize()
+    xl = xl.cpu().double()
+    out = {}
+    for i, kk in enumerate(sched):
+        if kk <= 0:
+            continue
+        masks = ops.topk_sel_to_masks(sel[i * words:(i + 1) * words], B, N, M, cross=bool(i & 1))
+        rows = 0
+        for side in range(2):
+            x = (xl[i - 1][:, :N] if side == 0 else xl[i - 1][:, N:]).transpose(1, 2)      # [B, 128, n]: the HIP path's input
+            other = (xl[i - 1][:, N:] if side == 0 else xl[i - 1][:, :N]).transpose(1, 2)
+            src = other if (i & 1) else x
+            p = f'gnn.layers.{i}.attn'
+            q = O._pointwise(sd[f'{p}.proj.0.weight'], sd[f'{p}.proj.0.bias'], x).view(B, 32, 4, -1)
+            kk_ = O._pointwise(sd[f'{p}.proj.1.weight'], sd[f'{p}.proj.1.bias'], src).view(B, 32, 4, -1)
+            logits = torch.einsum('bdhn,bdhm->bhnm', q, kk_) / 32 ** 0.5
+            own = torch.zeros_like(logits, dtype=torch.bool).scatter_(3, logits.topk(kk, dim=3).indices, True)
+            rows += int((own ^ masks[side].cpu()).any(-1).sum())
+        out[i] = rows
+    return out
+
+
 def main():
     torch.set_num_threads(synth.effective_cpu_count())
     counts = [int(x) for x in sys.argv[1:4]] + [8, 8, 1][len(sys.argv[1:4]):]
@@ -45,7 +85,7 @@ def main():
         net = MDGAT(cfg)
         net.load_state_dict(sd)
         net = net.double().eval().to('cuda:0')
-        tot_rows = tot_flip = tot_flip32 = 0
+        tot_rows = tot_flip = tot_flip32 = tot_local = literal = 0
         worst = worst_gap = worst_plain = worst32 = 0.0
         all_equal = True
         t0 = time.time()
@@ -59,9 +99,13 @@ def main():
             mm = int((r['out'][0].cpu() != ref['matches0']).sum() + (r['out'][1].cpu() != ref['matches1']).sum())
             f32rows, Z32 = fp32_flips(sd, cfg, data, own64) if n <= 512 else (-1, None)
             e32 = (Z32 - cap['Z']).abs().max().item() if Z32 is not None else float('nan')
+            loc = sum(local_flips(net, sd, data, L).values()) if n <= 512 else -1
+            tot_local += max(loc, 0)
+            literal += plain < 1e-4
             print(f'{name} pair {100 + p}: forced-selection max|dZ| {r["errZ"]:.2e} matches identical {r["matches_equal"]} | '
                   f'rows differing {r["flip_rows"]}/{r["topk_rows"]} max gap {r["max_gap"]:.2e} kept!=k {r["bad_count"]} | '
-                  f'vs plain fp64 oracle: max|dZ| {plain:.2e}, matches differing {mm} | fp32 PyTorch: rows differing {f32rows}, max|dZ| {e32:.2e}')
+                  f'vs plain fp64 oracle: max|dZ| {plain:.2e}, matches differing {mm} | fp32 PyTorch: rows differing {f32rows}, max|dZ| {e32:.2e} | '
+                  f'rows differing from the fp64 selection of the HIP path\'s own layer input (caused inside the layer): {loc}')
             tot_rows += r['topk_rows']; tot_flip += r['flip_rows']; tot_flip32 += max(f32rows, 0)
             worst = max(worst, r['errZ']); worst_gap = max(worst_gap, r['max_gap']); worst_plain = max(worst_plain, plain)
             worst32 = max(worst32, e32 if e32 == e32 else 0.0)
@@ -69,7 +113,9 @@ def main():
             sys.stdout.flush()
         print(f'== {name}: {pairs} pairs, {time.time() - t0:.0f} s: worst forced-selection max|dZ| {worst:.2e} (bar 1e-4), matches identical: {all_equal}, '
               f'top-k rows differing {tot_flip} of {tot_rows} ({tot_flip / max(tot_rows, 1):.2e}), worst gap {worst_gap:.2e}; '
-              f'plain fp64 comparison worst max|dZ| {worst_plain:.2e}; fp32 PyTorch rows differing {tot_flip32}, worst max|dZ| {worst32:.2e}')
+              f'plain fp64 comparison worst max|dZ| {worst_plain:.2e}; fp32 PyTorch rows differing {tot_flip32}, worst max|dZ| {worst32:.2e}; '
+              f'pairs within the LITERAL 1e-4 against the plain fp64 oracle: {literal}/{pairs}; flips caused inside the dynamic layer '
+              f'(q/k projection + q.k products, given the HIP input): {tot_local} of {tot_flip} - the rest arrives with the layer input')
 
 
 if __name__ == '__main__':
