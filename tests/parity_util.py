@@ -32,9 +32,11 @@ GAP_EPS = 2e-5
 # Unconditional bounds against the UNFORCED fp64 result.  One flipped near-tie moves one keypoint's message by
 # ~p_k |v_a - v_b| and Z by a few 1e-4 around that keypoint (measured worst case over 34 pairs: 8.1e-4 at configs[1],
 # 1.6e-3 at N=2048; profiles/parity_r2.txt, parity_r3.txt); an arithmetic or selection bug moves it by 1e-2 and more.
-TAP_EPS = 5e-6            # tapped vs shipped kernels (exact-tie rows only; everything else is bit-identical)
+TAP_EPS = 2e-5            # tapped vs shipped kernels on Z (exact-tie rows only - the ~1e-6 rounding of the correction on a
+                          # message, carried through the remaining layers: measured <= 6.7e-6; everything else is bit-identical)
 PLAIN_MAX = 2e-3          # max|dZ| with flips present
-PLAIN_FRAC = 1e-3         # fraction of Z entries beyond 1e-4 with flips present
+PLAIN_FRAC = 5e-3         # fraction of Z entries beyond 1e-4 with flips present (measured: up to 2.8e-3 of ONE pair's entries
+                          # at N = 2048 with 17 flipped rows; 8-pair batches stay below 1e-3)
 
 
 def hip_forward_with_selection(net, dev_data):
@@ -63,7 +65,7 @@ def attributed_parity(net, cfg, sd, data_cpu, device='cuda:0'):
     # ships.  Matches: identical.  Floats: identical except where a row's k-th place falls on EXACTLY equal fp32 logits
     # (about one row in 10^5): the tapped kernels drop the surplus tied key before their softmax pass, the shipped ones
     # take its share out of the written row afterwards (attention.hip, "exactly k keys") - the same selection, the
-    # correction's rounding apart (<= 2e-6 on the message; TAP_EPS bounds what is left of it in Z).
+    # correction's rounding apart (~1e-6 on the message; TAP_EPS bounds what the later layers make of it in Z).
     plain = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'],
                      dev['descriptors1'], want_Z=True)
     assert torch.equal(m0, plain[0]) and torch.equal(m1, plain[1]), 'tapped and untapped forward differ in the matches'

@@ -396,10 +396,17 @@ def test_forward_falls_back_when_sinkhorn_loses_a_partner(monkeypatch):
     monkeypatch.delenv('MDGAT_SK_FORCE_FALLBACK')
     assert status == {'sinkhorn_fallback': True}
     assert torch.isfinite(with_z[4]).all() and (with_z[4] - ref[4]).abs().max() < 1e-4
+    # the streaming kernel is another fp32 evaluation of the same iteration (Z agrees to ~1e-5): an arg-max that is a
+    # near-tie between two entries of Z may fall the other way - a handful of the 102 400 keypoints at most, each one a tie
+    # within 1e-4 in the normal path's Z
+    r0, r1, rs0, rs1 = O.extract_matches(with_z[4].cpu().double())
+    assert torch.equal(r0, with_z[0].cpu()) and torch.equal(r1, with_z[1].cpu())      # the matches ARE the arg-maxes of the fallback's Z
     for a, b, c in zip(ref[:2], with_z[:2], without_z[:2]):
-        assert torch.equal(a, b) and torch.equal(a, c)
+        assert torch.equal(b, c)                                                      # with or without Z requested: same bits
+        assert int((a != b).sum()) <= 4, int((a != b).sum())
     for a, b, c in zip(ref[2:4], with_z[2:4], without_z[2:4]):
-        assert (a - b).abs().max() < 1e-4 and torch.equal(b, c)
+        assert torch.equal(b, c)
+        assert ((a - b).abs() > 1e-4).sum() <= 4
     again = net.match(*args, return_scores=True)
     assert all(torch.equal(a, b) for a, b in zip(ref, again)) and net.check(DEV) == {'sinkhorn_fallback': False}
 
@@ -428,8 +435,8 @@ def test_two_streams_run_forwards_concurrently():
         status = net.check(DEV)
         for i in range(2):
             assert torch.isfinite(outs[i][4]).all()
-            if status['sinkhorn_fallback']:                  # a launch was redone by the streaming kernel: same matches, Z to round-off
-                assert torch.equal(outs[i][0], serial[i][0]) and torch.equal(outs[i][1], serial[i][1])
+            if status['sinkhorn_fallback']:                  # a launch was redone by the streaming kernel: Z to round-off, near-tie arg-maxes apart
+                assert int((outs[i][0] != serial[i][0]).sum()) <= 4 and int((outs[i][1] != serial[i][1]).sum()) <= 4
                 assert (outs[i][4] - serial[i][4]).abs().max() < 1e-4
             else:
                 for a, b in zip(outs[i], serial[i]):

@@ -81,11 +81,13 @@ def test_attention_full(N, M, cross):
 @pytest.mark.parametrize('N,topk', [(512, 0), (512, 128), (320, 0), (100, 30), (1024, 0), (1024, 128)])
 @pytest.mark.parametrize('case', ['small_q_large_k', 'small_v', 'small_everything', 'large'])
 def test_attention_mismatched_magnitudes(N, topk, case):
-    """The q / k / v planes carry an UNSCALED residual, lo = f16(x - hi) (common.hpp): its rounding is absolute (2^-25),
-    an f16 denormal below |x| = 0.25, so the fp32-class guarantee of the products is relative to operands of order one.
-    Trained checkpoints need not be there: queries ~1e-3 against keys ~30, values ~1e-3, everything ~1e-3, operands of
-    order 100.  Messages must agree with the fp64 oracle to 1e-5 RELATIVE to the magnitude of the values (and the
-    selection of a dynamic layer, where the logits are resolved at all, up to near-ties)."""
+    """The q / k / v planes carry an UNSCALED residual, lo = f16(x - hi) (common.hpp): its rounding is absolute (2^-25, an
+    f16 denormal below |x| = 0.25), so the products are fp32-class (2^-22 relative) for operands between ~0.02 and 6e4 and
+    carry an absolute error of ~3e-8 per term below that.  Trained checkpoints need not sit at order one: queries ~1e-3
+    against keys ~30, values ~1e-3, everything tiny, logits of several hundred.  What is asserted is that statement,
+    measured against the fp64 oracle (tools/magnitude_probe.py): message error <= |v| (3e-6 + 1.5e-7 max|logit|) + 4e-8 -
+    order-one operands 1-2e-6, logits of 400 5e-5 |v| (their own fp32 resolution), values of 1e-3 2.3e-8 absolute
+    (2e-5 relative: the denormal floor) - and a dynamic layer selects the fp64 keys up to near-ties at that resolution."""
     rs = np.random.RandomState(N + topk + len(case))
     qkv = rs.standard_normal((2, 2 * N, 3, 4, 32))
     sq, sk, sv = {'small_q_large_k': (1e-3 * 32 ** 0.5, 30.0, 1.0), 'small_v': (1.3, 1.3, 1e-3),
@@ -97,17 +99,19 @@ def test_attention_mismatched_magnitudes(N, topk, case):
     out = ops.attention(qkv.to(DEV), N, N, False, topk=topk).cpu().double()
     for lo, hi in ((0, N), (N, 2 * N)):
         q, kk, v = (qkv[:, lo:hi, i].permute(0, 3, 2, 1) for i in range(3))
+        logits = torch.einsum('bdhn,bdhm->bhnm', q, kk) / 32 ** 0.5
+        Lmax = float(logits.abs().max())
         if topk:
             ref, _ = O.dynamic_attention(q, kk, v, topk)
-            logits = torch.einsum('bdhn,bdhm->bhnm', q, kk) / 32 ** 0.5
             top = logits.topk(topk + 1, dim=3).values
-            ok = ((top[..., topk - 1] - top[..., topk]) >= 5e-6 * max(1.0, float(logits.abs().max()) / 10)).permute(0, 2, 1)   # [B, n, H]
-            assert ok.double().mean() > 0.99
+            ok = ((top[..., topk - 1] - top[..., topk]) >= 5e-7 * max(Lmax, 0.2)).permute(0, 2, 1)   # [B, n, H]: not a near-tie
+            assert ok.double().mean() > 0.97
         else:
             ref, _ = O.attention(q, kk, v)
             ok = torch.ones(2, N, 4, dtype=torch.bool)
         err = (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().reshape(2, N, 4, 32).amax(3)
-        assert err[ok].max() < 1e-5 * sv, (case, float(err[ok].max()), sv)
+        tol = sv * (3e-6 + 1.5e-7 * Lmax) + 4e-8
+        assert err[ok].max() < tol, (case, float(err[ok].max()), tol)
 
 
 @pytest.mark.parametrize('N,M,k', [(64, 64, 16), (64, 64, 1), (64, 64, 63), (40, 56, 8), (512, 512, 128), (512, 512, 64),
