@@ -104,8 +104,11 @@ def test_attention_mismatched_magnitudes(N, topk, case):
         if topk:
             ref, _ = O.dynamic_attention(q, kk, v, topk)
             top = logits.topk(topk + 1, dim=3).values
-            ok = ((top[..., topk - 1] - top[..., topk]) >= 5e-7 * max(Lmax, 0.2)).permute(0, 2, 1)   # [B, n, H]: not a near-tie
-            assert ok.double().mean() > 0.97
+            # not a near-tie at the resolution of the logits: 2^-22 relative, plus the absolute floor of the denormal
+            # residuals of tiny queries (2^-25 per term) times the size of the keys
+            res = 5e-7 * max(Lmax, 0.2) + 2e-7 * float(kk.abs().max())
+            ok = ((top[..., topk - 1] - top[..., topk]) >= res).permute(0, 2, 1)                       # [B, n, H]
+            assert ok.double().mean() > 0.9
         else:
             ref, _ = O.attention(q, kk, v)
             ok = torch.ones(2, N, 4, dtype=torch.bool)
