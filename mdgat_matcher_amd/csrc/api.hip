@@ -321,7 +321,9 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     // ---- final projection (mdgat.py:397, computed by the last launch above) and score matrix (430-431) ----
     if (taps && taps->mdesc)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
-    if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s))) return rc;
+    // (the score kernel also clears the exchange slots of the Sinkhorn kernel that follows: no memset launch in between)
+    const size_t sk_clear = ws.sk_bytes ? sinkhorn_slots_clear_bytes(N, M) : 0;
+    if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s, sk_clear ? ws.sk : nullptr, sk_clear))) return rc;
     mark(MDGAT_PROF_SCORES);
     if (taps && taps->scores)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;
@@ -332,7 +334,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
     const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust};
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, status_dev,
-                              Z ? Z : ws.Z))) return rc;
+                              Z ? Z : ws.Z, sk_clear != 0))) return rc;
     mark(MDGAT_PROF_SINKHORN);
     if (h->prof_on && prof_n > 1) {
         if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;

@@ -87,7 +87,9 @@ struct GemmArgs {
 };
 int launch_gemm(const GemmArgs& a, hipStream_t s);
 // score matrix [B][N][M] = mdesc0 . mdesc1^T * scale from mdesc [B][N + M][128] (scores.hip)
-int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s);
+// zero / zero_bytes (optional, 16-byte granular): memory the kernel clears on the side - the forward hands it the exchange
+// slots of the Sinkhorn kernel that runs next (sinkhorn_slots_clear_bytes) instead of a memset launch
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
 
 // fused encoders (encoder.hip).  es = split weights [kenc.3 64x2x32 | kenc.6 128x2x64 | denc.0 64x2x48 | denc.3 128x2x64 |
 // last convs 128x2x256]; inputs either as separate arrays or as raw 37-float frame records
@@ -155,9 +157,11 @@ constexpr int MDGAT_STATUS_WORDS = 4;
 constexpr float MDGAT_F16_GUARD = 6.0e4f;     // f16 max is 65504; the split's hi plane must stay finite
 // status (optional, device pointer to MDGAT_STATUS_WORDS host-mapped words).  Zfb: where the streaming fallback puts Z when
 // the cluster kernel lost a partner and the caller wanted no Z (NULL: the cluster launch is cooperative instead).
+// slots_cleared: the first sinkhorn_slots_clear_bytes(N, M) bytes of ws are already zero on the stream (no memset launch).
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
                     int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status = nullptr,
-                    float* Zfb = nullptr);
+                    float* Zfb = nullptr, bool slots_cleared = false);
+size_t sinkhorn_slots_clear_bytes(int N, int M);   // 0: the shape does not use the cluster kernel
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,
@@ -170,7 +174,7 @@ int launch_gt_match(int B, int N, int M, const float* kpts0, const float* kpts1,
 
 // out[b][i][j] = scale <A[b][i], Bm[b][j]> - col_bias[b][j] over 128 channels, split-f16 products (scores.hip)
 int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
-                const float* col_bias, hipStream_t s);
+                const float* col_bias, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
 int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
                void* ws, size_t ws_bytes, hipStream_t s);
 size_t mdgat_knn_ws_bytes_impl(int B, int C, int N, int M);

@@ -175,9 +175,6 @@ __global__ __launch_bounds__(64 * KNN_WAVES) void knn_select_kernel(KnnArgs a) {
 
 }  // namespace
 
-int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
-                const float* col_bias, hipStream_t s);
-
 size_t mdgat_knn_ws_bytes_impl(int B, int C, int N, int M) {
     if (C != 128 || B <= 0 || N <= 0 || M <= 0) return 0;       // other channel counts: distances on the fly, no workspace
     return ((size_t)B * N * M + (size_t)B * M) * sizeof(float);

@@ -18,6 +18,8 @@ struct ScoreArgs {
     int N, M;
     float scale;
     const float* col_bias;    // [B][M] or NULL (the kNN helper: |s_j|^2, pointops.hip)
+    f32x4* zero;              // optional: zero_n 16-byte units cleared on the side (the exchange slots of the Sinkhorn kernel that
+    size_t zero_n;            // runs next: spares the forward a memset launch)
 };
 
 // BIAS: subtract col_bias[b][j] (the kNN helper; kept out of the score-matrix instance, whose epilogue is store-bound)
@@ -33,6 +35,11 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const int b = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
     const float* A = a.A + (size_t)b * a.sA;
     const float* Bm = a.Bm + (size_t)b * a.sB;
+    if (a.zero) {
+        const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        const size_t nwg = (size_t)gridDim.x * gridDim.y * gridDim.z;
+        for (size_t i = wg * 512 + tid; i < a.zero_n; i += nwg * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // ---- both operand tiles: fp32 rows -> (hi | lo) halves in LDS; 8 x 16-byte loads per thread and operand ----
     auto stage = [&](const float* src, int r0, int nrows, _Float16* dst) {
@@ -97,9 +104,9 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
 }  // namespace
 
 int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
-                const float* col_bias, hipStream_t s) {
+                const float* col_bias, hipStream_t s, void* zero, size_t zero_bytes) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
-    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias};
+    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias, static_cast<f32x4*>(zero), zero ? zero_bytes / 16 : 0};
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
     static std::atomic<unsigned long long> optin[2];
     const void* kern = col_bias ? reinterpret_cast<const void*>(scores_kernel<true>) : reinterpret_cast<const void*>(scores_kernel<false>);
@@ -109,7 +116,7 @@ int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float
     return mdgat_check_hip(hipGetLastError(), "scores launch");
 }
 
-int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s) {
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero, size_t zero_bytes) {
     const size_t P = (size_t)(N + M) * 128;
-    return launch_dots(B, N, M, mdesc, P, mdesc + (size_t)N * 128, P, scores, scale, nullptr, s);
+    return launch_dots(B, N, M, mdesc, P, mdesc + (size_t)N * 128, P, scores, scale, nullptr, s, zero, zero_bytes);
 }

@@ -803,6 +803,11 @@ struct ExArgs {
     float* s0; float* s1;
     const unsigned* sk_error;   // optional: error word of the cluster kernel that produced the arg-maxes (a lost partner) ...
     const float* Zfb;           // ... in which case the streaming fallback has written Z here: scan it instead
+    // optional, zeroed before the launch: [0] frame-0 keypoints matched so far in the batch, [1] workgroups done.  The last
+    // workgroup to finish applies the batch-wide rule of mdgat.py:465-467 (nothing matched anywhere: all scores zero)
+    // - no separate fix-up launch
+    unsigned* alldust_counters;
+    int B;
     // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
     // per row slab [B][GR][M])
     const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int GR, GC;
@@ -882,12 +887,14 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
 
     if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
         const bool mutual = a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL;
+        int nvalid = 0;
         for (int i = tid; i < N; i += 1024) {
             const int j = idx0[i];
             const bool valid = j < M;
             const bool keep = valid && (!mutual || idx1[j] == i);
             m0[i] = valid ? j : -1;
             s0[i] = keep ? expf(val0[i]) : 0.f;
+            nvalid += valid;
         }
         for (int j = tid; j < M; j += 1024) {
             const int i = idx1[j];
@@ -895,6 +902,24 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             const bool keep = valid && (!mutual || idx0[i] == j);
             m1[j] = valid ? i : -1;
             s1[j] = keep ? expf(val1[j]) : 0.f;
+        }
+        if (a.alldust_counters) {
+            // mdgat.py:465-467 over the whole batch: count, and let the last workgroup to arrive decide
+            const int any_valid = __syncthreads_or(nvalid > 0);         // (also: this workgroup's stores are issued)
+            __shared__ int last;
+            if (tid == 0) {
+                __threadfence();                                         // scores of this pair before the ticket
+                if (any_valid) atomicAdd(a.alldust_counters, 1u);
+                __threadfence();
+                const unsigned ticket = atomicAdd(a.alldust_counters + 1, 1u);
+                last = ticket == (unsigned)a.B - 1 && __hip_atomic_load(a.alldust_counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+                __threadfence();
+            }
+            __syncthreads();
+            if (last) {                                                  // (s0 is zero already: no row was valid)
+                float* s1all = a.s1;
+                for (size_t i = tid; i < (size_t)a.B * M; i += 1024) s1all[i] = 0.f;
+            }
         }
     } else if (a.mode == MDGAT_EXTRACT_THRESHOLD) {
         for (int i = tid; i < N; i += 1024) {
@@ -991,8 +1016,10 @@ static int launch_streaming(const SkArgs& a, int B, hipStream_t s) {
     return MDGAT_ERR_UNSUPPORTED;
 }
 
+size_t sinkhorn_slots_clear_bytes(int N, int M) { return (N > 2048 || M > 2048) ? 0 : slots_bytes(N, M); }
+
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
-                          float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* status, float* Zfb, hipStream_t s) {
+                          float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* status, float* Zfb, bool slots_cleared, hipStream_t s) {
     constexpr int RPW = 16;
     int GR, GC;
     sk_tiling(N, M, GR, GC);
@@ -1011,7 +1038,8 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     const int grid = xcd_map ? ng8 * P : ngroups * P;
     if (ngroups < 1) { mdgat_set_error("sinkhorn: %d workgroups per pair do not fit the device", P); return MDGAT_ERR_UNSUPPORTED; }
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
-    if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
+    if (!slots_cleared)      // (the forward has the score kernel clear them)
+        if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
     // test hook (tests/test_gpu_ops.py): pretend a partner was lost - the launch's error word starts out set, so the gated
     // streaming kernel and the extraction from its Z run for real
     if (const char* f = getenv("MDGAT_SK_FORCE_FALLBACK"); f && *f == '1')
@@ -1052,7 +1080,9 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
         if (int rc = launch_streaming(f, B, s)) return rc;
     }
     if (ex) {
+        // (header words 2, 3 of the workspace: the all-dustbin counters of the extraction, cleared with the slots)
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb,
+                 ex->defer_alldust ? nullptr : a.error_word + 2, B,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
     }
@@ -1064,7 +1094,8 @@ size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M) { return sinkhorn_clust
 // ex != NULL: also extract the matches.  With the cluster kernel the arg-maxes are fused into its epilogue and Z may
 // be NULL; otherwise Z must be given and is scanned by the extraction kernel.
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
-                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status, float* Zfb) {
+                    int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status, float* Zfb,
+                    bool slots_cleared) {
     if (B <= 0) return MDGAT_OK;
     if (!Z && !ex) { mdgat_set_error("sinkhorn: nothing to compute (no Z, no extraction)"); return MDGAT_ERR_BAD_ARG; }
     if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("sinkhorn: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
@@ -1073,13 +1104,13 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, s);
+        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
     }
     if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr};
     const int rc = launch_streaming(a, B, s);
     if (rc || !ex) return rc;
-    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
 }
 
@@ -1096,13 +1127,13 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, boo
     const size_t lds = (size_t)(2 * (N + M) + 4) * sizeof(float);
     hipLaunchKernelGGL(extract_kernel, dim3(B), dim3(1024), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "extract launch")) return rc;
-    if (defer_alldust) return MDGAT_OK;
+    if (defer_alldust || a.alldust_counters) return MDGAT_OK;      // (counters: the kernel applied the rule itself)
     return launch_alldust_fixup(B, N, M, a.mode, a.m0, a.s1, s);
 }
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, a, s);
 }
