@@ -260,3 +260,138 @@ def test_load_packed_state_survives_casts():
     assert net._states.get(0) is st2 and not st2.closed
     net.float()
     assert st2.closed and not net._states
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# round 3: host logic around the library, with the library replaced by a recorder at the _lib boundary
+class _FakeLib:
+    """Records what reaches the C ABI; `status` = (sinkhorn_fallback, range_violation) the next mdgat_async_status reports."""
+
+    def __init__(self):
+        self.calls, self.loaded, self.status = [], [], (0, 0)
+
+    def mdgat_create(self, cfg, idx, handle):
+        self.calls.append(('create', idx))
+        handle._obj.value = 4000 + idx
+        return 0
+
+    def mdgat_blob_floats(self, L):
+        return pack.blob_layout(L)['total']
+
+    def mdgat_load_weights(self, handle, ptr, n, on_device):
+        addr = ptr.value if hasattr(ptr, 'value') else C.cast(ptr, C.c_void_p).value
+        self.loaded.append(np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_float)), shape=(n,)).copy())
+        self.calls.append(('load', int(on_device)))
+        return 0
+
+    def mdgat_workspace_bytes(self, handle, B, N, M):
+        return 256 * B
+
+    def mdgat_forward(self, *a):
+        self.calls.append(('forward', a[1], a[-2], a[-1]))          # B, workspace bytes, stream
+        return 0
+
+    def mdgat_async_status(self, handle, clear, fb, rg):
+        fb._obj.value, rg._obj.value = self.status
+        if clear:
+            self.status = (0, 0)
+        return _lib.ERR_UNSUPPORTED if rg._obj.value else 0
+
+    def mdgat_destroy(self, handle):
+        self.calls.append(('destroy',))
+
+    def mdgat_last_error(self):
+        return b'activations outside the f16 operand range'
+
+
+def _stubbed(fake, stream_holder):
+    """Context in which CPU tensors pose as device memory and the library is `fake`."""
+    import contextlib
+    from unittest import mock
+    cm = contextlib.ExitStack()
+    cm.enter_context(mock.patch.object(_lib, 'load', lambda: fake))
+    cm.enter_context(mock.patch.object(torch.Tensor, 'is_cuda', new=property(lambda self: True)))
+    cm.enter_context(mock.patch.object(torch.cuda, 'current_device', lambda: 0))
+    cm.enter_context(mock.patch.object(torch.cuda, 'device', lambda d: contextlib.nullcontext()))
+    cm.enter_context(mock.patch.object(torch.cuda, 'synchronize', lambda d=None: None))
+    cm.enter_context(mock.patch.object(torch.cuda, 'current_stream', lambda d=None: mock.Mock(cuda_stream=stream_holder[0])))
+    return cm
+
+
+def test_workspace_per_stream_and_status_check():
+    """Forwards issued on different streams get different workspaces (they may overlap on the device); check() reports
+    the asynchronous status: information about a Sinkhorn fallback, RuntimeError for the f16 range guard; forward()
+    applies the integer-zero quirk of mdgat.py:465-467 and checks the status itself."""
+    fake, stream = _FakeLib(), [11]
+    net = MDGAT(synth.default_config(L=1, k=[])).eval()
+    d = synth.make_batch(2, 8, 8)
+    args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'])
+    with _stubbed(fake, stream):
+        net._run(*args)
+        stream[0] = 22
+        net._run(*args)
+        stream[0] = 11
+        net._run(*args)
+        st = net._states[0]
+        assert set(st.workspaces) == {11, 22} and st.workspaces[11].data_ptr() != st.workspaces[22].data_ptr()
+        assert [c[3] for c in fake.calls if c[0] == 'forward'] == [11, 22, 11]
+        assert net.check('cuda:0') == {'sinkhorn_fallback': False}
+        fake.status = (1, 0)
+        assert net.check('cuda:0') == {'sinkhorn_fallback': True}
+        fake.status = (0, 1)
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            net.check('cuda:0')
+        assert net.check('cuda:0') == {'sinkhorn_fallback': False}          # reported once
+        # forward(): matches0 is uninitialised memory under the recorder; force "nothing matched"
+        from unittest import mock
+        with mock.patch.object(torch, 'empty', lambda *a, **k: torch.full(a[0] if a else k['size'], -1 if k.get('dtype') == torch.int64 else 0,
+                                                                             dtype=k.get('dtype', torch.float32))):
+            out = net(d)
+        assert out['matching_scores0'].dtype == torch.int64 and out['matching_scores1'].dtype == torch.int64      # mdgat.py:465-467
+        fake.status = (0, 1)
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            net(d)                                                          # the failing call raises, not the next one
+        net._invalidate()
+
+
+def test_load_packed_keeps_a_host_copy_for_other_devices():
+    """a blob installed by load_packed() must be what EVERY device / replica of the process runs - never the
+    module's own (random-init) parameters."""
+    fake, stream = _FakeLib(), [0]
+    net = MDGAT(synth.default_config(L=1, k=[])).eval()
+    other = MDGAT(synth.default_config(L=1, k=[]))
+    other.load_state_dict(synth.make_state_dict(L=1, seed=9, dtype=torch.float32))
+    blob = torch.from_numpy(other.packed_weights())
+    with _stubbed(fake, stream):
+        from unittest import mock
+        with mock.patch.object(torch.Tensor, 'device', new=property(lambda self: torch.device('cuda', 0))):
+            net.load_packed(blob)
+        assert fake.calls[-1] == ('load', 1) and net._blob_holder[1] is True
+        np.testing.assert_array_equal(net._blob_holder[0], blob.numpy())
+        st1 = net._state_for(torch.device('cuda', 1))                       # another device of the process
+        assert fake.calls[-1] == ('load', 0) and st1.device == 1
+        np.testing.assert_array_equal(fake.loaded[-1], blob.numpy())         # the installed blob, not net's own parameters
+        net._invalidate()
+
+
+def test_import_path_shim_resolves_models_mdgat():
+    """`from models.mdgat import MDGAT` (test.py:12) with <repo>/integration ahead on sys.path."""
+    import importlib
+    import sys
+    shim = os.path.join(ROOT, 'integration')
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'models' or k.startswith('models.')}
+    sys.path.insert(0, shim)
+    try:
+        mod = importlib.import_module('models.mdgat')
+        assert mod.MDGAT is MDGAT
+        for name in ('MLP', 'attention', 'dynamic_attention', 'log_optimal_transport', 'knn', 'get_graph_feature', 'match'):
+            assert callable(getattr(mod, name)), name
+        seq = mod.MLP([4, 32, 64, 128])
+        assert [type(m).__name__ for m in seq] == ['Conv1d', 'BatchNorm1d', 'ReLU', 'Conv1d', 'BatchNorm1d', 'ReLU', 'Conv1d']
+        with pytest.raises(RuntimeError, match='no CPU fallback'):
+            mod.log_optimal_transport(torch.zeros(1, 4, 4), 1.0, 3)         # CPU tensors: the product has no CPU path
+    finally:
+        sys.path.remove(shim)
+        for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)

@@ -154,3 +154,49 @@ def test_partition_properties():
             assert sum(c for _, c in parts) == n
             assert all(parts[i][0] + parts[i][1] == parts[i + 1][0] for i in range(world - 1))
             assert max(c for _, c in parts) - min(c for _, c in parts) <= 1
+
+
+def _one_rank_worker(port, q):
+    """A process started by a launcher with ONE rank (torch.distributed.run --nproc-per-node 1): the process group exists and
+    the helpers run their collectives through it - the CPU twin of tests/test_gpu_rccl.py (there: nccl on device tensors)."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    import torch.distributed as dist
+    from mdgat_matcher_amd import MDGAT, shard, synth
+    r, w, _ = shard.init_distributed(1, backend='gloo')
+    assert dist.is_initialized() and w == 1
+    net = MDGAT(synth.default_config(L=1, k=[]))
+    net.load_state_dict(synth.make_state_dict(L=1, seed=5))
+    blob = shard.broadcast_weights(net, 'cpu', r, w)
+    ok = blob is not None and np.array_equal(blob.numpy(), net.packed_weights())
+    shard.barrier(w)
+    t = shard.max_over_ranks(2.5, 'cpu', w)
+    g = shard.gather_matches(torch.arange(6)[:, None], w)
+    shard.finalize(w)
+    q.put((ok, t, g[:, 0].tolist(), dist.is_initialized()))
+
+
+def test_one_rank_launched_process_runs_the_collectives():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_one_rank_worker, args=(29811 + (os.getpid() % 100), q))
+    p.start()
+    ok, t, g, still = q.get(timeout=180)
+    p.join(60)
+    assert p.exitcode == 0 and ok and t == 2.5 and g == list(range(6)) and not still
+
+
+def test_share_device_hook_is_announced_and_needs_a_single_gpu(capsys, monkeypatch):
+    sys.path.insert(0, ROOT)
+    from mdgat_matcher_amd import shard
+    for k in ('RANK', 'MASTER_ADDR', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('MDGAT_SHARE_DEVICE', '1')
+    monkeypatch.setenv('LOCAL_RANK', '3')
+    assert shard.init_distributed(1) == (0, 1, 0)                 # every rank on device 0 ...
+    assert 'share_device test hook active' in capsys.readouterr().err     # ... and it says so
+    monkeypatch.setattr('torch.cuda.is_available', lambda: True)
+    monkeypatch.setattr('torch.cuda.device_count', lambda: 8)
+    import pytest
+    with pytest.raises(RuntimeError, match='single-GPU test hook'):
+        shard.init_distributed(1)
