@@ -309,6 +309,8 @@ class MDGAT(nn.Module):
             self.check(m0.device, synchronize=False)        # (the .any() above synchronised: report this call's status now)
             if nothing_matched:
                 s0, s1 = torch.zeros_like(m0), torch.zeros_like(m1)
+        else:
+            self.check(m0.device)                           # the dict API reports on the failing call in every branch
         return {
             'matches0': m0,
             'matches1': m1,
