@@ -295,8 +295,8 @@ constexpr int SKS_LDS_FLOATS = 520 + 8 * 512 + 8 + 8 + 8 * 512;
 constexpr int ROW_STRIDE = 136;
 
 // Granule traffic between the workgroups of a pair.  Agent scope (sc1) works wherever the partners run.  When all of
-// them report the same XCC_ID (checked per pair with an agent-scope exchange first), they share one L2, and
-// non-temporal 8-byte accesses (not kept in the CU's L1, served by that L2) carry the hand-off at lower latency.
+// them report the same XCC_ID (checked per pair with an agent-scope exchange first), they share one L2: plain 8-byte
+// stores and non-temporal loads (not kept in the CU's L1, served by that L2) carry the hand-off at lower latency.
 __device__ __forceinline__ unsigned long long xload(gu64* p, bool same_xcd) {
     if (same_xcd) {
         unsigned long long v;
@@ -306,7 +306,14 @@ __device__ __forceinline__ unsigned long long xload(gu64* p, bool same_xcd) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ void xstore(gu64* p, unsigned long long v, bool same_xcd) {
+    // A PLAIN store: the CU's L1 writes through to the XCD's L2, where the partners' (L1-bypassing) loads find it, and it stays
+    // there.  With `nt` - as until round 3 - the L2 streamed every granule on to HBM: 115 MB written per launch at B = 64
+    // (PMC WRITE_SIZE) against 11 MB now, and the hand-off waited for it: 3.2 -> 2.85 us per iteration, 391 -> 355 us per launch.
+#ifdef SK_STORE_NT
     if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
+#else
+    if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
+#endif
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
