@@ -326,9 +326,25 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
     unsigned spins = 0;
     while (pending) {
         unsigned long long x[NMAX];
+#ifndef SK_POLL_SERIAL
+        if (NMAX <= 4 && same_xcd) {
+            // all outstanding partners in ONE round trip: the loads are issued back to back and awaited together (a wait per
+            // load cost 346 against 337 us per launch at B = 64 once the stores had become plain; with up to 16 partners
+            // the sixteen granules in flight cost 86 more spilled registers: those kernels keep the serial poll)
 #pragma unroll
-        for (int p = 0; p < NMAX; ++p)
-            if (pending & (1u << p)) x[p] = xload(base + (size_t)p * stride, same_xcd);
+            for (int p = 0; p < NMAX; ++p)
+                if (pending & (1u << p)) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(x[p]) : "v"(base + (size_t)p * stride) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < NMAX; ++p)
+                if (pending & (1u << p)) asm volatile("" : "+v"(x[p]));       // (uses stay behind the wait)
+        } else
+#endif
+        {
+#pragma unroll
+            for (int p = 0; p < NMAX; ++p)
+                if (pending & (1u << p)) x[p] = xload(base + (size_t)p * stride, same_xcd);
+        }
 #pragma unroll
         for (int p = 0; p < NMAX; ++p)
             if ((pending & (1u << p)) && (unsigned)(x[p] >> 32) == tag) {
