@@ -319,13 +319,17 @@ __device__ __forceinline__ void xstore(gu64* p, unsigned long long v, bool same_
 
 // Poll the granules `base[p * stride]`, p in [0, n) except `self`, until they carry `tag`; all outstanding partners are
 // polled concurrently.  vals[p] receives the payloads.  Bounded: a timeout sets the error word.
+// `extra` (optional): one more granule polled in the same round trips (the dustbin column's partial of a partner, by the
+// lanes of the last wave that own it): extra_val receives its payload.
 template <int NMAX>
 __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, int self, unsigned tag, float (&vals)[NMAX],
-                                              bool& failed, unsigned* error_word, bool same_xcd = false) {
+                                              bool& failed, unsigned* error_word, bool same_xcd = false,
+                                              gu64* extra = nullptr, float* extra_val = nullptr) {
     unsigned pending = ((1u << n) - 1u) & ~(1u << self);
+    bool extra_pending = extra != nullptr;
     unsigned spins = 0;
-    while (pending) {
-        unsigned long long x[NMAX];
+    while (pending || extra_pending) {
+        unsigned long long x[NMAX], xe = 0;
 #ifndef SK_POLL_SERIAL
         if (NMAX <= 4 && same_xcd) {
             // all outstanding partners in ONE round trip: the loads are issued back to back and awaited together (a wait per
@@ -334,16 +338,19 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
                 if (pending & (1u << p)) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(x[p]) : "v"(base + (size_t)p * stride) : "memory");
+            if (extra_pending) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(xe) : "v"(extra) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
                 if (pending & (1u << p)) asm volatile("" : "+v"(x[p]));       // (uses stay behind the wait)
+            asm volatile("" : "+v"(xe));
         } else
 #endif
         {
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
                 if (pending & (1u << p)) x[p] = xload(base + (size_t)p * stride, same_xcd);
+            if (extra_pending) xe = xload(extra, same_xcd);
         }
 #pragma unroll
         for (int p = 0; p < NMAX; ++p)
@@ -351,7 +358,11 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
                 vals[p] = __builtin_bit_cast(float, (unsigned)x[p]);
                 pending &= ~(1u << p);
             }
-        if (pending) {
+        if (extra_pending && (unsigned)(xe >> 32) == tag) {
+            *extra_val = __builtin_bit_cast(float, (unsigned)xe);
+            extra_pending = false;
+        }
+        if (pending || extra_pending) {
             if (failed || ++spins > (1u << 22)) { failed = true; atomicOr(error_word, 1u); break; }
             __builtin_amdgcn_s_sleep(1);
         }
@@ -591,7 +602,11 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     for (int ww = 1; ww < 8; ++ww) dloc += pdust[ww];
                     if (GR > 1 && lane == 0) xstore(base + (size_t)jr * SLOT_STRIDE + 512, tagbits | __builtin_bit_cast(unsigned, dloc), same_xcd);
                 }
-                // (a) every thread: its own column of the slab, all row-slab partners polled concurrently
+                // (a) every thread: its own column of the slab, all row-slab partners polled concurrently; lane p of the last
+                //     wave polls row slab p's dustbin partial in the same round trips (a second poll after this one kept
+                //     the whole workgroup waiting at the barrier for one more L2 round trip per iteration)
+                bool have_dust = false;
+                float dust_in = 0.f;
                 if (tcol_valid) {
                     float loc = colp[tid];
 #pragma unroll
@@ -602,7 +617,14 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     if (GR > 1) {
                         xstore(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
                         SK_TP(6);
+#ifndef SK_DUST_SEPARATE
+                        const bool my_dust = wave == 7 && lane < GR && lane != jr;
+                        poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd,
+                                            my_dust ? base + (size_t)lane * SLOT_STRIDE + 512 : nullptr, &dust_in);
+                        have_dust = my_dust && !failed;
+#else
                         poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd);
+#endif
                         SK_TP(7);
                     }
                     float total = 0.f;
@@ -614,9 +636,9 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 }
                 // (b) wave 7: the dustbin column (slot 512), lane p polls row slab p
                 if (wave == 7) {
-                    float mine = dloc;
+                    float mine = have_dust ? dust_in : dloc;
                     if (GR > 1) {
-                        if (lane < GR && lane != jr) {
+                        if (lane < GR && lane != jr && !have_dust) {
                             unsigned spins = 0;
                             while (true) {
                                 const unsigned long long x = xload(base + (size_t)lane * SLOT_STRIDE + 512, same_xcd);
