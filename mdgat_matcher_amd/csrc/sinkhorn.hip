@@ -246,6 +246,11 @@ __device__ __forceinline__ float wave_sum16(float (&acc)[16], int lane) {
 }
 
 typedef __attribute__((address_space(1))) unsigned long long gu64;
+// cache policy of the polling loads: agent scope (served by the L2, never by a CU's L1).  "nt" measures the same and had
+// been used until round 3; "sc0" alone hits stale L1 lines (partners time out).
+#ifndef SK_LD
+#define SK_LD "sc1"
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Scaling-form cluster kernel (N, M <= 512), the production path.
@@ -296,11 +301,11 @@ constexpr int ROW_STRIDE = 136;
 
 // Granule traffic between the workgroups of a pair.  Agent scope (sc1) works wherever the partners run.  When all of
 // them report the same XCC_ID (checked per pair with an agent-scope exchange first), they share one L2: plain 8-byte
-// stores and non-temporal loads (not kept in the CU's L1, served by that L2) carry the hand-off at lower latency.
+// stores and agent-scope loads issued by hand (several in flight, one wait) carry the hand-off at lower latency.
 __device__ __forceinline__ unsigned long long xload(gu64* p, bool same_xcd) {
     if (same_xcd) {
         unsigned long long v;
-        asm volatile("global_load_dwordx2 %0, %1, off nt\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+        asm volatile("global_load_dwordx2 %0, %1, off " SK_LD "\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
         return v;
     }
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -337,8 +342,8 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
             // the sixteen granules in flight cost 86 more spilled registers: those kernels keep the serial poll)
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
-                if (pending & (1u << p)) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(x[p]) : "v"(base + (size_t)p * stride) : "memory");
-            if (extra_pending) asm volatile("global_load_dwordx2 %0, %1, off nt" : "=v"(xe) : "v"(extra) : "memory");
+                if (pending & (1u << p)) asm volatile("global_load_dwordx2 %0, %1, off " SK_LD : "=v"(x[p]) : "v"(base + (size_t)p * stride) : "memory");
+            if (extra_pending) asm volatile("global_load_dwordx2 %0, %1, off " SK_LD : "=v"(xe) : "v"(extra) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
