@@ -790,12 +790,25 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
                     for (int c = 1; c < 8; ++c)
                         if (z[c] > bv) { bv = z[c]; bi = gcol0 + c; }
+#ifdef SK_ARGMAX_SHUFFLE
 #pragma unroll
                     for (int o = 32; o > 0; o >>= 1) {
                         const float ov = __shfl_xor(bv, o, 64);
                         const int oi = __shfl_xor(bi, o, 64);
                         if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
                     }
+#else
+                    {
+                        // wave maximum on the vector ALU (DPP), then the LOWEST lane that holds it (lanes are in column order
+                        // and bi is the lane's own first maximum: torch.max's first maximal index) - one ballot and two
+                        // readlanes instead of twelve dependent ds_bpermute per row
+                        const float mx = wave_max_dpp(bv);
+                        const unsigned long long hit = __ballot(bv == mx);
+                        const int first = hit ? __builtin_ctzll(hit) : 0;        // (no lane: NaN-poisoned row)
+                        bi = __builtin_amdgcn_readlane(bi, first);
+                        bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), first));
+                    }
+#endif
                     if (!inner && last_c && zM > bv) { bv = zM; bi = M; }
                     if (lane == 0) {
                         a.rbest_idx[((size_t)pair * GC + jc) * N + i] = bi;
