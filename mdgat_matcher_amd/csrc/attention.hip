@@ -156,13 +156,33 @@ struct WaveComm {
     }
 };
 // QuadComm: the row lives in four lanes of one wave (l & 15 = query; 16x16 MFMA fragments).
+// The partners of a lane are lane ^ 16 and lane ^ 32: v_permlane16_swap / v_permlane32_swap on two copies of the value bring
+// them in on the vector ALU (x = y = v; after the swap x holds the even 16-lane rows' values and y the odd rows' - for every lane
+// the pair (x, y) is (own value, partner's) in some order), instead of a ds_bpermute round trip through the LDS per step.
+// (inline asm: the clang builtins of this ROCm return the first result twice; the compiler inserts no wait states around an asm)
+#ifdef QUAD_SHUFFLE
+template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v, Op op) {
+    v = op(v, __shfl_xor(v, 16, 64));
+    return op(v, __shfl_xor(v, 32, 64));
+}
+#else
+template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v, Op op) {
+    static_assert(sizeof(T) == 4, "32-bit values");
+    unsigned x = __builtin_bit_cast(unsigned, v), y = x;
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    v = op(__builtin_bit_cast(T, x), __builtin_bit_cast(T, y));
+    x = __builtin_bit_cast(unsigned, v); y = x;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
+    return op(__builtin_bit_cast(T, x), __builtin_bit_cast(T, y));
+}
+#endif
 struct QuadComm {
     static constexpr bool LOCAL_VOTE = true;
     static constexpr bool PACKED_COUNT = true;
-    __device__ __forceinline__ float rsum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-    __device__ __forceinline__ int rsum(int v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
-    __device__ __forceinline__ float rmin(float v) { v = fminf(v, __shfl_xor(v, 16, 64)); return fminf(v, __shfl_xor(v, 32, 64)); }
-    __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+    __device__ __forceinline__ float rsum(float v) { return quad_reduce(v, [](float a, float b) { return a + b; }); }
+    __device__ __forceinline__ int rsum(int v) { return quad_reduce(v, [](int a, int b) { return a + b; }); }
+    __device__ __forceinline__ float rmin(float v) { return quad_reduce(v, [](float a, float b) { return fminf(a, b); }); }
+    __device__ __forceinline__ float rmax(float v) { return quad_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
     __device__ __forceinline__ bool any(bool p) { return __any(p); }
     __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) { mn = rmin(mn); sum = rsum(sum); sq = rsum(sq); }
     __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
