@@ -759,21 +759,29 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     QuadComm comm;
     const int tiles_all = (nq + 15) >> 4;
     const int tiles_wg = (tiles_all + gridDim.x - 1) / gridDim.x;      // this workgroup: tiles [blockIdx.x tiles_wg, ...)
-    for (;;) {
+    // the next 16-query tile of this wave (wave-uniform; -1: none left) and its query fragment: dims 8 g .. 8 g + 7 of query
+    // l15 (B operand), planes hi / lo
+    auto claim_tile = [&]() -> int {
         int t = 0;
         if (lane == 0) t = atomicAdd(next_tile, 1);
         t = __builtin_amdgcn_readfirstlane(t);
-        if (t >= tiles_wg) break;
-        const int qw = (blockIdx.x * tiles_wg + t) * 16;
-        if (qw >= nq) break;                // wave-uniform; no barrier inside the loop
-        // query fragment: dims 8 g .. 8 g + 7 of query l15 (B operand), planes hi / lo
-        f16x8 qh, ql;
-        {
-            const int qrow = min(qw + l15, nq - 1);
-            const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * g;
-            qh = *reinterpret_cast<const f16x8*>(p);
-            ql = *reinterpret_cast<const f16x8*>(p + 32);
-        }
+        if (t >= tiles_wg) return -1;
+        const int q0 = (blockIdx.x * tiles_wg + t) * 16;
+        return q0 < nq ? q0 : -1;
+    };
+    auto load_q = [&](int q0, f16x8& h, f16x8& l) {
+        const int qrow = min(q0 + l15, nq - 1);
+        const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * g;
+        h = *reinterpret_cast<const f16x8*>(p);
+        l = *reinterpret_cast<const f16x8*>(p + 32);
+    };
+    f16x8 qh_next, ql_next;
+    int qw_next = claim_tile();
+    if (qw_next >= 0) load_q(qw_next, qh_next, ql_next);
+    for (;;) {
+        const int qw = qw_next;
+        if (qw < 0) break;                  // wave-uniform; no barrier inside the loop
+        f16x8 qh = qh_next, ql = ql_next;
         // ---- S^T: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
         const _Float16* kfrag_h = Ks + l15 * 64 + (g ^ (l15 & 7)) * 8;
         const _Float16* kfrag_l = Ks + l15 * 64 + ((4 + g) ^ (l15 & 7)) * 8;
@@ -891,6 +899,11 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 out[(size_t)q * 128 + 16] = Om[1][r] * inv;
             }
         }
+        // the next tile is claimed and its query fragment requested HERE, before the (rare) tie repair below and the loop's
+        // branch: 151-154 -> 148-151 us per launch.  (Requested earlier - right after the logits, so that the L2 round trip
+        // hides behind the search - the fragment occupies 8 registers the pass needs: 76 spilled registers, 185 us.)
+        qw_next = claim_tile();
+        if (qw_next >= 0) load_q(qw_next, qh_next, ql_next);
         if (TAP) continue;
         // ---- exact ties at the k-th place: a row kept more than k logits (topk_break_ties; about one row in 10^5).
         // A launch waits for its slowest workgroup, so this has to be short and must not burden the code above: the
@@ -899,6 +912,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // written:  o <- (o l - P' v) / (l - P'),  l <- l - P'.  (A second pass instead costs the launch 10 % at B = 64.)
         const int surplus = comm.rsum(kept_count(kept)) - a.topk;
         if (comm.any(surplus > 0)) {
+            load_q(qw, qh, ql);             // (the fragment registers may have been handed to the prefetch)
             logits(S);
             const float e = __builtin_amdgcn_exp2f(thr - m11);                  // P' of a tied logit, as softmax8 computes it
             const float eh = (float)(_Float16)e;
