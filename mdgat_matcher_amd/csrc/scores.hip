@@ -20,6 +20,7 @@ struct ScoreArgs {
     const float* col_bias;    // [B][M] or NULL (the kNN helper: |s_j|^2, pointops.hip)
     f32x4* zero;              // optional: zero_n 16-byte units cleared on the side (the exchange slots of the Sinkhorn kernel that
     size_t zero_n;            // runs next: spares the forward a memset launch)
+    int B, tx, ty;            // pairs; 128-wide tiles per pair along columns / rows
 };
 
 // BIAS: subtract col_bias[b][j] (the kNN helper; kept out of the score-matrix instance, whose epilogue is store-bound)
@@ -32,14 +33,20 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, i0 = blockIdx.y * 128, j0 = blockIdx.x * 128;
-    const float* A = a.A + (size_t)b * a.sA;
-    const float* Bm = a.Bm + (size_t)b * a.sB;
     if (a.zero) {
-        const size_t wg = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-        const size_t nwg = (size_t)gridDim.x * gridDim.y * gridDim.z;
+        const size_t wg = blockIdx.x, nwg = gridDim.x;
         for (size_t i = wg * 512 + tid; i < a.zero_n; i += nwg * 512) a.zero[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // XCD-aware tile order: workgroup i runs on XCD i % 8 and every XCD has its own L2.  All tiles of a pair go to ONE XCD
+    // (pair = 8 slot + i % 8), so each row of the two operand blocks is fetched from HBM once and re-read (tx / ty times)
+    // from that L2 - with the plain (x, y, pair) order the tiles of a pair were spread over all XCDs and PMC FETCH_SIZE
+    // showed 98 MB per launch for 33.5 MB of operands.  The grid is padded to 8 pairs per slot.
+    const int tiles = a.tx * a.ty;
+    const int q = blockIdx.x >> 3, b = (q / tiles) * 8 + (blockIdx.x & 7), t = q % tiles;
+    if (b >= a.B) return;
+    const int i0 = (t / a.tx) * 128, j0 = (t % a.tx) * 128;
+    const float* A = a.A + (size_t)b * a.sA;
+    const float* Bm = a.Bm + (size_t)b * a.sB;
 
     // ---- both operand tiles: fp32 rows -> (hi | lo) halves in LDS; 8 x 16-byte loads per thread and operand ----
     auto stage = [&](const float* src, int r0, int nrows, _Float16* dst) {
@@ -106,13 +113,15 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
 int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
                 const float* col_bias, hipStream_t s, void* zero, size_t zero_bytes) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
-    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias, static_cast<f32x4*>(zero), zero ? zero_bytes / 16 : 0};
+    const int tx = (M + 127) / 128, ty = (N + 127) / 128;
+    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias, static_cast<f32x4*>(zero), zero ? zero_bytes / 16 : 0, B, tx, ty};
+    const unsigned grid = (unsigned)(((B + 7) / 8) * 8 * tx * ty);
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
     static std::atomic<unsigned long long> optin[2];
     const void* kern = col_bias ? reinterpret_cast<const void*>(scores_kernel<true>) : reinterpret_cast<const void*>(scores_kernel<false>);
     if (int rc = mdgat_lds_optin(kern, lds, optin[col_bias != nullptr], "scores LDS attribute")) return rc;
-    if (col_bias) hipLaunchKernelGGL(scores_kernel<true>, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
-    else hipLaunchKernelGGL(scores_kernel<false>, dim3((M + 127) / 128, (N + 127) / 128, B), dim3(512), lds, s, a);
+    if (col_bias) hipLaunchKernelGGL(scores_kernel<true>, dim3(grid), dim3(512), lds, s, a);
+    else hipLaunchKernelGGL(scores_kernel<false>, dim3(grid), dim3(512), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "scores launch");
 }
 
