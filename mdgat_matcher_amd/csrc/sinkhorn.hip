@@ -866,9 +866,9 @@ struct ExArgs {
     float* s0; float* s1;
     const unsigned* sk_error;   // optional: error word of the cluster kernel that produced the arg-maxes (a lost partner) ...
     const float* Zfb;           // ... in which case the streaming fallback has written Z here: scan it instead
-    // optional, zeroed before the launch: [0] frame-0 keypoints matched so far in the batch, [1] workgroups done.  The last
-    // workgroup to finish applies the batch-wide rule of mdgat.py:465-467 (nothing matched anywhere: all scores zero)
-    // - no separate fix-up launch
+    // optional, zeroed before the launch (B < 65536): one ticket word, (workgroups whose pair matched anything) << 16 |
+    // workgroups done.  The last workgroup to finish applies the batch-wide rule of mdgat.py:465-467 (nothing matched
+    // anywhere: all scores zero) - no separate fix-up launch
     unsigned* alldust_counters;
     int B;
     // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
@@ -967,15 +967,14 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             s1[j] = keep ? expf(val1[j]) : 0.f;
         }
         if (a.alldust_counters) {
-            // mdgat.py:465-467 over the whole batch: count, and let the last workgroup to arrive decide
+            // mdgat.py:465-467 over the whole batch: one ticket word = (workgroups that matched anything) << 16 | workgroups done;
+            // the last workgroup to arrive decides
             const int any_valid = __syncthreads_or(nvalid > 0);         // (also: this workgroup's stores are issued)
             __shared__ int last;
             if (tid == 0) {
                 __threadfence();                                         // scores of this pair before the ticket
-                if (any_valid) atomicAdd(a.alldust_counters, 1u);
-                __threadfence();
-                const unsigned ticket = atomicAdd(a.alldust_counters + 1, 1u);
-                last = ticket == (unsigned)a.B - 1 && __hip_atomic_load(a.alldust_counters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0;
+                const unsigned old = atomicAdd(a.alldust_counters, (any_valid ? 0x10000u : 0u) + 1u);
+                last = (old & 0xffffu) == (unsigned)a.B - 1 && (old >> 16) == 0 && !any_valid;
                 __threadfence();
             }
             __syncthreads();
@@ -1145,7 +1144,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     if (ex) {
         // (header words 2, 3 of the workspace: the all-dustbin counters of the extraction, cleared with the slots)
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb,
-                 ex->defer_alldust ? nullptr : a.error_word + 2, B,
+                 (ex->defer_alldust || B >= 65536) ? nullptr : a.error_word + 2, B,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
     }
