@@ -114,12 +114,29 @@ def qk_roofline(dev, B, n, reps=20):
     flops = B * 2 * 4 * (2.0 * n * n * 32)            # Q K^T only: half of an attention launch
     useful = flops / (ms * 1e-3) / 1e12
     sus = ops.mfma_sustained(dev)
+    # the same phase as a standalone kernel with 32 (as shipped) and 64 queries per wave (every K fragment
+    # feeding two sets of products); the 64-query form exists only in isolation - the full kernel cannot hold its registers
+    standalone = {}
+    for sets in (1, 2):
+        for _ in range(3):
+            probe.run(nq_sets=sets)
+        torch.cuda.synchronize()
+        a.record()
+        for _ in range(reps):
+            probe.run(nq_sets=sets)
+        b.record()
+        torch.cuda.synchronize()
+        t = a.elapsed_time(b) / reps
+        standalone[f'standalone_{32 * sets}q_per_wave'] = {
+            'avg_launch_ms': t, 'frac_executed': SPLIT_FACTOR * flops / (t * 1e-3) / 1e12 / PEAK_F16_MFMA_TFLOPS,
+            'frac_executed_of_sustained': SPLIT_FACTOR * flops / (t * 1e-3) / 1e12 / sus['tflops']}
     return {'kernel': 'attention_stream_kernel, Q K^T phase in isolation (softmax and P.V knocked out)', 'bound': 'mfma',
             'avg_launch_ms': ms, 'algorithmic_flops_per_launch': flops, 'peak': PEAK_F16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
             'achieved': useful, 'frac': useful / PEAK_F16_MFMA_TFLOPS,
             'achieved_executed': SPLIT_FACTOR * useful, 'frac_executed': SPLIT_FACTOR * useful / PEAK_F16_MFMA_TFLOPS,
             'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
             'frac_executed_of_sustained': SPLIT_FACTOR * useful / sus['tflops'],
+            'variants': standalone,
             'note': 'achieved / frac = algorithmic (fp32-equivalent) Q K^T FLOP/s; *_executed = f16 MFMA FLOP/s executed (3 MFMAs '
                     'per fp32-class product: no term can be dropped at the 1e-4 bar, profiles/precision_ablation_r2.txt)'}
 

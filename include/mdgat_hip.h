@@ -193,6 +193,13 @@ int mdgat_attention_sel(int B, int N, int M, int cross, int topk, const float* q
 int mdgat_attention_qk_probe(int B, int N, int M, int cross, const float* qkv, float* msg,
                              void* workspace, size_t workspace_bytes, void* stream);
 
+/* Measurement only (bench.py, roofline_qk.standalone_*): the same Q K^T phase as a standalone kernel with nq_sets = 1 (32
+ * queries per wave, the shipped arrangement) or 2 (64 queries per wave: every K fragment read from LDS feeds two sets of
+ * products) - the lever VERDICT r2 names; the full kernel cannot hold the registers for it.  Arguments
+ * and output as mdgat_attention_qk_probe.  Not part of the matching path. */
+int mdgat_attention_qk_probe_sets(int B, int N, int M, int cross, int nq_sets, const float* qkv, float* msg,
+                                  void* workspace, size_t workspace_bytes, void* stream);
+
 /* Measurement only (bench.py, roofline.sustained_*): the rate this device SUSTAINS on v_mfma_f32_16x16x32_f16 with random
  * operands resident in registers (two waves per SIMD, nothing but MFMAs, one workgroup pair per CU, `reps` x 24 MFMAs per
  * wave) - the chip clocks to its power budget under such a load, well below the 2.4 GHz the dense peak is quoted at.

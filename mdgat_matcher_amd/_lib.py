@@ -69,6 +69,7 @@ SIGNATURES = {
     'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_mfma_probe': (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_void_p]),
     'mdgat_attention_qk_probe': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_attention_qk_probe_sets': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_attention_sel': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_size_t, C.c_void_p]),
     'mdgat_topk_sel_words': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

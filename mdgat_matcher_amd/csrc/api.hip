@@ -482,6 +482,20 @@ extern "C" int mdgat_attention_qk_probe(int B, int N, int M, int cross, const fl
     return launch_attention_qk_probe(B, N, M, cross, q16, msg, s);
 }
 
+extern "C" int mdgat_attention_qk_probe_sets(int B, int N, int M, int cross, int nq_sets, const float* qkv, float* msg, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    if (!qkv || !msg || !workspace) { mdgat_set_error("mdgat_attention_qk_probe_sets: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (workspace_bytes < mdgat_attention_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 15)) {
+        mdgat_set_error("mdgat_attention_qk_probe_sets: workspace too small or not 16-byte aligned");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const Qkv16 q16 = mdgat_qkv16_carve(static_cast<_Float16*>(workspace), B, N, M);
+    if (static_cast<const void*>(qkv) != workspace)
+        if (int rc = launch_qkv_split(B, N, M, qkv, q16, s)) return rc;
+    return launch_qk_phase_probe(B, N, M, cross, nq_sets, q16, msg, s);
+}
+
 extern "C" int mdgat_pointwise(int M, int N, int K, const float* A, int lda, const float* W, int ldw, const float* bias,
                                int relu, const float* R, int ldr, float* C, int ldc, void* stream) {
     if (!A || !W || !C) { mdgat_set_error("mdgat_pointwise: null pointer"); return MDGAT_ERR_BAD_ARG; }

@@ -338,6 +338,116 @@ __global__ __launch_bounds__(256, 2) void attention_stream_kernel(StreamArgs a) 
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Measurement only: the Q K^T phase with NQ = 1 or 2 query sets per wave.  Same chunk ring, K copies
+// (global_load_lds), LDS layout, fragment reads and split-f16 MFMA sequence as attention_stream_kernel; per 32-key block a
+// wave reads the four K fragments ONCE and feeds them to NQ sets of six products (32 NQ queries per wave, 128 NQ per
+// workgroup).  NQ = 2 is the "64 queries per wave" form: half the LDS reads and ring / barrier overhead per product and four
+// independent accumulator chains instead of two.  It exists here only in isolation: with the softmax state of the full
+// kernel doubled as well (logits 2 x 32, products 2 x 32, O^T 2 x 16, query fragments 2 x 16, ...) a wave needs 270+
+// registers, i.e. one wave per SIMD - DESIGN.md section 5, profiles/NOTES_r3.md.  Output: the row maximum of the base-2
+// logits in msg[p][head * 32] (so that nothing is dead code), exactly what the QK_ONLY instance of the kernel above writes.
+template <int NQ>
+__global__ __launch_bounds__(256, 2) void qk_phase_probe_kernel(StreamArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int i0 = blockIdx.x;
+    const int grp = (i0 / (8 * a.QT)) * 8 + (i0 & 7), qt = (i0 >> 3) % a.QT;
+    const int head = grp & 3, side = (grp >> 2) & 1, b = grp >> 3;
+    const int P = a.N + a.M;
+    const int nq = side ? a.M : a.N, q_off = side ? a.N : 0;
+    const int src = a.cross ? 1 - side : side;
+    const int nk = src ? a.M : a.N, k_off = src ? a.N : 0;
+    const int q0 = qt * 128 * NQ;
+    if (q0 >= nq) return;
+    const int NCH = nk >> 6;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    // K copies: waves 0, 1 move the two 32-key blocks of every chunk (the V^T halves of the ring stay unused)
+    const int rl8 = lane >> 3, swz = (lane & 7) ^ rl8;
+    const char* dbase = reinterpret_cast<const char*>(a.k16 + (((size_t)b * P + k_off + (wave & 1) * 32) * 4 + head) * 64);
+    const unsigned voff = rl8 * 512 + swz * 16;
+    auto dma_chunk = [&](int ch) __attribute__((always_inline)) {
+        if (wave >= 2) return;
+        const char* s0 = dbase + (size_t)ch * (64 * 512);
+        const unsigned d0 = lds0 + (unsigned)(ch & (NSLOT - 1)) * CHUNK_BYTES + (unsigned)wave * BLK_BYTES;
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                         :: "s"(d0 + p * 1024 + ((p >> 1) & 1) * 128), "v"(voff), "s"(s0 + (size_t)p * (8 * 512)) : "memory");
+    };
+    const int krow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    unsigned kofs[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = 2 * i + hi;
+        kofs[i] = (krow >> 3) * 1024 + ((krow >> 4) & 1) * 128 + ((krow & 7) * 8 + (c ^ (krow & 7))) * 16;
+    }
+    const int qw = q0 + wave * 32 * NQ;
+    f16x8 qh[NQ][2], ql[NQ][2];
+#pragma unroll
+    for (int s_ = 0; s_ < NQ; ++s_) {
+        const int qrow = min(qw + 32 * s_ + l31, nq - 1);
+        const _Float16* p = a.q16 + (((size_t)b * P + q_off + qrow) * 4 + head) * 64 + 8 * hi;
+        qh[s_][0] = *reinterpret_cast<const f16x8*>(p);
+        qh[s_][1] = *reinterpret_cast<const f16x8*>(p + 16);
+        ql[s_][0] = *reinterpret_cast<const f16x8*>(p + 32);
+        ql[s_][1] = *reinterpret_cast<const f16x8*>(p + 48);
+    }
+    dma_chunk(0);
+    if (NCH > 1) dma_chunk(1);
+    if (NCH > 2) dma_chunk(2);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float mx[NQ];
+#pragma unroll
+    for (int s_ = 0; s_ < NQ; ++s_) mx[s_] = -__builtin_inff();
+    for (int c = 0; c < NCH; ++c) {
+        // chunk c has landed; the copies of chunks c + 1, c + 2 may stay in flight (4 per chunk in waves 0, 1)
+        if (wave < 2) {
+            if (c + 2 < NCH) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (c + 1 < NCH) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (c == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the query loads)
+        __syncthreads();                       // every wave is done with chunk c - 1: its slot takes chunk c + 3
+        if (c + 3 < NCH) dma_chunk(c + 3);
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb) {
+            const char* base = smem + (c & (NSLOT - 1)) * CHUNK_BYTES + jb * BLK_BYTES;
+            f16x8 kf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) kf[i] = *reinterpret_cast<const f16x8_a*>(base + kofs[i]);
+            f32x16 A[NQ], X[NQ];
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) A[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], qh[s_][0], zero16, 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) X[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[0], ql[s_][0], zero16, 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) A[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], qh[s_][1], A[s_], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) X[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[1], ql[s_][1], X[s_], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) X[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[2], qh[s_][0], X[s_], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_) X[s_] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[3], qh[s_][1], X[s_], 0, 0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < NQ; ++s_)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2 v = f32x2{X[s_][r], X[s_][r + 1]} + f32x2{A[s_][r], A[s_][r + 1]};
+                    mx[s_] = fmaxf(mx[s_], fmaxf(v[0], v[1]));
+                }
+        }
+    }
+#pragma unroll
+    for (int s_ = 0; s_ < NQ; ++s_) {
+        const float m = fmaxf(mx[s_], __shfl_xor(mx[s_], 32, 64));
+        const int q = qw + 32 * s_ + l31;
+        if (hi == 0 && q < nq) a.msg[((size_t)b * P + q_off + q) * 128 + head * 32] = m;
+    }
+}
+
 }  // namespace
 
 bool attention_stream_supported(int N, int M) { return N % 64 == 0 && M % 64 == 0; }
@@ -363,4 +473,20 @@ int launch_attention_qk_probe(int B, int N, int M, int cross, const Qkv16& qkv, 
     if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(attention_stream_kernel<false, true>), lds, optin, "qk probe LDS attribute")) return rc;
     hipLaunchKernelGGL((attention_stream_kernel<false, true>), dim3(B * 8 * a.QT), dim3(256), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "qk probe launch");
+}
+
+// nq_sets: 1 (32 queries per wave, as shipped) or 2 (64 queries per wave); see qk_phase_probe_kernel
+int launch_qk_phase_probe(int B, int N, int M, int cross, int nq_sets, const Qkv16& qkv, float* msg, hipStream_t s) {
+    if (!attention_stream_supported(N, M)) { mdgat_set_error("qk probe: key counts must be multiples of 64"); return MDGAT_ERR_UNSUPPORTED; }
+    if (nq_sets != 1 && nq_sets != 2) { mdgat_set_error("qk probe: nq_sets must be 1 or 2"); return MDGAT_ERR_BAD_ARG; }
+    const int nq_max = N > M ? N : M;
+    const int per_wg = 128 * nq_sets;
+    StreamArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, (nq_max + per_wg - 1) / per_wg};
+    const size_t lds = (size_t)NSLOT * CHUNK_BYTES;
+    static std::atomic<unsigned long long> optin[2];
+    const void* kern = nq_sets == 2 ? reinterpret_cast<const void*>(qk_phase_probe_kernel<2>) : reinterpret_cast<const void*>(qk_phase_probe_kernel<1>);
+    if (int rc = mdgat_lds_optin(kern, lds, optin[nq_sets - 1], "qk phase probe LDS attribute")) return rc;
+    if (nq_sets == 2) hipLaunchKernelGGL(qk_phase_probe_kernel<2>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
+    else hipLaunchKernelGGL(qk_phase_probe_kernel<1>, dim3(B * 8 * a.QT), dim3(256), lds, s, a);
+    return mdgat_check_hip(hipGetLastError(), "qk phase probe launch");
 }

@@ -124,6 +124,7 @@ bool attention_stream_supported(int N, int M);
 int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0);
 // measurement only: the Q K^T phase of the streamed kernel in isolation (msg[row][head * 32] receives the row maximum)
 int launch_attention_qk_probe(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s);
+int launch_qk_phase_probe(int B, int N, int M, int cross, int nq_sets, const Qkv16& qkv, float* msg, hipStream_t s);
 
 // fused layer tail (layer.hip): [mlp.0 -> mlp.3 -> residual] of one layer + q|k|v projection of the next
 struct LayerLaunch {

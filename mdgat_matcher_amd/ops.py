@@ -109,11 +109,18 @@ class QkProbe:
             _lib.check(self.lib.mdgat_attention_qk_probe(self.B, N, M, 0, x.data_ptr(), self.msg.data_ptr(), self.ws.data_ptr(),
                                                          self.need, _stream(x)), 'mdgat_attention_qk_probe')
 
-    def run(self, cross: bool = False):
+    def run(self, cross: bool = False, nq_sets: int = 0):
+        """nq_sets = 0: the Q K^T phase of the shipped kernel (softmax and P.V knocked out); 1 / 2: the standalone phase kernel
+        with 32 / 64 queries per wave (``mdgat_attention_qk_probe_sets``)."""
         with torch.cuda.device(self.ws.device):
-            _lib.check(self.lib.mdgat_attention_qk_probe(self.B, self.N, self.M, int(bool(cross)), self.ws.data_ptr(),
-                                                         self.msg.data_ptr(), self.ws.data_ptr(), self.need, _stream(self.ws)),
-                       'mdgat_attention_qk_probe')
+            if nq_sets:
+                _lib.check(self.lib.mdgat_attention_qk_probe_sets(self.B, self.N, self.M, int(bool(cross)), int(nq_sets), self.ws.data_ptr(),
+                                                                  self.msg.data_ptr(), self.ws.data_ptr(), self.need, _stream(self.ws)),
+                           'mdgat_attention_qk_probe_sets')
+            else:
+                _lib.check(self.lib.mdgat_attention_qk_probe(self.B, self.N, self.M, int(bool(cross)), self.ws.data_ptr(),
+                                                             self.msg.data_ptr(), self.ws.data_ptr(), self.need, _stream(self.ws)),
+                           'mdgat_attention_qk_probe')
         return self.msg
 
 

@@ -78,6 +78,26 @@ def test_attention_full(N, M, cross):
         assert err < 1e-5, (side, err)
 
 
+@pytest.mark.parametrize('B,N,M,cross', [(3, 512, 512, False), (2, 256, 512, True), (1, 1024, 768, False), (2, 64, 64, True)])
+def test_qk_phase_probes_agree(B, N, M, cross):
+    """bench.py's roofline_qk legs: the standalone Q K^T phase kernels with 32 and 64 queries per wave leave the row maxima of
+    the base-2 logits in msg[:, :, head * 32] - bit-identical to each other, the oracle's (fp64) to fp32 resolution; the Q K^T
+    phase of the shipped streamed kernel (softmax and P.V knocked out) leaves its RUNNING softmax reference there, which
+    follows the maximum only on jumps beyond 4 octaves: within [max - 4, max]."""
+    rs = np.random.RandomState(B + N + M)
+    qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
+    probe = ops.QkProbe(qkv.to(DEV), N, M)
+    outs = [probe.run(cross, nq_sets=s).clone()[:, :, ::32] for s in (0, 1, 2)]        # [B, N + M, 4 heads]
+    torch.cuda.synchronize()
+    assert torch.equal(outs[1], outs[2])
+    assert (outs[0] <= outs[1]).all() and (outs[0] >= outs[1] - 4.0).all()
+    for lo, hi, slo, shi in ((0, N, *((N, N + M) if cross else (0, N))), (N, N + M, *((0, N) if cross else (N, N + M)))):
+        q = qkv[:, lo:hi, 0].permute(0, 3, 2, 1)
+        k = qkv[:, slo:shi, 1].permute(0, 3, 2, 1)
+        ref = (torch.einsum('bdhn,bdhm->bhnm', q, k) / 32 ** 0.5 * 1.4426950408889634).amax(-1).permute(0, 2, 1)   # [B, n, H]
+        assert (outs[1][:, lo:hi].cpu().double() - ref).abs().max() < 2e-5
+
+
 @pytest.mark.parametrize('N,topk', [(512, 0), (512, 128), (320, 0), (100, 30), (1024, 0), (1024, 128)])
 @pytest.mark.parametrize('case', ['small_q_large_k', 'small_v', 'small_everything', 'large'])
 def test_attention_mismatched_magnitudes(N, topk, case):
