@@ -734,7 +734,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
         for (int c = 0; c < 8; ++c) V[c] = (ran && gcol0 + c < M) ? v0[c] + lg2(b[c]) : 0.f;
         // Z (base-2) = s + U + V with s = lg2(K) - u0 - v0 from the register block: the scores are not read a second time
-        // (67 MB per launch at B = 64).  K = exp2(s + u0 + v0) <= 1 carries s to ~1e-7; an entry that underflowed to 0
+        // (67 MB per launch at B = 64).  K = exp2(s + u0 + v0) <= 1 carries s to ~1e-7; an entry that underflowed to 0 OR INTO THE
+        // DENORMALS (v_log_f32 returns -inf for a denormal: found by tools/fuzz_forward.py on scores spanning 100 units)
         // (more than 126 octaves below its row maximum) is re-read.  Only where the block's registers have room for it:
         // in the kernels for more than 512 keypoints the longer live range of K costs 12 more spilled registers inside
         // the iteration loop (N = 2048: 7.5 -> 9.1 us per iteration), so they read the scores again instead.
@@ -762,13 +763,13 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     bool under = false;
 #pragma unroll
                     for (int c = 0; c < 8; ++c) {
-                        under |= (gcol0 + c < M) && !(K[r][c] > 0.f);
+                        under |= (gcol0 + c < M) && !(K[r][c] >= 1.17549435e-38f);
                         z[c] = (gcol0 + c < M) ? (lg2(K[r][c]) + dU + dV[c]) * MDGAT_LN2 - norm : -__builtin_inff();
                     }
                     if (__any(under)) {
 #pragma unroll
                         for (int c = 0; c < 8; ++c)
-                            if ((gcol0 + c < M) && !(K[r][c] > 0.f)) z[c] = (row[gcol0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
+                            if ((gcol0 + c < M) && !(K[r][c] >= 1.17549435e-38f)) z[c] = (row[gcol0 + c] * MDGAT_LOG2E + U + V[c]) * MDGAT_LN2 - norm;
                     }
                 } else {
 #pragma unroll

@@ -378,6 +378,21 @@ def test_sinkhorn_vs_oracle(N, M, iters):
         assert (Z - ref).abs().max() < 1e-4, streaming
 
 
+@pytest.mark.parametrize('N,M,iters,scale', [(512, 128, 7, 30.0), (512, 512, 3, 40.0), (300, 200, 20, 25.0), (1024, 512, 5, 30.0)])
+def test_sinkhorn_wide_dynamic_range(N, M, iters, scale):
+    """Scores spanning ~100 units and few iterations: entries of K = exp2(s - row maximum) fall INTO THE DENORMALS (and the
+    scalings fold them further down); the epilogue recovers the scores from log2 K, and v_log_f32 of a denormal is -inf
+    (found by tools/fuzz_forward.py: 7 entries of Z at -inf where the reference has -60).  Z must be finite and within
+    1e-4 of the oracle everywhere, for the cluster and the streaming kernel."""
+    rs = np.random.RandomState(N + M + iters)
+    s = torch.from_numpy(rs.standard_normal((2, N, M)) * scale + 50.0)
+    ref = O.log_optimal_transport(s, 0.37, iters)
+    for streaming in (False, True):
+        Z = ops.sinkhorn(s.to(DEV), 0.37, iters, streaming=streaming).cpu().double()
+        assert torch.isfinite(Z).all(), streaming
+        assert (Z - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()) / 100), (streaming, float((Z - ref).abs().max()))
+
+
 @pytest.mark.parametrize('B,N,M', [(3, 512, 512), (70, 300, 512), (2, 1024, 700), (1, 2048, 2048)])
 def test_sinkhorn_fallback_after_a_lost_partner(B, N, M, monkeypatch):
     """The cluster kernel's workgroups wait for their partners with bounded spins; a workgroup that gives up raises the

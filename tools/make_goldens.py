@@ -263,6 +263,7 @@ def main():
     # BASELINE configs[0] / configs[1] shapes, 8 reference-held pairs each (round 3: the headline shape had 2)
     gen_config(M, 'cfg_n256_L4_S20', 8, 256, 256, 4, 20, synth.DEFAULT_K)
     gen_config(M, 'cfg_n512_L9_S100', 8, 512, 512, 9, 100, synth.DEFAULT_K)
+    gen_config(M, 'cfg_n2048_L9_S200', 1, 2048, 2048, 9, 200, synth.DEFAULT_K)      # BASELINE configs[4]
     gen_ops(M)
     gen_edges(M)
 
