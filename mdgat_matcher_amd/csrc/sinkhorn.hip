@@ -498,6 +498,22 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
         }
         if (my_row_valid) { kbr = ex2(alpha + u0r); ar = 1.f; } else { u0r = 0.f; }
+        // Range of the scaling form: an entry more than ~100 octaves below its row's largest - a score 69 below the row
+        // maximum, or a bin score that far from it - is on its way out of fp32 (2^-126, sooner after a fold), and a column
+        // (or the dustbin column) made of such entries only has no sum left, where the log-domain reference still resolves
+        // it.  No trained network is near that; when the inputs are (tools/fuzz_sinkhorn.py: scores spread over 100+ units),
+        // the launch is handed to the log-domain streaming kernel: raise the error word.
+        {
+            float kmin = my_row_valid ? kbr : 1.f;
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
+#pragma unroll
+                for (int c = 0; c < 8; c += 2) {
+                    const bool v0_ = row0 + r < N && gcol0 + c < M, v1_ = row0 + r < N && gcol0 + c + 1 < M;
+                    kmin = fminf(kmin, fminf(v0_ ? K[r][c] : 1.f, v1_ ? K[r][c + 1] : 1.f));
+                }
+            if (kmin < 0x1p-100f) atomicOr(a.error_word, 2u);
+        }
         // absorbed dustbin row: u0_N = -alpha, so its entries are exp2(v0_j) = 1
         float u0N = -alpha, aN = 1.f;
         float v0[8], kr[8], b[8];         // per lane column: absorbed potential, dustbin-row entry, column scaling
@@ -724,7 +740,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
-        const bool partner_lost = P > 1 && __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const bool partner_lost = __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // (or: out of range)
         const float poison = partner_lost ? __builtin_nanf("") : 0.f;   // a partner never arrived: whatever this launch writes is
                                                                        // overwritten by the gated streaming kernel that follows
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
@@ -1138,7 +1154,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     if (cooperative || !can_fall_back || ngroups * P > num_cu) e = hipLaunchCooperativeKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     else e = hipLaunchKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
-    if (can_fall_back && P > 1) {
+    if (can_fall_back) {
         SkArgs f{scores, alpha_dev, alpha_host, zfb, N, M, iters, a.error_word, status ? status + MDGAT_STATUS_SK_FALLBACK : nullptr};
         if (int rc = launch_streaming(f, B, s)) return rc;
     }

@@ -3,7 +3,8 @@
 Every case: B, N, M, L, Sinkhorn iterations, top-k schedule, extraction mode, bin score drawn at random (frames up to 700
 keypoints, not multiples of anything).  Z must match the oracle run with the HIP selections forced to 1e-4
 (tests/parity_util.py), matches and scores must be what the extraction rules make of that Z, every dynamic row must hold
-exactly k keys, and the status of the handle must be clean.  tests/test_gpu_forward.py::test_fuzz_short runs 15 s of it."""
+exactly k keys, and the handle must not report a range violation (a Sinkhorn launch handed to the log-domain kernel
+because its scores span more than the scaling form holds is fine - and counted).  tests/test_gpu_forward.py::test_fuzz_short runs 15 s of it."""
 import os
 import sys
 import time
@@ -52,7 +53,7 @@ def one_case(rs):
         r['matches_vs_own_Z'] = bool(torch.equal(m0.cpu(), e0) and torch.equal(m1.cpu(), e1))
         r['err_mscores'] = max(float((s0.cpu().double() - es0).abs().max()), float((s1.cpu().double() - es1).abs().max()))
         ok = r['errZ'] <= 1e-4 and r['bad_count'] == 0 and r['max_gap'] < 2e-5 and r['matches_vs_own_Z'] and r['err_mscores'] <= 1e-5 * smax
-        ok = ok and not net.check('cuda:0')['sinkhorn_fallback']
+        r['fallback'] = net.check('cuda:0')['sinkhorn_fallback']      # (information: scores beyond the range of the scaling form)
     except Exception as e:                  # noqa: BLE001
         print('EXCEPTION', tag, repr(e))
         ok, r = False, {'errZ': float('nan')}
@@ -62,17 +63,18 @@ def one_case(rs):
 def run(budget=60.0, seed=0, verbose=True):
     """Returns (cases run, failures, worst forced-selection max|dZ|)."""
     rs = np.random.RandomState(seed)
-    t0, cases, fails, worst = time.time(), 0, 0, 0.0
+    t0, cases, fails, worst, fallbacks = time.time(), 0, 0, 0.0, 0
     while time.time() - t0 < budget:
         cases += 1
         ok, tag, r = one_case(rs)
+        fallbacks += bool(r.get('fallback'))
         worst = max(worst, r['errZ'] if r['errZ'] == r['errZ'] else 0.0)
         if not ok:
             fails += 1
             if verbose:
                 print('FAIL', tag, {kk: r.get(kk) for kk in ('errZ', 'matches_vs_own_Z', 'err_mscores', 'bad_count', 'max_gap', 'flip_rows')})
     if verbose:
-        print(f'{cases} cases in {time.time() - t0:.0f} s, {fails} failures, worst forced-selection max|dZ| {worst:.2e}')
+        print(f'{cases} cases in {time.time() - t0:.0f} s, {fails} failures, {fallbacks} with a Sinkhorn range fallback, worst forced-selection max|dZ| {worst:.2e}')
     return cases, fails, worst
 
 
