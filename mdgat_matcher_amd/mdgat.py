@@ -156,6 +156,25 @@ class MDGAT(nn.Module):
         # replicas never run __init__, so only the original module owns (and finally frees) the handles
         weakref.finalize(self, _close_states, self._states)
 
+    # ------------------------------------------------------------------ copy / pickle
+    _RUNTIME_ATTRS = ('_states', '_states_lock', '_blob_holder', '_sig_holder')
+
+    def __getstate__(self):
+        """copy.deepcopy(net) / torch.save(net) (the reference's nn.Module supports both): library handles, locks and packed
+        blobs are runtime state of THIS object and are rebuilt on first use of the copy."""
+        d = self.__dict__.copy()
+        for k in self._RUNTIME_ATTRS:
+            d.pop(k, None)
+        return d
+
+    def __setstate__(self, d):
+        super().__setstate__(d)
+        self._states = {}
+        self._states_lock = threading.RLock()
+        self._blob_holder = [None, False]
+        self._sig_holder = [self._signature()]
+        weakref.finalize(self, _close_states, self._states)
+
     # ------------------------------------------------------------------ cache invalidation
     def _invalidate(self):
         with self._states_lock:

@@ -480,6 +480,25 @@ def test_f16_operand_range_is_guarded():
     assert torch.isfinite(out['matching_scores0']).all() and net.check(DEV) == {'sinkhorn_fallback': False}
 
 
+def test_deepcopy_of_a_running_module():
+    """copy.deepcopy of a module that has already run: the copy builds its own library handle on first use and gives the
+    same bits; the original keeps working and both can be freed independently."""
+    import copy
+    net = MDGAT(synth.default_config(L=2, k=[16, None, 8, None], sinkhorn_iterations=10))
+    net.load_state_dict(synth.make_state_dict(L=2, seed=1))
+    net = net.eval().to(DEV)
+    d = synth.make_batch(2, 64, 48, device=DEV, dtype=torch.float32)
+    args = (d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1'])
+    ref = net.match(*args, return_scores=True)
+    clone = copy.deepcopy(net)
+    assert clone._states == {} and len(net._states) == 1
+    out = clone.match(*args, return_scores=True)
+    assert all(torch.equal(a, b) for a, b in zip(ref, out))
+    assert clone._states[0].handle.value != net._states[0].handle.value
+    del clone
+    assert all(torch.equal(a, b) for a, b in zip(ref, net.match(*args, return_scores=True)))
+
+
 def test_fuzz_short():
     """15 s of tools/fuzz_forward.py: random B, N, M (1 ... 700, not multiples of anything), L, Sinkhorn iterations, top-k
     schedules, all four extraction modes, bin scores - Z within 1e-4 of the oracle with the HIP selections forced, matches

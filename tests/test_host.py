@@ -395,3 +395,29 @@ def test_import_path_shim_resolves_models_mdgat():
         for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
             del sys.modules[k]
         sys.modules.update(saved)
+
+
+def test_deepcopy_and_pickle_drop_the_runtime_state():
+    """The reference's MDGAT is a plain nn.Module: copy.deepcopy(net) and torch.save(net) work.  Here the module also owns
+    library handles, locks and a packed blob - none of which may travel into a copy (a copied handle would be freed twice)."""
+    import copy
+    import io
+    net = MDGAT(synth.default_config(L=1, k=[4, None])).double().eval()
+    net.load_state_dict(synth.make_state_dict(L=1, seed=2))
+    net._host_blob()                                        # runtime state exists
+    net._states[0] = object()                               # (stands for a device state)
+    for clone in (copy.deepcopy(net), torch.load(io.BytesIO(_saved(net)), weights_only=False)):
+        assert clone is not net and clone._states == {} and clone._blob_holder == [None, False]
+        assert clone._states is not net._states and clone._states_lock is not net._states_lock
+        assert clone.config == net.config and not clone.training and clone.bin_score.dtype == torch.float64
+        for (ka, va), (kb, vb) in zip(net.state_dict().items(), clone.state_dict().items()):
+            assert ka == kb and torch.equal(va, vb) and va.data_ptr() != vb.data_ptr()
+        np.testing.assert_array_equal(clone.packed_weights(), net.packed_weights())
+    net._states.clear()
+
+
+def _saved(net):
+    import io
+    buf = io.BytesIO()
+    torch.save(net, buf)
+    return buf.getvalue()
