@@ -374,16 +374,32 @@ def test_load_packed_keeps_a_host_copy_for_other_devices():
         net._invalidate()
 
 
-def test_import_path_shim_resolves_models_mdgat():
-    """`from models.mdgat import MDGAT` (test.py:12) with <repo>/integration ahead on sys.path."""
+def test_import_path_shim_resolves_models_mdgat(tmp_path):
+    """`from models.superglue import SuperGlue; from models.mdgat import MDGAT` (test.py:11-12) with <repo>/integration ahead of
+    a reference checkout on sys.path: those two resolve to this implementation, the rest of the reference's `models` package
+    (models.pointnet...) to the checkout."""
     import importlib
     import sys
     shim = os.path.join(ROOT, 'integration')
+    checkout = tmp_path / 'reference_checkout'                    # stands for the reference tree: models/{__init__,mdgat,superglue,pointnet/..}
+    (checkout / 'models' / 'pointnet').mkdir(parents=True)
+    (checkout / 'models' / '__init__.py').write_text('')
+    (checkout / 'models' / 'mdgat.py').write_text('MDGAT = "the reference class"\n')
+    (checkout / 'models' / 'superglue.py').write_text('SuperGlue = "the reference class"\n')
+    (checkout / 'models' / 'pointnet' / '__init__.py').write_text('')
+    (checkout / 'models' / 'pointnet' / 'pointnet_util.py').write_text('WHERE = "checkout"\n')
     saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == 'models' or k.startswith('models.')}
+    sys.path.insert(0, str(checkout))
     sys.path.insert(0, shim)
     try:
         mod = importlib.import_module('models.mdgat')
         assert mod.MDGAT is MDGAT
+        sg = importlib.import_module('models.superglue').SuperGlue
+        assert issubclass(sg, MDGAT)
+        net = sg(synth.default_config(L=2))                       # a k entry in the config is ignored: every layer fully connected
+        assert net.k == [] and net._topk_schedule() == [0, 0, 0, 0]
+        assert set(net.state_dict()) == set(MDGAT(synth.default_config(L=2)).state_dict())
+        assert importlib.import_module('models.pointnet.pointnet_util').WHERE == 'checkout'
         for name in ('MLP', 'attention', 'dynamic_attention', 'log_optimal_transport', 'knn', 'get_graph_feature', 'match'):
             assert callable(getattr(mod, name)), name
         seq = mod.MLP([4, 32, 64, 128])
@@ -392,6 +408,7 @@ def test_import_path_shim_resolves_models_mdgat():
             mod.log_optimal_transport(torch.zeros(1, 4, 4), 1.0, 3)         # CPU tensors: the product has no CPU path
     finally:
         sys.path.remove(shim)
+        sys.path.remove(str(checkout))
         for k in [k for k in sys.modules if k == 'models' or k.startswith('models.')]:
             del sys.modules[k]
         sys.modules.update(saved)
