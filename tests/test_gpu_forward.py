@@ -116,6 +116,28 @@ def test_config_shapes_golden(golden_dir, name):
                  z_index=lambda Zc: np.concatenate([Zc[:, ::8, ::8].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1))
 
 
+@pytest.mark.parametrize('name', ['var_n256_L4_S20', 'var_n512_L9_S100', 'var_n400m512_L9_S100'])
+def test_config_shape_variants_golden(golden_dir, name):
+    """All four extraction branches of mdgat.py:441-483 at the BASELINE shapes and a ragged 400 x 512 pair, against the
+    REFERENCE's own outputs (tests/golden/var_*.npz): matches bit-identical, matching scores to 1e-4 except where a flipped
+    top-k near-tie moved them (bounded like Z in parity_util.assert_plain)."""
+    from parity_util import PLAIN_MAX
+    g = _g(golden_dir, name)
+    for tag, (loss_method, mutual) in {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True),
+                                       'sg': ('superglue', False), 'sgmutual': ('superglue', True)}.items():
+        if f'{tag}_matches0' not in g:
+            continue
+        net, data, (B, n, m, L) = _build(g, loss_method=loss_method, mutual_check=mutual)
+        with torch.no_grad():
+            out = net(data)
+        np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g[f'{tag}_matches0'], err_msg=tag)
+        np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g[f'{tag}_matches1'], err_msg=tag)
+        e0 = np.abs(out['matching_scores0'].cpu().numpy() - g[f'{tag}_mscores0'])
+        e1 = np.abs(out['matching_scores1'].cpu().numpy() - g[f'{tag}_mscores1'])
+        print(f'[parity] {name} {tag}: matches identical to the reference, max|d mscores| {max(e0.max(), e1.max()):.2e}')
+        assert max(e0.max(), e1.max()) < PLAIN_MAX and (np.concatenate([e0.ravel(), e1.ravel()]) > Z_TOL).mean() < 1e-2, tag
+
+
 def test_dataparallel_dropin_like_test_py(golden_dir):
     """The call sequence of test.py:156-201: DataParallel wrapper, 'module.'-prefixed checkpoint,
     net.double().eval() before every forward, dict in -> dict out."""

@@ -81,6 +81,30 @@ def test_config_shapes(golden_dir, name):
     np.testing.assert_allclose(out['matching_scores0'].numpy(), g['default_mscores0'], atol=1e-9)
 
 
+VARIANT_MODES = {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True), 'sg': ('superglue', False), 'sgmutual': ('superglue', True)}
+
+
+@pytest.mark.parametrize('name', ['var_n256_L4_S20', 'var_n512_L9_S100', 'var_n400m512_L9_S100'])
+def test_config_shape_variants(golden_dir, name):
+    """One pair at the BASELINE shapes (and a ragged 400 x 512 pair) through every extraction branch the reference can run."""
+    g = _load(golden_dir, name)
+    sd, data, k, L, S, n, m = _setup(g)
+    for tag, (loss_method, mutual) in VARIANT_MODES.items():
+        if f'{tag}_matches0' not in g:
+            continue
+        cap = {}
+        cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual)
+        out = O.mdgat_forward(sd, cfg, data, cap)
+        np.testing.assert_array_equal(out['matches0'].numpy(), g[f'{tag}_matches0'], err_msg=tag)
+        np.testing.assert_array_equal(out['matches1'].numpy(), g[f'{tag}_matches1'], err_msg=tag)
+        np.testing.assert_allclose(out['matching_scores0'].numpy(), g[f'{tag}_mscores0'], atol=1e-9, err_msg=tag)
+        np.testing.assert_allclose(out['matching_scores1'].numpy(), g[f'{tag}_mscores1'], atol=1e-9, err_msg=tag)
+        if tag == 'default':
+            Z = cap['Z'].numpy()
+            assert np.abs(Z[:, ::8, ::8] - g['Z_sub']).max() < 1e-8
+            assert np.abs(Z[:, -1, :] - g['Z_lastrow']).max() < 1e-8 and np.abs(Z[:, :, -1] - g['Z_lastcol']).max() < 1e-8
+
+
 def test_op_sinkhorn(golden_dir):
     g = _load(golden_dir, 'op_vectors')
     for tag in ('sk_7x5', 'sk_64x64', 'sk_48x64'):

@@ -173,6 +173,31 @@ def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0):
     print('wrote', name, Z.shape)
 
 
+def gen_config_variants(M, name, n, m, L, S, k, seed=0, first_pair=0):
+    """One pair at a BASELINE-sized shape through every extraction branch the reference can run for it (mdgat.py:441-483):
+    matches and scores per variant + the Z the default variant produced (sub-sampled).  Ragged pairs (N != M): the triplet /
+    superglue LOSS code raises there, so 'gap_loss' stands for the default branch and the superglue variants are skipped."""
+    sd = synth.make_state_dict(L=L, seed=seed)
+    data = synth.make_batch(1, n, m, first_pair=first_pair)
+    arrays = {'meta': np.array([1, n, m, L, S, seed, first_pair], dtype=np.int64),
+              'k': np.array([-1 if x is None else x for x in k], dtype=np.int64)}
+    for tag, (loss_method, mutual) in VARIANTS.items():
+        if n != m:
+            if loss_method == 'superglue':
+                continue
+            loss_method = 'gap_loss'
+        cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual)
+        out, cap = run_ref(M, build_ref_net(M, cfg, sd), data, capture=False)
+        arrays.update(out_arrays(out, tag))
+        if tag == 'default':
+            Z = cap['Z'].numpy()
+            arrays['Z_sub'] = Z[:, ::8, ::8].copy()
+            arrays['Z_lastrow'] = Z[:, -1, :].copy()
+            arrays['Z_lastcol'] = Z[:, :, -1].copy()
+    np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
+    print('wrote', name, [t for t in VARIANTS if f'{t}_matches0' in arrays])
+
+
 def gen_ops(M):
     rs = np.random.RandomState(42)
     arrays = {}
@@ -264,6 +289,9 @@ def main():
     gen_config(M, 'cfg_n256_L4_S20', 8, 256, 256, 4, 20, synth.DEFAULT_K)
     gen_config(M, 'cfg_n512_L9_S100', 8, 512, 512, 9, 100, synth.DEFAULT_K)
     gen_config(M, 'cfg_n2048_L9_S200', 1, 2048, 2048, 9, 200, synth.DEFAULT_K)      # BASELINE configs[4]
+    gen_config_variants(M, 'var_n256_L4_S20', 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)
+    gen_config_variants(M, 'var_n512_L9_S100', 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)
+    gen_config_variants(M, 'var_n400m512_L9_S100', 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)
     gen_ops(M)
     gen_edges(M)
 
