@@ -94,7 +94,7 @@ def test_forward_dict_contract_and_variants(golden_dir, name):
         assert np.abs(out['matching_scores1'].cpu().numpy() - g[f'{tag}_mscores1']).max() < Z_TOL, tag
 
 
-@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200'])
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n512_L9_S100_seed7'])
 def test_config_shapes_golden(golden_dir, name):
     """BASELINE configs[0] / configs[1] shapes (8 pairs each) and configs[4] (N = 2048, L = 9, 200 iterations: one pair) with the default dynamic schedule, against the REFERENCE's
     own fp64 output (tests/golden/cfg_*.npz) - unconditionally: matches bit-identical, plain |dZ| bounded, the literal

@@ -153,15 +153,15 @@ def gen_forward(M, name, B, n, m, L, S, k, seed=0, bin_score=1.0, first_pair=0):
     print('wrote', name, {k2: v.shape for k2, v in arrays.items() if k2 in ('Z', 'scores')})
 
 
-def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0):
-    sd = synth.make_state_dict(L=L, seed=seed)
+def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0, bin_score=1.0):
+    sd = synth.make_state_dict(L=L, seed=seed, bin_score=bin_score)
     data = synth.make_batch(B, n, m, first_pair=first_pair)
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
     net = build_ref_net(M, cfg, sd)
     out, cap = run_ref(M, net, data, capture=False)
     Z = cap['Z'].numpy()
     arrays = {'meta': np.array([B, n, m, L, S, seed, first_pair], dtype=np.int64),
-              'k': np.array([-1 if x is None else x for x in k], dtype=np.int64)}
+              'k': np.array([-1 if x is None else x for x in k], dtype=np.int64), 'bin_score': np.array(bin_score)}
     arrays.update(out_arrays(out, 'default'))
     arrays['Z_sub'] = Z[:, ::8, ::8].copy()
     arrays['Z_lastrow'] = Z[:, -1, :].copy()
@@ -289,6 +289,7 @@ def main():
     gen_config(M, 'cfg_n256_L4_S20', 8, 256, 256, 4, 20, synth.DEFAULT_K)
     gen_config(M, 'cfg_n512_L9_S100', 8, 512, 512, 9, 100, synth.DEFAULT_K)
     gen_config(M, 'cfg_n2048_L9_S200', 1, 2048, 2048, 9, 200, synth.DEFAULT_K)      # BASELINE configs[4]
+    gen_config(M, 'cfg_n512_L9_S100_seed7', 4, 512, 512, 9, 100, synth.DEFAULT_K, seed=7, first_pair=40, bin_score=0.37)   # other weights, other bin score
     gen_config_variants(M, 'var_n256_L4_S20', 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)
     gen_config_variants(M, 'var_n512_L9_S100', 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)
     gen_config_variants(M, 'var_n400m512_L9_S100', 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)
