@@ -160,12 +160,6 @@ struct WaveComm {
 // them in on the vector ALU (x = y = v; after the swap x holds the even 16-lane rows' values and y the odd rows' - for every lane
 // the pair (x, y) is (own value, partner's) in some order), instead of a ds_bpermute round trip through the LDS per step.
 // (inline asm: the clang builtins of this ROCm return the first result twice; the compiler inserts no wait states around an asm)
-#ifdef QUAD_SHUFFLE
-template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v, Op op) {
-    v = op(v, __shfl_xor(v, 16, 64));
-    return op(v, __shfl_xor(v, 32, 64));
-}
-#else
 template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v, Op op) {
     static_assert(sizeof(T) == 4, "32-bit values");
     unsigned x = __builtin_bit_cast(unsigned, v), y = x;
@@ -175,7 +169,6 @@ template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v,
     asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(x), "+v"(y));
     return op(__builtin_bit_cast(T, x), __builtin_bit_cast(T, y));
 }
-#endif
 struct QuadComm {
     static constexpr bool LOCAL_VOTE = true;
     static constexpr bool PACKED_COUNT = true;

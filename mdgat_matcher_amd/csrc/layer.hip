@@ -135,12 +135,8 @@ __device__ __forceinline__ void for_units(F&& f) { for_each_unit(f, std::make_in
 // "at most YOUNGER outstanding" says exactly that (stores issued in between only make the wait stricter).
 template <int YOUNGER>
 __device__ __forceinline__ void stage_wait() {
-#ifndef KO_NOVM
     asm volatile("s_waitcnt vmcnt(%0)" :: "n"(YOUNGER) : "memory");
-#endif
-#ifndef KO_NOBAR
     __syncthreads();
-#endif
 }
 // end of a PAIR of stages (last stage h1) that share one barrier: stages h1 + 1 and h1 + 2 must have landed, the copy of
 // stage h1 + 3 (issued during h1) may be in flight.  Needs NSLOT >= 5: stage h + 3 and h + 4 land in the slots of the pair before.
@@ -278,11 +274,7 @@ __global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int gp = min(wave_pt0 + 2 * i + hi, a.R - 1);
-#ifdef KO_NOPRO
-            t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)(gp & 15) * 128 + l31 * 4);
-#else
             t[i] = *reinterpret_cast<const f32x4*>(src + (size_t)gp * 128 + l31 * 4);
-#endif
         }
     };
     // f16 operand range guard: every activation becomes an f16 head + residual; a head beyond 65504 is

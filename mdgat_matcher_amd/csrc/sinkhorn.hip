@@ -248,9 +248,7 @@ __device__ __forceinline__ float wave_sum16(float (&acc)[16], int lane) {
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 // cache policy of the polling loads: agent scope (served by the L2, never by a CU's L1).  "nt" measures the same and had
 // been used until round 3; "sc0" alone hits stale L1 lines (partners time out).
-#ifndef SK_LD
 #define SK_LD "sc1"
-#endif
 
 // ------------------------------------------------------------------------------------------------
 // Scaling-form cluster kernel (N, M <= 512), the production path.
@@ -314,11 +312,7 @@ __device__ __forceinline__ void xstore(gu64* p, unsigned long long v, bool same_
     // A PLAIN store: the CU's L1 writes through to the XCD's L2, where the partners' (L1-bypassing) loads find it, and it stays
     // there.  With `nt` - as until round 3 - the L2 streamed every granule on to HBM: 115 MB written per launch at B = 64
     // (PMC WRITE_SIZE) against 11 MB now, and the hand-off waited for it: 3.2 -> 2.85 us per iteration, 391 -> 355 us per launch.
-#ifdef SK_STORE_NT
-    if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off nt" :: "v"(p), "v"(v) : "memory");
-#else
     if (same_xcd) asm volatile("global_store_dwordx2 %0, %1, off" :: "v"(p), "v"(v) : "memory");
-#endif
     else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -335,7 +329,6 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
     unsigned spins = 0;
     while (pending || extra_pending) {
         unsigned long long x[NMAX], xe = 0;
-#ifndef SK_POLL_SERIAL
         if (NMAX <= 4 && same_xcd) {
             // all outstanding partners in ONE round trip: the loads are issued back to back and awaited together (a wait per
             // load cost 346 against 337 us per launch at B = 64 once the stores had become plain; with up to 16 partners
@@ -349,9 +342,7 @@ __device__ __forceinline__ void poll_partners(gu64* base, size_t stride, int n, 
             for (int p = 0; p < NMAX; ++p)
                 if (pending & (1u << p)) asm volatile("" : "+v"(x[p]));       // (uses stay behind the wait)
             asm volatile("" : "+v"(xe));
-        } else
-#endif
-        {
+        } else {
 #pragma unroll
             for (int p = 0; p < NMAX; ++p)
                 if (pending & (1u << p)) x[p] = xload(base + (size_t)p * stride, same_xcd);
@@ -638,14 +629,10 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     if (GR > 1) {
                         xstore(base + (size_t)jr * SLOT_STRIDE + tid, tagbits | __builtin_bit_cast(unsigned, loc), same_xcd);
                         SK_TP(6);
-#ifndef SK_DUST_SEPARATE
                         const bool my_dust = wave == 7 && lane < GR && lane != jr;
                         poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd,
                                             my_dust ? base + (size_t)lane * SLOT_STRIDE + 512 : nullptr, &dust_in);
                         have_dust = my_dust && !failed;
-#else
-                        poll_partners<GMAX>(base + tid, SLOT_STRIDE, GR, jr, cep, vals, failed, a.error_word, same_xcd);
-#endif
                         SK_TP(7);
                     }
                     float total = 0.f;
@@ -807,14 +794,6 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 #pragma unroll
                     for (int c = 1; c < 8; ++c)
                         if (z[c] > bv) { bv = z[c]; bi = gcol0 + c; }
-#ifdef SK_ARGMAX_SHUFFLE
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) {
-                        const float ov = __shfl_xor(bv, o, 64);
-                        const int oi = __shfl_xor(bi, o, 64);
-                        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-                    }
-#else
                     {
                         // wave maximum on the vector ALU (DPP), then the LOWEST lane that holds it (lanes are in column order
                         // and bi is the lane's own first maximum: torch.max's first maximal index) - one ballot and two
@@ -825,7 +804,6 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                         bi = __builtin_amdgcn_readlane(bi, first);
                         bv = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, bv), first));
                     }
-#endif
                     if (!inner && last_c && zM > bv) { bv = zM; bi = M; }
                     if (lane == 0) {
                         a.rbest_idx[((size_t)pair * GC + jc) * N + i] = bi;
