@@ -18,7 +18,12 @@ the MEDIAN window is the reported value (`timing` lists them all).  Rank 0 print
 (whole job), plus
   roofline     - the dominant kernel class of the step against the f16 MFMA roofline (or HBM for Sinkhorn): algorithmic
                  FLOPs per launch over its average launch duration, measured live with HIP events on the launch stream
-                 (mdgat_profile); `frac_executed` = the 3x split-f16 MFMA work the matrix cores actually run;
+                 (mdgat_profile); `frac_executed` = the 3x split-f16 MFMA work the matrix cores actually run.  The library runs a
+                 batch of more than 32 768 keypoints as two half-batches in flight on two streams (csrc/api.hip: forward_batched;
+                 that is what the timed windows measure); a kernel's own worth is measured with the launches NOT overlapping -
+                 `roofline` / `kernels` come from extra forwards with mdgat_set_lanes(1) (one launch per class and layer over the
+                 whole batch; agrees with a kernel trace of `MDGAT_FORWARD_LANES=1 python bench.py`), `roofline_two_lanes` /
+                 `kernels_two_lanes` from the timed configuration (half the work per launch, intervals include waiting for CUs);
   roofline_qk  - the Q K^T contraction of full attention (the north star's "QK^T roofline"): the phase in isolation
                  (same kernel, softmax and P.V knocked out; mdgat_attention_qk_probe) timed with HIP events on the
                  launch stream, as algorithmic (`frac`) and executed (`frac_executed`) fraction of the dense f16 MFMA peak;
@@ -261,37 +266,70 @@ def main():
         if not args.no_breakdown:
             rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
             nsl = next((r['launches_per_step'] for r in rows if r['kernel'] == 'sinkhorn'), 1)
+            two_lanes = nsl > 1 and net.lanes != 1 and os.environ.get('MDGAT_FORWARD_LANES') != '1'
             if nsl > 1:
-                out['config']['batch_slices'] = f'{nsl} slices of {-(-B // nsl)} pairs per step inside the library (cache blocking; per-launch work below is a slice\'s)'
+                out['config']['batch_slices'] = (f'{nsl} slices of {-(-B // nsl)} pairs per step inside the library' +
+                                                 (', alternating between two streams (two slices in flight)' if two_lanes else ' (cache blocking)') +
+                                                 '; per-launch work below is a slice\'s')
             dom = max(rows, key=lambda r: r['step_ms'])
-            traffic, source = pmc_traffic(args.config if B == c['B'] and att == c['att'] else -1, dom['kernel'])
-            if 'flops' in dom:
-                alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
-                ach = (SPLIT_FACTOR if parity or not dom['kernel'].startswith('attention') else 1.0) * alg
-                roof = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': alg, 'peak': PEAK_F16_MFMA_TFLOPS,
-                        'unit': 'TFLOP/s', 'frac': alg / PEAK_F16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
-                        'avg_launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
-                        'achieved_executed': ach, 'frac_executed': ach / PEAK_F16_MFMA_TFLOPS,
-                        'note': 'achieved / frac = ALGORITHMIC (fp32-equivalent) FLOPs of one launch (SURVEY 8d, DESIGN.md '
-                                'section 5) over its average duration, against the dense f16 MFMA peak; *_executed = the f16 '
-                                'MFMA FLOPs the matrix cores run for it = 3 x algorithmic (every product is hi.hi + hi.lo + '
-                                'lo.hi); traffic = HBM bytes per launch from the PMC passes of this command named in '
-                                'traffic_source (not measured in this run)'}
-            else:
-                ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
-                roof = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
-                        'frac': ach / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': dom['ms'],
-                        'bytes_per_launch': dom['bytes'],
-                        'note': 'bytes = the streamed-form algorithmic traffic 2 S (n+1)^2 4 B per pair (SURVEY 8d)'}
-            if roof['bound'] == 'mfma':
-                # the ceiling that exists on this box: the matrix cores under nothing but MFMAs on random operands (the chip
-                # clocks to its power budget: ~1.6 instead of 2.4 GHz on this pool), measured live (mdgat_mfma_probe)
-                sus = ops.mfma_sustained(dev)
-                roof.update({'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
-                             'frac_executed_of_sustained': roof['achieved_executed'] / sus['tflops'],
-                             'sustained_note': 'sustained_peak = f16 MFMA TFLOP/s of an MFMA-only loop on random operands on '
-                                               'this device, measured in this run (mdgat_mfma_probe); frac stays against the '
-                                               'dense peak at 2.4 GHz; frac_executed_of_sustained = executed rate over it'})
+
+            def roofline_block(dom, pmc_key):
+                traffic, source = pmc_traffic(pmc_key if B == c['B'] and att == c['att'] else -1, dom['kernel'])
+                if 'flops' in dom:
+                    alg = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+                    ach = (SPLIT_FACTOR if parity or not dom['kernel'].startswith('attention') else 1.0) * alg
+                    roof = {'kernel': dom['kernel'], 'bound': 'mfma', 'achieved': alg, 'peak': PEAK_F16_MFMA_TFLOPS,
+                            'unit': 'TFLOP/s', 'frac': alg / PEAK_F16_MFMA_TFLOPS, 'traffic': traffic, 'traffic_source': source,
+                            'avg_launch_ms': dom['ms'], 'algorithmic_flops_per_launch': dom['flops'],
+                            'achieved_executed': ach, 'frac_executed': ach / PEAK_F16_MFMA_TFLOPS,
+                            'note': 'achieved / frac = ALGORITHMIC (fp32-equivalent) FLOPs of one launch (SURVEY 8d, DESIGN.md '
+                                    'section 5) over its average duration, against the dense f16 MFMA peak; *_executed = the f16 '
+                                    'MFMA FLOPs the matrix cores run for it = 3 x algorithmic (every product is hi.hi + hi.lo + '
+                                    'lo.hi); traffic = HBM bytes per launch from the PMC passes of this command named in '
+                                    'traffic_source (not measured in this run)'}
+                else:
+                    ach = dom['bytes'] / (dom['ms'] * 1e-3) / 1e9
+                    roof = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'frac': ach / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': dom['ms'],
+                            'bytes_per_launch': dom['bytes'],
+                            'note': 'bytes = the streamed-form algorithmic traffic 2 S (n+1)^2 4 B per pair (SURVEY 8d)'}
+                if roof['bound'] == 'mfma':
+                    # the ceiling that exists on this box: the matrix cores under nothing but MFMAs on random operands (the chip
+                    # clocks to its power budget: ~1.6 instead of 2.4 GHz on this pool), measured live (mdgat_mfma_probe)
+                    sus = ops.mfma_sustained(dev)
+                    roof.update({'sustained_peak': sus['tflops'], 'sustained_clock_ghz': sus['clock_ghz'],
+                                 'frac_executed_of_sustained': roof['achieved_executed'] / sus['tflops'],
+                                 'sustained_note': 'sustained_peak = f16 MFMA TFLOP/s of an MFMA-only loop on random operands on '
+                                                   'this device, measured in this run (mdgat_mfma_probe); frac stays against the '
+                                                   'dense peak at 2.4 GHz; frac_executed_of_sustained = executed rate over it'})
+                return roof
+
+            roof = roofline_block(dom, str(args.config))
+            if two_lanes:
+                # The timed configuration keeps two half-batches in flight on two streams (api.hip: forward_batched): every launch
+                # shares the device with a launch of the other lane.  What a kernel is worth is measured with the launches NOT
+                # overlapping: the same kernel class launched alone over the whole batch (mdgat_set_lanes(1), the configuration
+                # of rounds 1-3; a kernel trace of `MDGAT_FORWARD_LANES=1 python bench.py` shows the same durations) - that is
+                # `roofline` / `kernels`.  `roofline_two_lanes` / `kernels_two_lanes` are the launches of the timed configuration:
+                # half the work per launch, and the interval between consecutive events on a lane's stream, which includes the
+                # time a launch waits for the other lane's workgroups to leave the CUs (a kernel trace, which clocks a kernel from
+                # its first wave, shows shorter durations: profiles/).
+                shared = roof
+                shared['lanes'] = 2
+                shared['note'] += ('; TWO lanes in flight: a launch covers half of the batch and shares the device with a launch of '
+                                   'the other lane; avg_launch_ms is the interval between consecutive events on the lane\'s stream '
+                                   '(includes waiting for CUs)')
+                out['roofline_two_lanes'] = shared
+                out['kernels_two_lanes'] = [{'kernel': r['kernel'], 'launches_per_step': r['launches_per_step'],
+                                             'avg_ms': round(r['ms'], 4), 'step_ms': round(r['step_ms'], 3)} for r in rows]
+                net.set_lanes(1)
+                rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
+                net.set_lanes(2)
+                roof = roofline_block(next(r for r in rows if r['kernel'] == dom['kernel']), f'{args.config}:single_lane')
+                roof['lanes'] = 1
+                roof['note'] += ('; measured with the launches of the batch NOT overlapping (mdgat_set_lanes(1): one launch per class '
+                                 'and layer over the whole batch) - the timed windows above run two half-batch lanes concurrently, '
+                                 'see roofline_two_lanes')
             out['roofline'] = roof
             if n % 64 == 0 and att == 'fp32':
                 out['roofline_qk'] = qk_roofline(dev, B, n)

@@ -146,7 +146,8 @@ int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, 
  * accumulated per class since the previous call in ms[MDGAT_PROF_CLASSES] / launches[...] (either may
  * be NULL), clears them, and switches the instrumentation on or off.  While it is on, mdgat_forward
  * ends with a stream synchronisation; an interval covers the launch(es) of the class and the gap
- * before them. */
+ * before them on that lane's stream (with two lanes in flight the launches of the two lanes share the device: an interval is
+ * then a launch's duration under that sharing, as a kernel trace reports it). */
 enum {
     MDGAT_PROF_ENCODER = 0,        /* both encoders up to the summed descriptor */
     MDGAT_PROF_LAYER = 1,          /* fused mlp + residual + next q/k/v projection (or final_proj) */
@@ -160,6 +161,16 @@ enum {
     MDGAT_PROF_CLASSES = 9
 };
 int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
+
+/* How a batch is executed (no counterpart in the reference, which hands the whole batch to every ATen kernel,
+ * models/mdgat.py:369-483).  lanes = 2 (default; MDGAT_FORWARD_LANES=1 in the environment selects 1): a batch of more than
+ * 32 768 keypoints is cut into an even number of balanced slices which alternate between the caller's stream and a second
+ * stream owned by the handle - forked from and joined to the caller's stream with events, so the call stays asynchronous
+ * and ordered on the caller's stream - because two half-size forwards in flight fill each other's idle phases (csrc/api.hip:
+ * forward_batched).  lanes = 1: everything on the caller's stream, slices of 65 536 keypoints beyond 1.5 x that.  Results do
+ * not depend on the setting (pairs are independent).  mdgat_workspace_bytes() follows the handle's setting: size the workspace
+ * after changing it. */
+int mdgat_set_lanes(mdgat_handle* h, int lanes);
 
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
 

@@ -60,6 +60,7 @@ SIGNATURES = {
                              [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_async_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+    'mdgat_set_lanes': (C.c_int, [C.c_void_p, C.c_int]),
     'mdgat_sinkhorn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     'mdgat_sinkhorn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -61,9 +61,13 @@ struct mdgat_handle {
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard
-    // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream
+    // Two lanes (forward_batched): the second lane's stream and the events that fork it off the caller's stream and join it again
+    int lanes;            // 1 or 2 (mdgat_set_lanes; default 2, MDGAT_FORWARD_LANES)
+    hipStream_t lane_stream;
+    hipEvent_t ev_fork, ev_join;
+    // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream of each lane
     bool prof_on;
-    std::vector<hipEvent_t> prof_ev;
+    struct ProfLane { std::vector<hipEvent_t> ev; std::vector<int> cls; size_t n = 0; } prof[2];
     double prof_ms[MDGAT_PROF_CLASSES];
     long long prof_launches[MDGAT_PROF_CLASSES];
 };
@@ -99,6 +103,12 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->loaded = false;
     h->host_error = nullptr;
     h->prof_on = false;
+    h->lane_stream = nullptr;
+    h->ev_fork = h->ev_join = nullptr;
+    {
+        const char* e = getenv("MDGAT_FORWARD_LANES");
+        h->lanes = (e && atoi(e) == 1) ? 1 : 2;
+    }
     for (int c = 0; c < MDGAT_PROF_CLASSES; ++c) { h->prof_ms[c] = 0.0; h->prof_launches[c] = 0; }
     int prev = 0;
     (void)hipGetDevice(&prev);
@@ -108,12 +118,12 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMemset(split weights)");
     if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
     if (!rc) for (int i = 0; i < MDGAT_STATUS_WORDS; ++i) h->host_error[i] = 0;
+    if (!rc) rc = mdgat_check_hip(hipStreamCreateWithFlags(&h->lane_stream, hipStreamNonBlocking), "hipStreamCreate(lane)");
+    if (!rc) rc = mdgat_check_hip(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "hipEventCreate");
+    if (!rc) rc = mdgat_check_hip(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "hipEventCreate");
     (void)hipSetDevice(prev);
     if (rc) {
-        if (h->weights) (void)hipFree(h->weights);
-        if (h->wsplit) (void)hipFree(h->wsplit);
-        if (h->host_error) (void)hipHostFree(h->host_error);
-        delete h;
+        mdgat_destroy(h);
         return rc;
     }
     *out = h;
@@ -167,7 +177,11 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (h->weights) (void)hipFree(h->weights);
     if (h->wsplit) (void)hipFree(h->wsplit);
     if (h->host_error) (void)hipHostFree(h->host_error);
-    for (hipEvent_t e : h->prof_ev) (void)hipEventDestroy(e);
+    if (h->lane_stream) { (void)hipStreamSynchronize(h->lane_stream); (void)hipStreamDestroy(h->lane_stream); }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    for (auto& pl : h->prof)
+        for (hipEvent_t e : pl.ev) (void)hipEventDestroy(e);
     delete h;
 }
 
@@ -198,10 +212,6 @@ Workspace carve(float* base, int B, int N, int M) {
 }
 }  // namespace
 
-extern "C" size_t mdgat_workspace_bytes(const mdgat_handle*, int B, int N, int M) {
-    if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return carve(nullptr, B, N, M).total * sizeof(float);
-}
 
 // ---------------------------------------------------------------------------------- forward
 static GemmArgs pointwise(const float* A, int lda, int K, const float* W, const float* bias, int relu, float* C, int ldc,
@@ -218,7 +228,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
                         const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
                         const float* rec0, const float* rec1, int normalize_fpfh,
                         int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
-                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0) {
+                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0, int lane = 0) {
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
     if (static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_RANGE]) {
@@ -235,7 +245,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         mdgat_set_error("mdgat_forward: null pointer argument");
         return MDGAT_ERR_BAD_ARG;
     }
-    const size_t need = mdgat_workspace_bytes(h, B, N, M);
+    const size_t need = carve(nullptr, B, N, M).total * sizeof(float);
     if (workspace_bytes < need) { mdgat_set_error("mdgat_forward: workspace %zu < %zu bytes", workspace_bytes, need); return MDGAT_ERR_BAD_ARG; }
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) { mdgat_set_error("mdgat_forward: workspace must be 256-byte aligned"); return MDGAT_ERR_BAD_ARG; }
     const int L2 = 2 * h->cfg.L;
@@ -256,19 +266,18 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     unsigned* status_dev = nullptr;
     if ((rc = mdgat_check_hip(hipHostGetDevicePointer(reinterpret_cast<void**>(&status_dev), h->host_error, 0), "hipHostGetDevicePointer"))) return rc;
 
-    // profiling (off by default): an event after every launch; intervals are attributed to kernel classes after
-    // the forward, which then ends with a stream synchronisation
-    std::vector<int> prof_cls;
-    size_t prof_n = 0;
+    // profiling (off by default): an event after every launch on this lane's stream; the intervals are attributed to the
+    // kernel classes after the whole batch has been enqueued (prof_collect), which then ends with a synchronisation
+    mdgat_handle::ProfLane& pl = h->prof[lane];
     auto mark = [&](int cls) {
         if (!h->prof_on) return;
-        if (prof_n == h->prof_ev.size()) {
+        if (pl.n == pl.ev.size()) {
             hipEvent_t e;
             if (hipEventCreate(&e) != hipSuccess) return;
-            h->prof_ev.push_back(e);
+            pl.ev.push_back(e);
         }
-        (void)hipEventRecord(h->prof_ev[prof_n++], s);
-        prof_cls.push_back(cls);
+        (void)hipEventRecord(pl.ev[pl.n++], s);
+        pl.cls.push_back(cls);
     };
     mark(-1);
 
@@ -336,50 +345,133 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, status_dev,
                               Z ? Z : ws.Z, sk_clear != 0))) return rc;
     mark(MDGAT_PROF_SINKHORN);
-    if (h->prof_on && prof_n > 1) {
-        if ((rc = mdgat_check_hip(hipEventSynchronize(h->prof_ev[prof_n - 1]), "profile sync"))) return rc;
-        for (size_t i = 1; i < prof_n; ++i) {
-            float ms = 0.f;
-            if (hipEventElapsedTime(&ms, h->prof_ev[i - 1], h->prof_ev[i]) == hipSuccess && prof_cls[i] >= 0) {
-                h->prof_ms[prof_cls[i]] += ms;
-                h->prof_launches[prof_cls[i]] += 1;
+    return MDGAT_OK;
+}
+
+// profiling: wait for the events of both lanes and add the intervals between consecutive ones to their kernel classes
+// (an interval that starts at a -1 mark - the beginning of a forward_impl call - is counted, one that ends there is not)
+static int prof_collect(mdgat_handle* h) {
+    if (!h->prof_on) return MDGAT_OK;
+    for (auto& pl : h->prof) {
+        if (pl.n > 1) {
+            if (int rc = mdgat_check_hip(hipEventSynchronize(pl.ev[pl.n - 1]), "profile sync")) return rc;
+            for (size_t i = 1; i < pl.n; ++i) {
+                float ms = 0.f;
+                if (pl.cls[i] >= 0 && hipEventElapsedTime(&ms, pl.ev[i - 1], pl.ev[i]) == hipSuccess) {
+                    h->prof_ms[pl.cls[i]] += ms;
+                    h->prof_launches[pl.cls[i]] += 1;
+                }
             }
         }
+        pl.n = 0;
+        pl.cls.clear();
     }
     return MDGAT_OK;
 }
 
-// Large batches run in slices.  Pairs are independent, and a slice of ~64 pairs already fills the part (512 tiles of the layer
-// kernel, 2048 workgroups of the attention kernel, one Sinkhorn workgroup per CU at N = M = 512) - but its working set
-// (q / k / v: 1.6 MB per pair and layer at N = M = 512) still fits the 256 MB Infinity Cache between the kernel that writes it
-// and the one that reads it, which a batch of 128 no longer does: 20 400 pairs/s at B = 64 against 19 100-19 500 at
-// B = 128 ... 512 before.  Slices are balanced (B = 100 -> 2 x 50); the one batch-wide rule of the reference, mdgat.py:465-467,
-// is applied over the whole batch afterwards.  Taps (whole-batch layouts) run unsliced.
-static int forward_sliced(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
-                          const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
-                          const float* rec0, const float* rec1, int normalize_fpfh,
-                          int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
-                          const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
-    static const long slice_points = [] { const char* e = getenv("MDGAT_FORWARD_SLICE_POINTS"); return e ? atol(e) : 65536L; }();
+// Batches run in slices on two lanes.  Pairs are independent.  (i) A slice of ~64 pairs fills the part (512 tiles of the
+// layer kernel, 2048 workgroups of the attention kernel, one Sinkhorn workgroup per CU at N = M = 512) while its working set
+// (q / k / v: 1.6 MB per pair and layer) still fits the 256 MB Infinity Cache between the kernel that writes it and the one
+// that reads it, which a batch of 128 no longer does (20 400 pairs/s at B = 64 against 19 100-19 500 at B = 128 ... 512).
+// (ii) Round 3: the kernels of ONE forward run back to back with synchronised phases (every layer workgroup loads its tile
+// at the same moment, every launch has a tail, the Sinkhorn kernel mostly waits for its partners); two half-size forwards
+// on two streams fill each other's gaps: 2 x 32 pairs in flight 21 300 pairs/s against 20 500 for 1 x 64 on the same box
+// (tools/overlap_streams.py; 2 x 20 against 1 x 40: 20 300 / 16 350 - a single launch of 1.25 tile rounds has a long tail).
+// So: a batch of more than MDGAT_FORWARD_SLICE_POINTS (32 768) keypoints is cut into an EVEN number of balanced slices of at
+// most that many, which alternate between the caller's stream and the handle's second stream (forked from and joined to the
+// caller's stream by events: the call stays asynchronous and ordered on the caller's stream); each lane has its own half of
+// the workspace.  The one batch-wide rule of the reference, mdgat.py:465-467, is applied over the whole batch afterwards.
+// Taps (whole-batch layouts) run unsliced; mdgat_set_lanes(h, 1) / MDGAT_FORWARD_LANES=1 keeps everything on the caller's stream
+// (slices of 65 536 keypoints beyond 1.5 x that).
+struct LanePlan { int nslices, per, lanes; size_t lane_bytes; };
+static LanePlan lane_plan(int lanes, int B, int N, int M) {
+    static const long env_points = [] { const char* e = getenv("MDGAT_FORWARD_SLICE_POINTS"); return e ? atol(e) : -1L; }();   // unset: defaults; 0: never slice
+    LanePlan p{1, B, 1, 0};
     const long per_pair = (long)N + M;
-    long slice = per_pair > 0 ? slice_points / per_pair : 0;        // pairs per slice (64 at N = M = 512)
-    if (slice < 1) slice = 1;
-    if (!h || taps || B <= 0 || N <= 0 || M <= 0 || slice_points <= 0 || (long)B <= slice + slice / 2 || !matches0 || !matches1 || !mscores0 || !mscores1)
-        return forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
-                            mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
-    const int nslices = (int)((B + slice - 1) / slice);
-    const int per = (B + nslices - 1) / nslices;
-    auto off = [](const float* p, size_t n) { return p ? p + n : nullptr; };
-    for (int c = 0; c < B; c += per) {
-        const int b = B - c < per ? B - c : per;
-        const size_t c_ = (size_t)c;
-        if (int rc = forward_impl(h, b, N, M, off(kpts0, c_ * N * 3), off(sigma0, c_ * N), off(fpfh0, c_ * N * 33), off(kpts1, c_ * M * 3),
-                                  off(sigma1, c_ * M), off(fpfh1, c_ * M * 33), off(rec0, c_ * N * 37), off(rec1, c_ * M * 37), normalize_fpfh,
-                                  matches0 + c_ * N, matches1 + c_ * M, mscores0 + c_ * N, mscores1 + c_ * M,
-                                  Z ? Z + c_ * (N + 1) * (M + 1) : nullptr, nullptr, workspace, workspace_bytes, stream, 1))
-            return rc;
+    if (B <= 1 || per_pair <= 0 || env_points == 0) return p;
+    const long total = (long)B * per_pair;
+    if (lanes >= 2) {
+        const long pts = env_points > 0 ? env_points : 32768L;
+        if (total <= pts) return p;
+        long n = 2 * ((total + 2 * pts - 1) / (2 * pts));
+        if (n > B) n = B;
+        p.nslices = (int)n;
+        p.per = (int)((B + n - 1) / n);
+        p.nslices = (B + p.per - 1) / p.per;
+        p.lanes = p.nslices >= 2 ? 2 : 1;
+    } else {
+        const long pts = env_points > 0 ? env_points : 65536L;
+        long slice = pts / per_pair;
+        if (slice < 1) slice = 1;
+        if ((long)B <= slice + slice / 2) return p;
+        const long n = (B + slice - 1) / slice;
+        p.per = (int)((B + n - 1) / n);
+        p.nslices = (B + p.per - 1) / p.per;
     }
-    return launch_alldust_fixup(B, N, M, h->cfg.extract_mode, matches0, mscores1, static_cast<hipStream_t>(stream));
+    p.lane_bytes = (carve(nullptr, p.per, N, M).total * sizeof(float) + 255) & ~size_t(255);
+    return p;
+}
+
+extern "C" size_t mdgat_workspace_bytes(const mdgat_handle* h, int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    // (taps run unsliced: the whole batch's workspace is the lower bound in every case)
+    const size_t whole = carve(nullptr, B, N, M).total * sizeof(float);
+    const LanePlan p = lane_plan(h ? h->lanes : 2, B, N, M);
+    const size_t laned = p.lane_bytes * (size_t)p.lanes;
+    return whole > laned ? whole : laned;
+}
+
+extern "C" int mdgat_set_lanes(mdgat_handle* h, int lanes) {
+    if (!h || lanes < 1 || lanes > 2) { mdgat_set_error("mdgat_set_lanes: lanes must be 1 or 2"); return MDGAT_ERR_BAD_ARG; }
+    h->lanes = lanes;
+    return MDGAT_OK;
+}
+
+static int forward_batched(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
+                           const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
+                           const float* rec0, const float* rec1, int normalize_fpfh,
+                           int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                           const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+    LanePlan p{1, B, 1, 0};
+    if (h && !taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M);
+    if (p.nslices <= 1) {
+        const int rc = forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
+                                    mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+        return rc ? rc : prof_collect(h);
+    }
+    if (!workspace || workspace_bytes < p.lane_bytes * (size_t)p.lanes) {
+        mdgat_set_error("mdgat_forward: workspace %zu < %zu bytes", workspace_bytes, p.lane_bytes * (size_t)p.lanes);
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s0 = static_cast<hipStream_t>(stream);
+    int rc = MDGAT_OK;
+    if (p.lanes == 2) {
+        // (both lanes start together: a second lane started one to five launches behind the first - complementary kernels
+        // side by side - pays the delay as a tail: 20 900 -> 20 300 ... 19 700 pairs/s at B = 64)
+        if ((rc = mdgat_check_hip(hipEventRecord(h->ev_fork, s0), "fork record"))) return rc;
+        if ((rc = mdgat_check_hip(hipStreamWaitEvent(h->lane_stream, h->ev_fork, 0), "fork wait"))) return rc;
+    }
+    auto off = [](const float* q, size_t n) { return q ? q + n : nullptr; };
+    int slice = 0;
+    for (int c = 0; c < B && !rc; c += p.per, ++slice) {
+        const int b = B - c < p.per ? B - c : p.per;
+        const size_t c_ = (size_t)c;
+        const int lane = p.lanes == 2 ? (slice & 1) : 0;
+        rc = forward_impl(h, b, N, M, off(kpts0, c_ * N * 3), off(sigma0, c_ * N), off(fpfh0, c_ * N * 33), off(kpts1, c_ * M * 3),
+                          off(sigma1, c_ * M), off(fpfh1, c_ * M * 33), off(rec0, c_ * N * 37), off(rec1, c_ * M * 37), normalize_fpfh,
+                          matches0 + c_ * N, matches1 + c_ * M, mscores0 + c_ * N, mscores1 + c_ * M,
+                          Z ? Z + c_ * (N + 1) * (M + 1) : nullptr, nullptr, static_cast<char*>(workspace) + (size_t)lane * p.lane_bytes,
+                          p.lane_bytes, lane ? static_cast<void*>(h->lane_stream) : stream, 1, lane);
+    }
+    if (p.lanes == 2) {
+        // (joined even after a failed launch: the caller's stream must not run ahead of what the second lane was given)
+        const int rj = mdgat_check_hip(hipEventRecord(h->ev_join, h->lane_stream), "join record");
+        const int rw = mdgat_check_hip(hipStreamWaitEvent(s0, h->ev_join, 0), "join wait");
+        if (!rc) rc = rj ? rj : rw;
+    }
+    if (rc) return rc;
+    if ((rc = launch_alldust_fixup(B, N, M, h->cfg.extract_mode, matches0, mscores1, s0))) return rc;
+    return prof_collect(h);
 }
 
 extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
@@ -387,7 +479,7 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
                              int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                              const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1) { mdgat_set_error("mdgat_forward: null input pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_sliced(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
+    return forward_batched(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
                           mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
@@ -396,7 +488,7 @@ extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const 
                                     float* mscores1, float* Z, const mdgat_taps* taps, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if (!frames0 || !frames1) { mdgat_set_error("mdgat_forward_frames: null frame pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_sliced(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
+    return forward_batched(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
                           matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 

@@ -128,6 +128,11 @@ class MDGAT(nn.Module):
         self.attention_dtype = str(self.config.get('attention_dtype', 'fp32'))
         if self.attention_dtype not in ('fp32', 'f16', 'bf16'):
             raise ValueError(f"attention_dtype={self.attention_dtype!r}: expected 'fp32' or 'f16'")
+        # not a reference key either: how the library executes a batch (include/mdgat_hip.h: mdgat_set_lanes).  0 = its default
+        # (two lanes: the halves of a batch in flight on two streams); results do not depend on it
+        self.lanes = int(self.config.get('lanes', 0))
+        if self.lanes not in (0, 1, 2):
+            raise ValueError(f'lanes={self.lanes}: expected 1 or 2 (0: library default)')
         if self.descriptor != 'FPFH':
             raise NotImplementedError(
                 f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
@@ -268,6 +273,8 @@ class MDGAT(nn.Module):
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx)
             try:
+                if self.lanes:
+                    _lib.check(lib.mdgat_set_lanes(handle, self.lanes), 'mdgat_set_lanes')
                 if blob_device_tensor is not None:
                     n = blob_device_tensor.numel()
                     _lib.check(lib.mdgat_load_weights(handle, C.c_void_p(blob_device_tensor.data_ptr()), n, 1),
@@ -282,6 +289,17 @@ class MDGAT(nn.Module):
                 raise
             self._states[idx] = st
             return st
+
+    def set_lanes(self, lanes: int):
+        """1: every kernel of a batch on the caller's stream; 2 (library default): the halves of a batch in flight on two
+        streams (csrc/api.hip: forward_batched).  Applies to this module's handles on every device, now and later."""
+        if lanes not in (1, 2):
+            raise ValueError(f'lanes={lanes}: expected 1 or 2')
+        with self._states_lock:
+            self.lanes = lanes
+            for st in self._states.values():
+                with st.lock:
+                    _lib.check(_lib.load().mdgat_set_lanes(st.handle, lanes), 'mdgat_set_lanes')
 
     def load_packed(self, blob: torch.Tensor):
         """Install an already packed fp32 blob that lives on a GPU (e.g. received by an RCCL broadcast,

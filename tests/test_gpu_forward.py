@@ -553,7 +553,7 @@ def test_repeatable_bitwise():
 
 @pytest.mark.parametrize('bin_score', [1.0, 60.0])
 def test_large_batch_runs_in_slices(bin_score):
-    """A batch beyond 1.5 x 65536 keypoints runs as balanced slices inside mdgat_forward (api.hip: forward_sliced).  Pairs are
+    """A large batch runs as balanced slices inside mdgat_forward (api.hip: forward_batched).  Pairs are
     independent, so the result must be bit-identical to running the same pairs in two separate calls - including the one
     batch-wide rule of the reference (mdgat.py:465-467: no frame-0 keypoint matched anywhere -> all scores zero; bin_score 60
     sends every keypoint to the dustbin)."""
@@ -563,8 +563,8 @@ def test_large_batch_runs_in_slices(bin_score):
     net = net.to(DEV).eval()
     data = synth.make_batch(B, n, n, device=DEV)
     with torch.no_grad():
-        whole = net(data)                                     # 130 pairs: two slices of 65
-        halves = [net({k: (v[i:i + 65] if torch.is_tensor(v) else v) for k, v in data.items()}) for i in (0, 65)]   # unsliced calls
+        whole = net(data)                                     # 130 pairs: six slices of 22 on two lanes
+        halves = [net({k: (v[i:i + 65] if torch.is_tensor(v) else v) for k, v in data.items()}) for i in (0, 65)]   # separate calls
     for key in ('matches0', 'matches1', 'matching_scores0', 'matching_scores1'):
         assert torch.equal(whole[key], torch.cat([h[key] for h in halves])), key
     if bin_score > 10:
@@ -572,6 +572,44 @@ def test_large_batch_runs_in_slices(bin_score):
         assert (whole['matching_scores0'] == 0).all() and (whole['matching_scores1'] == 0).all()
     else:
         assert (whole['matches0'] >= 0).any()
+
+
+@pytest.mark.parametrize('B,n,m,bin_score', [(64, 512, 512, 1.0), (100, 200, 256, 1.0), (131, 512, 480, 1.0), (70, 512, 512, 60.0),
+                                            (33, 512, 512, 1.0)])
+def test_two_lanes_equal_one_lane(B, n, m, bin_score):
+    """A batch of more than 32 768 keypoints runs as an even number of slices alternating between the caller's stream and the
+    handle's second stream (api.hip: forward_batched).  Bit-identical to the same batch on one stream - matches, scores and Z,
+    ragged slice sizes, the batch-wide all-dustbin rule (mdgat.py:465-467; bin score 60) - and the call stays ordered on the
+    caller's stream: the outputs are read right behind it, and a second call reuses both workspaces."""
+    cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5, bin_score=bin_score))
+    net = net.to(DEV).eval()
+    data = synth.make_batch(B, n, m, device=DEV, dtype=torch.float32)
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    with torch.no_grad():
+        net.set_lanes(1)
+        one = net.match(*args, return_scores=True)
+        torch.cuda.synchronize()
+        net.set_lanes(2)
+        two = [net.match(*args, return_scores=True) for _ in range(3)]      # (back to back: the lanes' workspaces are reused)
+        side = torch.cuda.Stream(DEV)                                       # and from a stream of the caller's own
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            two.append(net.match(*args, return_scores=True))
+        torch.cuda.synchronize()
+    for out in two:
+        for a, b in zip(one, out):
+            assert torch.equal(a, b)
+    if bin_score > 10:
+        assert (one[0] == -1).all() and (one[2] == 0).all() and (one[3] == 0).all()
+    else:
+        assert (one[0] >= 0).any()
+    assert not net.check(DEV)['sinkhorn_fallback']
+    # the Python wrapper's forward(): the batch-wide rule and the status words behave the same with two lanes
+    with torch.no_grad():
+        out = net(data)
+    assert torch.equal(out['matches0'], one[0]) and (out['matching_scores0'].dtype == torch.int64) == (bin_score > 10)
 
 
 def test_match_frames_raw_records():
