@@ -612,6 +612,44 @@ def test_two_lanes_equal_one_lane(B, n, m, bin_score):
     assert torch.equal(out['matches0'], one[0]) and (out['matching_scores0'].dtype == torch.int64) == (bin_score > 10)
 
 
+def test_forward_is_capturable_as_a_hip_graph():
+    """The library allocates nothing and launches only on the stream it is given - plus, for a batch on two lanes, on its own
+    second stream, which is forked from and joined to the caller's stream with events: a stream capture of the caller's
+    stream therefore takes in both lanes.  torch.cuda.CUDAGraph (= hipGraph on ROCm) of a B = 64 forward replays to the
+    bits of the eager call, also after the inputs have changed in place."""
+    cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    net = net.to(DEV).eval()
+    d = synth.make_batch(64, 512, 512, device=DEV, dtype=torch.float32)
+    inputs = tuple(d[k] for k in ('keypoints0', 'scores0', 'descriptors0', 'keypoints1', 'scores1', 'descriptors1'))
+    other = synth.make_batch(64, 512, 512, first_pair=500, device=DEV, dtype=torch.float32)
+    with torch.no_grad():
+        eager = [t.clone() for t in net._run(*inputs, want_Z=True)]
+        eager_other = [t.clone() for t in net._run(*(other[k] for k in ('keypoints0', 'scores0', 'descriptors0', 'keypoints1',
+                                                                          'scores1', 'descriptors1')), want_Z=True)]
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):                                  # (warm-up on the capture side, as torch asks)
+            net._run(*inputs, want_Z=True)
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = net._run(*inputs, want_Z=True)
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(eager, out):
+            assert torch.equal(a, b)
+        for k, t in zip(('keypoints0', 'scores0', 'descriptors0', 'keypoints1', 'scores1', 'descriptors1'), inputs):
+            t.copy_(other[k])
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(eager_other, out):
+            assert torch.equal(a, b)
+    assert not net.check(DEV)['sinkhorn_fallback']
+
+
 def test_match_frames_raw_records():
     """Raw 37-float keypoint records (load_data.py:152-165) straight into the encoder kernel, FPFH normalisation
     (load_data.py:290-292) fused: same result as decoding with the oracle's restatement of the loader."""
