@@ -331,7 +331,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     if (taps && taps->mdesc)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
     // (the score kernel also clears the exchange slots of the Sinkhorn kernel that follows: no memset launch in between)
-    const size_t sk_clear = ws.sk_bytes ? sinkhorn_slots_clear_bytes(N, M) : 0;
+    const size_t sk_clear = ws.sk_bytes ? sinkhorn_slots_clear_bytes(B, N, M) : 0;
     if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s, sk_clear ? ws.sk : nullptr, sk_clear))) return rc;
     mark(MDGAT_PROF_SCORES);
     if (taps && taps->scores)

@@ -162,7 +162,7 @@ constexpr float MDGAT_F16_GUARD = 6.0e4f;     // f16 max is 65504; the split's h
 int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_score_dev, float bin_score_host,
                     int iters, float* Z, void* ws, size_t ws_bytes, const SkExtract* ex, hipStream_t s, unsigned* status = nullptr,
                     float* Zfb = nullptr, bool slots_cleared = false);
-size_t sinkhorn_slots_clear_bytes(int N, int M);   // 0: the shape does not use the cluster kernel
+size_t sinkhorn_slots_clear_bytes(int B, int N, int M);   // 0: the shape does not use the cluster kernel
 size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,

@@ -38,10 +38,13 @@ struct SkArgs {
     float alpha_host;
     float* Z;                 // [B][N+1][M+1]
     int N, M, iters;
-    // fallback use: run only if *only_if != 0 (the cluster kernel's error word: it lost a partner workgroup); workgroup 0
-    // then raises status_fallback (host-mapped, optional)
+    // fallback use: a pair is only redone if bit 0 of *only_if is set (the cluster kernel's error word: the launch lost a partner
+    // workgroup - every pair is redone) or its own word of pair_flags is (the pair's scores are beyond the range of the scaling
+    // form - the other pairs of the launch keep the cluster kernel's result: what a pair gets does not depend on its batch);
+    // a workgroup that runs raises status_fallback (host-mapped, optional)
     const unsigned* only_if;
     unsigned* status_fallback;
+    const unsigned* pair_flags;
 };
 
 __device__ __forceinline__ float wave_max(float v) {
@@ -75,8 +78,10 @@ __global__ __launch_bounds__(NW * 64) void sinkhorn_kernel(SkArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (a.only_if) {
-        if (__hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;
-        if (blockIdx.x == 0 && tid == 0 && a.status_fallback) __hip_atomic_store(a.status_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const bool mine = (__hip_atomic_load(a.only_if, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0 ||
+                          (a.pair_flags && __hip_atomic_load(a.pair_flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+        if (!mine) return;
+        if (tid == 0 && a.status_fallback) __hip_atomic_store(a.status_fallback, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     const float* S = a.scores + (size_t)blockIdx.x * N * M;
     float* Z = a.Z + (size_t)blockIdx.x * (N + 1) * (M + 1);
@@ -280,7 +285,8 @@ struct SksArgs {
     float alpha_host;
     float* Z;
     unsigned long long* slots;   // per group: column slots [2][GC][GR][SLOT_STRIDE], then row slots [2][GR][GC][ROW_STRIDE]; zeroed per launch
-    unsigned* error_word;
+    unsigned* error_word;        // bit 0: a workgroup gave up waiting for a partner (the whole launch is redone); bit 1: some pair is out of range
+    unsigned* pair_flags;        // [B], zeroed per launch: this pair's scores are beyond the range of the scaling form (it alone is redone)
     unsigned* range_guard;       // optional, host-mapped: set when a score is not finite (an activation upstream left the f16 range)
     int B, N, M, iters, ngroups, GR, GC;
     int xcd_map;         // workgroup blockIdx = (slot * P + partner) * 8 + xcd: the partners of a pair share blockIdx % 8 (launch_scaling)
@@ -503,7 +509,10 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     const bool v0_ = row0 + r < N && gcol0 + c < M, v1_ = row0 + r < N && gcol0 + c + 1 < M;
                     kmin = fminf(kmin, fminf(v0_ ? K[r][c] : 1.f, v1_ ? K[r][c + 1] : 1.f));
                 }
-            if (kmin < 0x1p-100f) atomicOr(a.error_word, 2u);
+            if (kmin < 0x1p-100f) {
+                atomicOr(a.error_word, 2u);
+                __hip_atomic_store(a.pair_flags + pair, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
         // absorbed dustbin row: u0_N = -alpha, so its entries are exp2(v0_j) = 1
         float u0N = -alpha, aN = 1.f;
@@ -727,7 +736,8 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
-        const bool partner_lost = __hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // (or: out of range)
+        const bool partner_lost = (__hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0 ||
+                                  __hip_atomic_load(a.pair_flags + pair, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // (or: this pair out of range)
         const float poison = partner_lost ? __builtin_nanf("") : 0.f;   // a partner never arrived: whatever this launch writes is
                                                                        // overwritten by the gated streaming kernel that follows
         const bool ran = a.iters > 0;    // with zero iterations u = v = 0 (the absorbed potentials are not potentials)
@@ -859,8 +869,9 @@ struct ExArgs {
     float thr;
     int64_t* m0; int64_t* m1;
     float* s0; float* s1;
-    const unsigned* sk_error;   // optional: error word of the cluster kernel that produced the arg-maxes (a lost partner) ...
+    const unsigned* sk_error;   // optional: error word of the cluster kernel that produced the arg-maxes (bit 0: a lost partner) ...
     const float* Zfb;           // ... in which case the streaming fallback has written Z here: scan it instead
+    const unsigned* pair_flags; // ... or, with sk_error, this pair alone was redone by the streaming kernel ([B])
     // optional, zeroed before the launch (B < 65536): one ticket word, (workgroups whose pair matched anything) << 16 |
     // workgroups done.  The last workgroup to finish applies the batch-wide rule of mdgat.py:465-467 (nothing matched
     // anywhere: all scores zero) - no separate fix-up launch
@@ -877,7 +888,9 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // the cluster kernel lost a partner workgroup (bounded spin ran out): its fused arg-maxes are garbage; the gated streaming
     // kernel has recomputed Z since
-    const float* Zsrc = (a.sk_error && __hip_atomic_load(a.sk_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? a.Zfb : a.Z;
+    const bool redone = a.sk_error && ((__hip_atomic_load(a.sk_error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0 ||
+                                       (a.pair_flags && __hip_atomic_load(a.pair_flags + blockIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0));
+    const float* Zsrc = redone ? a.Zfb : a.Z;
     const float* Z = Zsrc + (size_t)blockIdx.x * (N + 1) * (M + 1);
     int* idx0 = reinterpret_cast<int*>(smem);   // [N]
     int* idx1 = idx0 + N;                       // [M]
@@ -1049,12 +1062,13 @@ static size_t slots_bytes(int N, int M) {
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
     return (256 + per_group * sk_max_groups(N, M) + 255) & ~(size_t)255;
 }
+static size_t flags_bytes(int B) { return ((size_t)B * sizeof(unsigned) + 255) & ~(size_t)255; }
 size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
     if (N > 2048 || M > 2048) return 0;
     int GR, GC;
     sk_tiling(N, M, GR, GC);
-    // exchange slots + fused arg-max scratch: row bests [B][GC][N] (int + float), column bests [B][GR][M] (int + float)
-    return slots_bytes(N, M) + ((size_t)B * GC * N * 2 + (size_t)B * GR * M * 2) * sizeof(float);
+    // exchange slots + per-pair range flags + fused arg-max scratch: row bests [B][GC][N] (int + float), column bests [B][GR][M] (int + float)
+    return slots_bytes(N, M) + flags_bytes(B) + ((size_t)B * GC * N * 2 + (size_t)B * GR * M * 2) * sizeof(float);
 }
 
 static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, bool defer_alldust = false);
@@ -1073,7 +1087,7 @@ static int launch_streaming(const SkArgs& a, int B, hipStream_t s) {
     return MDGAT_ERR_UNSUPPORTED;
 }
 
-size_t sinkhorn_slots_clear_bytes(int N, int M) { return (N > 2048 || M > 2048) ? 0 : slots_bytes(N, M); }
+size_t sinkhorn_slots_clear_bytes(int B, int N, int M) { return (N > 2048 || M > 2048) ? 0 : slots_bytes(N, M) + flags_bytes(B); }
 
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
                           float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* status, float* Zfb, bool slots_cleared, hipStream_t s) {
@@ -1095,16 +1109,19 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     const int grid = xcd_map ? ng8 * P : ngroups * P;
     if (ngroups < 1) { mdgat_set_error("sinkhorn: %d workgroups per pair do not fit the device", P); return MDGAT_ERR_UNSUPPORTED; }
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
-    if (!slots_cleared)      // (the forward has the score kernel clear them)
+    if (!slots_cleared) {    // (the forward has the score kernel clear them)
         if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 0, 256 + per_group * ngroups, s), "memset(sinkhorn slots)")) return rc;
+        if (int rc = mdgat_check_hip(hipMemsetAsync(static_cast<char*>(ws) + slots_bytes(N, M), 0, flags_bytes(B), s), "memset(sinkhorn pair flags)")) return rc;
+    }
     // test hook (tests/test_gpu_ops.py): pretend a partner was lost - the launch's error word starts out set, so the gated
     // streaming kernel and the extraction from its Z run for real
     if (const char* f = getenv("MDGAT_SK_FORCE_FALLBACK"); f && *f == '1')
         if (int rc = mdgat_check_hip(hipMemsetAsync(ws, 1, sizeof(unsigned), s), "memset(sinkhorn error word)")) return rc;
     SksArgs a{scores, alpha_dev, alpha_host, Z, reinterpret_cast<unsigned long long*>(static_cast<char*>(ws) + 256),
-              static_cast<unsigned*>(ws), status ? status + MDGAT_STATUS_RANGE : nullptr, B, N, M, iters, ngroups, GR, GC, xcd_map ? 1 : 0, -1, nullptr, nullptr, nullptr, nullptr};
+              static_cast<unsigned*>(ws), reinterpret_cast<unsigned*>(static_cast<char*>(ws) + slots_bytes(N, M)),
+              status ? status + MDGAT_STATUS_RANGE : nullptr, B, N, M, iters, ngroups, GR, GC, xcd_map ? 1 : 0, -1, nullptr, nullptr, nullptr, nullptr};
     if (ex) {
-        char* p = static_cast<char*>(ws) + slots_bytes(N, M);
+        char* p = static_cast<char*>(ws) + slots_bytes(N, M) + flags_bytes(B);
         a.ext_mode = ex->mode;
         a.rbest_idx = reinterpret_cast<int*>(p);                      p += (size_t)B * GC * N * sizeof(int);
         a.rbest_val = reinterpret_cast<float*>(p);                    p += (size_t)B * GC * N * sizeof(float);
@@ -1133,12 +1150,12 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
     else e = hipLaunchKernel(kern, dim3(grid), dim3(SKS_THREADS), args, 0, s);
     if (int rc = mdgat_check_hip(e, "sinkhorn scaling launch")) return rc;
     if (can_fall_back) {
-        SkArgs f{scores, alpha_dev, alpha_host, zfb, N, M, iters, a.error_word, status ? status + MDGAT_STATUS_SK_FALLBACK : nullptr};
+        SkArgs f{scores, alpha_dev, alpha_host, zfb, N, M, iters, a.error_word, status ? status + MDGAT_STATUS_SK_FALLBACK : nullptr, a.pair_flags};
         if (int rc = launch_streaming(f, B, s)) return rc;
     }
     if (ex) {
         // (header words 2, 3 of the workspace: the all-dustbin counters of the extraction, cleared with the slots)
-        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb,
+        ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb, a.pair_flags,
                  (ex->defer_alldust || B >= 65536) ? nullptr : a.error_word + 2, B,
                  a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
         return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
@@ -1164,10 +1181,10 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
     }
     if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
-    SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr};
+    SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr, nullptr};
     const int rc = launch_streaming(a, B, s);
     if (rc || !ex) return rc;
-    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
 }
 
@@ -1191,6 +1208,6 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, boo
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
     return launch_extract_impl(B, N, M, a, s);
 }

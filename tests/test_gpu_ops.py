@@ -393,6 +393,33 @@ def test_sinkhorn_wide_dynamic_range(N, M, iters, scale):
         assert (Z - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()) / 100), (streaming, float((Z - ref).abs().max()))
 
 
+@pytest.mark.parametrize('B,N,M,wide', [(5, 512, 512, (1,)), (9, 300, 400, (0, 7)), (3, 1024, 700, (2,)), (66, 512, 512, (13, 40))])
+def test_sinkhorn_range_fallback_is_per_pair(B, N, M, wide):
+    """A pair whose scores are beyond the range of the scaling form is handed to the log-domain kernel - THAT pair, not the
+    launch it happens to share with others: every pair of a mixed batch gets, bit for bit, what it gets alone (what a pair
+    returns must not depend on its batch: tools/fuzz_forward.py found slicings of one batch differing by 1e-5 on Z when the
+    whole launch was redone), wide pairs equal the streaming kernel's result, and everything is within the bar of the oracle."""
+    g = torch.Generator(DEV).manual_seed(B + N + M)
+    s = torch.randn(B, N, M, device=DEV, generator=g) * 3
+    for w in wide:
+        s[w] = s[w] * 14 + 50.0                    # spread over ~250 units: far beyond 100 octaves below the row maximum
+    Z = ops.sinkhorn(s, 0.8, 20)
+    Zs = ops.sinkhorn(s, 0.8, 20, streaming=True)
+    torch.cuda.synchronize()
+    assert torch.isfinite(Z).all()
+    for b in sorted(set(wide) | {0, B - 1, B // 2}):
+        alone = ops.sinkhorn(s[b:b + 1].contiguous(), 0.8, 20)
+        assert torch.equal(alone[0], Z[b]), b
+        if b in wide:
+            assert torch.equal(Z[b], Zs[b]), b      # redone by the streaming kernel
+        else:
+            assert not torch.equal(Z[b], Zs[b]) and (Z[b] - Zs[b]).abs().max() < 1e-4, b    # the cluster kernel's own result
+    some = sorted(set(wide) | {B - 1})
+    ref = O.log_optimal_transport(s[some].cpu().double(), 0.8, 20)
+    got = Z[some].cpu().double()
+    assert (got - ref).abs().max() < 1e-4 * max(1.0, float(ref.abs().max()) / 100)
+
+
 @pytest.mark.parametrize('B,N,M', [(3, 512, 512), (70, 300, 512), (2, 1024, 700), (1, 2048, 2048)])
 def test_sinkhorn_fallback_after_a_lost_partner(B, N, M, monkeypatch):
     """The cluster kernel's workgroups wait for their partners with bounded spins; a workgroup that gives up raises the
