@@ -71,6 +71,12 @@ typedef struct {
     int32_t extract_mode;              /* mdgat_extract_mode */
     float match_threshold;             /* config['match_threshold'] (322) */
     int32_t attention_mode;            /* mdgat_attention_mode; not a reference key (BASELINE configs[2]) */
+    int32_t exact_topk;                /* != 0 (the Python side's default): rows of a dynamic layer whose k-th and (k+1)-th largest
+                                          logit are closer than the fp32-class arithmetic of the attention kernels resolves are
+                                          re-decided from an fp64 evaluation of those logits (q / k re-projected from the layer's
+                                          input with the fp64 weights), so that `logits.topk(k)` (mdgat.py:202) selects what exact
+                                          arithmetic selects on the same layer input.  Not a reference key (the reference IS fp64);
+                                          fp32 attention mode only; MDGAT_TOPK_REPAIR=0 in the environment switches it off. */
 } mdgat_config;
 
 typedef struct mdgat_handle mdgat_handle;
@@ -86,6 +92,9 @@ typedef struct {
                            bit j of word w = key 32 w + j of the query's source frame; slices of full-attention layers are
                            left untouched.  Parity tests feed this selection to the oracle to separate near-tie flips of
                            the discontinuous top-k from arithmetic error. */
+    int32_t* repair_stats; /* [2L][4], zeroed by the caller: per dynamic layer the near-threshold rows examined by the exact
+                              re-decision (mdgat_config.exact_topk), rewritten, rewritten with a selection other than the one
+                              the fp32-class logits give, and given up (more than 32 candidates: masses of equal logits) */
 } mdgat_taps;
 size_t mdgat_topk_sel_words(int B, int N, int M);
 
@@ -96,7 +105,9 @@ size_t mdgat_topk_sel_words(int B, int N, int M);
 int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out);
 
 /* net.load_state_dict(...) (test.py:159) after host-side packing (BN folded into the convs, heads
- * de-interleaved, merge folded into mlp.0; mdgat_matcher_amd/pack.py).  `blob` holds
+ * de-interleaved, merge folded into mlp.0; mdgat_matcher_amd/pack.py).  Every weight is the fp32
+ * rounding of the folded fp64 value; the q and k projection rows also carry their fp32 RESIDUAL
+ * (fp64 weight - fp32 weight), which the exact top-k re-decision uses.  `blob` holds
  * mdgat_blob_floats(L) fp32 values; `on_device` != 0 when it is device memory (e.g. received by
  * an RCCL broadcast), else host memory. */
 int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device);

@@ -34,15 +34,16 @@ class MdgatConfig(C.Structure):
         ('extract_mode', C.c_int32),
         ('match_threshold', C.c_float),
         ('attention_mode', C.c_int32),
+        ('exact_topk', C.c_int32),
     ]
 
 
 class MdgatTaps(C.Structure):
     _fields_ = [('x_enc', C.c_void_p), ('x_layers', C.c_void_p), ('mdesc', C.c_void_p), ('scores', C.c_void_p),
-                ('topk_sel', C.c_void_p)]
+                ('topk_sel', C.c_void_p), ('repair_stats', C.c_void_p)]
 
 
-TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel')
+TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel', 'repair_stats')
 
 
 # name -> (restype, argtypes); every symbol include/mdgat_hip.h declares

@@ -42,6 +42,7 @@ BlobLayout mdgat_blob_layout(int L) {
     b.qkv_w = ltake(384 * 128);  b.qkv_b = ltake(384);
     b.mlp1_w = ltake(256 * 256); b.mlp1_b = ltake(256);
     b.mlp2_w = ltake(128 * 256); b.mlp2_b = ltake(128);
+    b.qk_lo_w = ltake(256 * 128); b.qk_lo_b = ltake(256);
     b.layer_stride = lo;
     o += lo * (size_t)(2 * L);
     b.final_w = take(128 * 128); b.final_b = take(128);
@@ -60,6 +61,7 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
+    bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk, fp32 attention mode, not MDGAT_TOPK_REPAIR=0
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard
     // Two lanes (forward_batched): the second lane's stream and the events that fork it off the caller's stream and join it again
     int lanes;            // 1 or 2 (mdgat_set_lanes; default 2, MDGAT_FORWARD_LANES)
@@ -101,6 +103,10 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights = nullptr;
     h->wsplit = nullptr;
     h->loaded = false;
+    {
+        const char* e = getenv("MDGAT_TOPK_REPAIR");
+        h->repair = cfg->exact_topk != 0 && cfg->attention_mode == MDGAT_ATTENTION_FP32 && !(e && atoi(e) == 0);
+    }
     h->host_error = nullptr;
     h->prof_on = false;
     h->lane_stream = nullptr;
@@ -190,9 +196,14 @@ namespace {
 struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
     _Float16* qkv16;
+    int* near_count;        // [MDGAT_MAX_LAYERS] near-threshold rows listed by each dynamic layer (zeroed at the start of a forward)
+    RepairRec* near_recs;   // [near_cap] the list itself, reused layer after layer (a layer's repair runs before the next layer lists)
+    int near_cap;
     size_t sk_bytes;
     size_t total;   // floats
 };
+// capacity of the near-threshold list: ~1-2 rows in 10^3 are listed; 1/16 of all (pair, head, query) rows is never reached
+int near_capacity(size_t R) { const size_t c = R * 4 / 16; return (int)(c < 1024 ? 1024 : c > (1u << 20) ? (1u << 20) : c); }
 Workspace carve(float* base, int B, int N, int M) {
     const size_t R = (size_t)B * (N + M);
     Workspace w{};
@@ -207,6 +218,9 @@ Workspace carve(float* base, int B, int N, int M) {
     w.sk_bytes = mdgat_sinkhorn_ws_bytes_impl(B, N, M);
     w.sk = take((w.sk_bytes + 3) / 4);
     w.qkv16 = reinterpret_cast<_Float16*>(take((mdgat_qkv16_halves(B, N, M) + 1) / 2));
+    w.near_count = reinterpret_cast<int*>(take(MDGAT_MAX_LAYERS));
+    w.near_cap = near_capacity(R);
+    w.near_recs = reinterpret_cast<RepairRec*>(take((size_t)w.near_cap * (sizeof(RepairRec) / sizeof(float))));
     w.total = o;
     return w;
 }
@@ -281,6 +295,12 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     };
     mark(-1);
 
+    // near-threshold lists of the dynamic layers (repair.hip): one counter per layer, cleared once per forward
+    bool repair = false;
+    for (int i = 0; i < L2; ++i) repair |= h->repair && h->cfg.topk[i] > 0 && !(h->cfg.topk[i] == N && h->cfg.topk[i] == M);
+    if (repair)
+        if ((rc = mdgat_check_hip(hipMemsetAsync(ws.near_count, 0, MDGAT_MAX_LAYERS * sizeof(int), s), "memset(near-threshold counters)"))) return rc;
+
     // ---- encoders (mdgat.py:392-393), one fused launch ----
     {
         EncoderLaunch e{};
@@ -314,8 +334,17 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
         uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
-        if ((rc = launch_attention(B, N, M, cross, h->cfg.topk[i], q16, ws.msg, s, h->cfg.attention_mode, sel))) return rc;
-        mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
+        const int kk = h->cfg.topk[i];
+        const bool fix = repair && kk > 0 && !(kk == N && kk == M);
+        const NearList nl{ws.near_count + i, ws.near_recs, ws.near_cap};
+        if ((rc = launch_attention(B, N, M, cross, kk, q16, ws.msg, s, h->cfg.attention_mode, sel, fix ? &nl : nullptr))) return rc;
+        if (fix) {
+            // ws.x still holds this layer's input (the descriptors q / k / v were projected from)
+            RepairLaunch rp{q16, ws.msg, ws.x, lw + bl.qkv_w, lw + bl.qk_lo_w, lw + bl.qkv_b, lw + bl.qk_lo_b, B, N, M, cross, kk, nl, sel,
+                            (taps && taps->repair_stats) ? taps->repair_stats + 4 * i : nullptr};
+            if ((rc = launch_topk_repair(rp, s))) return rc;
+        }
+        mark(kk > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1; p.guard = status_dev + MDGAT_STATUS_RANGE;
         p.w1s = ls + WS_W1; p.b1 = lw + bl.mlp1_b; p.w2s = ls + WS_W2; p.b2 = lw + bl.mlp2_b;

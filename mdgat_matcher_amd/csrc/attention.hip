@@ -48,7 +48,18 @@ struct AttnArgs {
     float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
     uint32_t* sel;         // TAP kernels only: [B][4][P][selW] bit j of word w = key 32 w + j of the source frame was kept
     int selW;
+    // near-threshold rows of a dynamic layer (repair.hip): a row whose largest DROPPED logit lies within near_eps() of the
+    // threshold is appended here and re-decided by topk_repair_kernel from an fp64 evaluation of the candidates
+    int* near_count;       // NULL: no list
+    RepairRec* near_recs;
+    int near_cap;
 };
+
+// append a near-threshold row (one lane per row calls this; rare: ~1 row in 10^3)
+__device__ __forceinline__ void near_append(const AttnArgs& a, int b, int side, int head, int q, float thr, float m) {
+    const int i = atomicAdd(a.near_count, 1);
+    if (i < a.near_cap) a.near_recs[i] = RepairRec{(b * 2 + side) * 4 + head, q, thr, m};
+}
 
 // parity tap (mdgat_taps.topk_sel): OR `bits` (NB consecutive keys starting at key0, NB | 32) into the row's mask
 __device__ __forceinline__ void tap_keys(uint32_t* row, int key0, unsigned bits) {
@@ -104,6 +115,8 @@ __device__ __forceinline__ float ge_const(float t) {
     const float tp = __builtin_bit_cast(float, bp);
     return t == -__builtin_inff() ? 3.0e38f : -tp * MDGAT_GE_BIG;
 }
+// the near threshold of a row (base-2 logit units; m = row maximum): what the fp32-class logits cannot resolve below thr
+__device__ __forceinline__ float near_thr(float thr, float m) { return thr - mdgat_near_eps(thr, m); }
 __device__ __forceinline__ f32x2 ge_ind(f32x2 s, float c) {
     f32x2 d;
     const f32x2 c2 = {c, c};
@@ -195,7 +208,7 @@ struct QuadComm {
 // logits (fp32 logits closer than one ulp, duplicated keypoints); the kernels count what the softmax pass keeps and
 // call topk_break_ties() for such rows, so that every row keeps exactly k keys like torch.topk.
 template <int NBLK, bool EXACT, typename Comm>
-__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
+__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm, bool want_near, bool& near) {
     const float INF = __builtin_inff();
     // the packed indicator form needs the logits in vector registers proper: not the 256-logit instance (half of its
     // row lives in accumulation registers) and not the split-key kernel (no register to spare)
@@ -375,7 +388,17 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         const int c2 = count_ge(e2);
         if (state == 3) thr = (c2 >= k) ? e2 : e1;
     }
-    return canon_thr(thr);          // (what every later comparison uses)
+    thr = canon_thr(thr);           // (what every later comparison uses)
+    // near-threshold rows (repair.hip): more than k logits at or above thr - near_eps means that the (k + 1)-th largest
+    // logit is closer to the threshold than the fp32-class logits resolve (or tied with the k-th).  One more counting
+    // pass per tile (want_near is uniform over the launch; MDGAT_NEAR_OFF compiles it out for A/B measurements).
+#ifndef MDGAT_NEAR_OFF
+    if (want_near) {
+        const int c = count_ge(near_thr(thr, m));      // (-inf pads never count: a finite near threshold, or nk <= k below)
+        near = nk > k && c > k;
+    }
+#endif
+    return thr;
 }
 
 // Exactly k keys per row (torch.topk keeps exactly k; which of several EQUAL logits it keeps is unspecified there -
@@ -527,6 +550,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
         bool redo = false;                                      // dynamic layers: exact ties at the k-th place
         int surplus = 0;
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
+        bool near_row = false;                                  // dynamic layers: a dropped logit within near_eps of the threshold
+        float thr_row = NEG_INF, m_row = NEG_INF;
 
         for (int wb0 = 0; wb0 < nblk; wb0 += wcap) {            // LDS windows (one unless LARGE)
             const int wnb = min(wcap, nblk - wb0);
@@ -583,7 +608,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 float thr = NEG_INF;
                 if (TOPK) {
                     WaveComm comm;
-                    thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm);
+                    thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
+                    thr_row = thr; m_row = m;
                     if (TAP) {      // the TAP build counts first, so that the selection it records is final
                         int c = 0;
 #pragma unroll
@@ -671,6 +697,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
         float l = l2[0] + l2[1];
         l += xor32(l);
         const float inv_l = 1.0f / l;
+        if (TOPK && a.near_count && near_row && hi == 0 && qw + l31 < nq) near_append(a, b, side, head, qw + l31, thr_row, m_row);
 
         // ---- message rows: lane holds column (dim) l31 of queries mfma32_row(r, hi) ----
         float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
@@ -809,7 +836,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[c][r]);
         m = comm.rmax(m);
-        const float thr = topk_threshold<8, true>(S, m, a.topk, nk, a.zq, comm);
+        bool near_row = false;
+        const float thr = topk_threshold<8, true>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
+        if (near_row && g == 0 && qw + l15 < nq) near_append(a, b, side, head, qw + l15, thr, m);      // -> repair list (rare)
         if (TAP) {
             // the selection the tap records is final: count and break exact ties at the k-th place before the pass
             int c = 0;
@@ -1073,7 +1102,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
         m = comm.rmax(m);
         WT(2);
-        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
+        bool near_row = false;
+        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
+        if (near_row && kw == 0 && hi == 0 && qw + l31 < nq) near_append(a, b, side, head, qw + l31, thr, m);      // -> repair list (rare)
         WT(3);
         {
             // exact ties at the k-th place (topk_break_ties): this kernel counts what the threshold keeps BEFORE its pass
@@ -1269,7 +1300,7 @@ extern "C" size_t mdgat_topk_sel_words(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     return (size_t)B * 4 * (N + M) * (((N > M ? N : M) + 31) / 32); }
 
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode, uint32_t* sel) {
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode, uint32_t* sel, const NearList* near) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
     if (topk > 0) {
@@ -1280,7 +1311,8 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             return MDGAT_ERR_BAD_ARG;
         }
     }
-    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f, nullptr, (nk_max + 31) / 32};
+    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f, nullptr, (nk_max + 31) / 32, nullptr, nullptr, 0};
+    if (near && near->count && topk > 0 && mode == 0) { a.near_count = near->count; a.near_recs = near->recs; a.near_cap = near->cap; }
     if (topk > 0) a.zq = normal_quantile_upper(((double)topk - 0.5) / (double)nk_max);
     const int nkp = ((nk_max + 31) / 32) * 32;
     const int wkeys = nkp > 512 ? 512 : nkp;      // keys the LDS window holds

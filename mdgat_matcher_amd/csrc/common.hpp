@@ -33,6 +33,19 @@ __device__ __forceinline__ void mdgat_split_unscaled(float x, _Float16& h, _Floa
 }
 #endif
 
+// ---- near-threshold rows of a dynamic layer (attention.hip -> repair.hip) ----------------------------------------------
+// dynamic_attention (mdgat.py:196-210) is discontinuous: a row whose k-th and (k+1)-th largest logit are closer than the
+// error of the fp32-class logits may keep the other key.  The dynamic-attention kernels append every row with a dropped
+// logit within mdgat_near_eps() below its threshold to a list; topk_repair_kernel re-decides those rows from an fp64
+// evaluation of the candidates (q / k re-projected from the fp32 descriptors with the fp64 weights) and rewrites the
+// row's message when a candidate straddles the threshold.
+struct RepairRec { int bsh; int q; float thr; float m; };   // ((pair * 2 + frame) * 4 + head), query row within its frame, threshold, row maximum
+#ifdef __HIPCC__
+// base-2 logit units.  Error of a logit against exact arithmetic on the same layer input: rms 1.9e-6, max 1.4e-5 for
+// logits of standard deviation 2.8 (profiles/NOTES_r3.md), proportional to the logits' scale - (|m| + |thr|) / 10 is ~1 there.
+__device__ __forceinline__ float mdgat_near_eps(float thr, float m) { return 2.0e-5f * fmaxf(1.0f, (fabsf(m) + fabsf(thr)) * 0.1f); }
+#endif
+
 // row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
 // (cdna_hip_programming.md section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).
 __device__ __forceinline__ constexpr int mfma32_row(int r, int hi) { return (r & 3) + 8 * (r >> 2) + 4 * hi; }
@@ -65,6 +78,7 @@ struct BlobLayout {
     size_t qkv_w, qkv_b;       // [384][128] rows = which*128 + head*32 + dim, [384]
     size_t mlp1_w, mlp1_b;     // [256][256] cols = [x | head-major message (merge folded)], [256]
     size_t mlp2_w, mlp2_b;     // [128][256], [128]
+    size_t qk_lo_w, qk_lo_b;   // [256][128], [256]: fp32 residuals of the q and k rows of qkv_w / qkv_b (fp64 weight = head + residual; repair.hip)
     size_t final_w, final_b;   // [128][128], [128]
     size_t bin_score;          // [1] (+3 pad)
     size_t total;
@@ -118,7 +132,21 @@ Qkv16 mdgat_qkv16_carve(_Float16* base, int B, int N, int M);
 int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& out, hipStream_t s);
 // mode: mdgat_attention_mode (1 = single-f16 products where implemented)
 // sel (parity tap, may be NULL): the kept keys of a dynamic layer as bit masks [B][4][P][W], W = ceil(max(N, M) / 32)
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0, uint32_t* sel = nullptr);
+struct NearList { int* count; RepairRec* recs; int cap; };    // device memory; count: one int per launch, zeroed by the caller
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0, uint32_t* sel = nullptr,
+                     const NearList* near = nullptr);
+// repair.hip: re-decide the near-threshold rows of the dynamic layer that has just run (x = the layer's input descriptors
+// [B][P][128]; w / wlo = the layer's q|k|v weights [384][128] (fp32 heads of the fp64 weights) and the residuals of the q and k
+// rows [256][128]; b / blo likewise [384] / [256]); stats (optional) = 4 device counters: rows examined, rewritten, changed
+// against the fp32-class selection, given up
+struct RepairLaunch {
+    Qkv16 qkv; float* msg; const float* x;
+    const float *w, *wlo, *b, *blo;
+    int B, N, M, cross, topk;
+    NearList near;
+    uint32_t* sel; int* stats;
+};
+int launch_topk_repair(const RepairLaunch& p, hipStream_t s);
 // full attention as a stream of 64-key chunks (attention_stream.hip); frames with key counts that are multiples of 64
 bool attention_stream_supported(int N, int M);
 int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0);

@@ -133,6 +133,9 @@ class MDGAT(nn.Module):
         self.lanes = int(self.config.get('lanes', 0))
         if self.lanes not in (0, 1, 2):
             raise ValueError(f'lanes={self.lanes}: expected 1 or 2 (0: library default)')
+        # not a reference key: exact re-decision of near-threshold rows of the dynamic layers (include/mdgat_hip.h:
+        # mdgat_config.exact_topk).  On by default: it is what makes `logits.topk(k)` select like fp64 arithmetic.
+        self.exact_topk = bool(self.config.get('exact_topk', True))
         if self.descriptor != 'FPFH':
             raise NotImplementedError(
                 f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
@@ -269,6 +272,7 @@ class MDGAT(nn.Module):
             cfg.extract_mode = self._extract_mode()
             cfg.match_threshold = float(self.config['match_threshold'])
             cfg.attention_mode = 0 if self.attention_dtype == 'fp32' else 1
+            cfg.exact_topk = int(getattr(self, 'exact_topk', True))
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx)

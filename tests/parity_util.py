@@ -148,3 +148,42 @@ def assert_plain_vs_oracle(res, cfg, sd, data_cpu, tag=''):
     ref = O.mdgat_forward(sd, cfg, data_cpu, cap)
     return assert_plain(res, cap['Z'].numpy(), ref['matches0'].numpy(), ref['matches1'].numpy(),
                         ref['matching_scores0'].numpy(), ref['matching_scores1'].numpy(), tag)
+
+
+def local_flips(net, sd, data_cpu, device='cuda:0', with_stats=False):
+    """{dynamic layer: rows whose HIP selection differs from the fp64 top-k of the HIP path's OWN fp32 layer input}: the flips
+    caused INSIDE the layer (q / k projection + q.k products), which the exact re-decision of near-threshold rows
+    (mdgat_config.exact_topk, csrc/repair.hip) removes.  ``with_stats``: also the repair counters [2L][4] (rows examined,
+    rewritten, rewritten with another selection than the fp32-class logits give, given up)."""
+    dev = {k: v.to(device) for k, v in data_cpu.items()}
+    k0 = dev['keypoints0']
+    B, N, M = k0.shape[0], k0.shape[1], dev['keypoints1'].shape[1]
+    sched = net._topk_schedule()
+    L2 = len(sched)
+    words = ops.topk_sel_words(B, N, M)
+    sel = torch.zeros(L2 * words, dtype=torch.int32, device=k0.device)
+    xl = torch.empty(L2, B, N + M, 128, device=k0.device)
+    xe = torch.empty(B, N + M, 128, device=k0.device)
+    stats = torch.zeros(L2, 4, dtype=torch.int32, device=k0.device)
+    net._run(k0, dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=False,
+             taps={'topk_sel': sel, 'x_layers': xl, 'x_enc': xe, 'repair_stats': stats})
+    torch.cuda.synchronize()
+    xl = torch.cat([xl, xe[None]]).cpu().double()          # index -1 = the encoder output = the input of layer 0
+    out = {}
+    for i, kk in enumerate(sched):
+        if kk <= 0:
+            continue
+        masks = ops.topk_sel_to_masks(sel[i * words:(i + 1) * words], B, N, M, cross=bool(i & 1))
+        rows = 0
+        for side in range(2):
+            x = (xl[i - 1][:, :N] if side == 0 else xl[i - 1][:, N:]).transpose(1, 2)      # [B, 128, n]: the HIP path's input
+            other = (xl[i - 1][:, N:] if side == 0 else xl[i - 1][:, :N]).transpose(1, 2)
+            src = other if (i & 1) else x
+            p = f'gnn.layers.{i}.attn'
+            q = O._pointwise(sd[f'{p}.proj.0.weight'], sd[f'{p}.proj.0.bias'], x).view(B, 32, 4, -1)
+            kk_ = O._pointwise(sd[f'{p}.proj.1.weight'], sd[f'{p}.proj.1.bias'], src).view(B, 32, 4, -1)
+            logits = torch.einsum('bdhn,bdhm->bhnm', q, kk_) / 32 ** 0.5
+            own = torch.zeros_like(logits, dtype=torch.bool).scatter_(3, logits.topk(kk, dim=3).indices, True)
+            rows += int((own ^ masks[side].cpu()).any(-1).sum())
+        out[i] = rows
+    return (out, stats.cpu()) if with_stats else out

@@ -11,7 +11,7 @@ pytestmark = pytest.mark.gpu
 from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
 
-from parity_util import assert_attributed, assert_plain, assert_plain_vs_oracle, attributed_parity  # noqa: E402
+from parity_util import assert_attributed, assert_plain, assert_plain_vs_oracle, attributed_parity, local_flips  # noqa: E402
 
 DEV = 'cuda:0'
 Z_TOL = 1e-4        # north star: soft-assignment matrix within 1e-4 (fp32-class kernels vs fp64 reference)
@@ -32,7 +32,7 @@ def _build(g, **cfg_over):
     k = [None if x < 0 else int(x) for x in g['k']]
     bin_score = float(g['bin_score']) if 'bin_score' in g else 1.0
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, **cfg_over)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=L, seed=seed, bin_score=bin_score))
     net = net.double().eval().to(DEV)
     data = synth.make_batch(B, n, m, first_pair=first_pair, device=DEV)
@@ -160,7 +160,7 @@ def test_dataparallel_dropin_like_test_py(golden_dir):
 
 def test_empty_keypoints_and_errors(golden_dir):
     g = _g(golden_dir, 'edge_cases')
-    net = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=5))
+    net = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=5)).double()
     net.load_state_dict(synth.make_state_dict(L=1, seed=3))
     net = net.double().eval().to(DEV)
     data = synth.make_batch(1, 8, 8, device=DEV)
@@ -172,21 +172,21 @@ def test_empty_keypoints_and_errors(golden_dir):
         assert tuple(out[a].shape) == g[b].shape
         np.testing.assert_array_equal(out[a].cpu().numpy(), g[b])
     # k larger than the number of keypoints raises like torch.topk does in the reference
-    net2 = MDGAT(synth.default_config(L=1, k=[16, None], sinkhorn_iterations=5))
+    net2 = MDGAT(synth.default_config(L=1, k=[16, None], sinkhorn_iterations=5)).double()
     net2.load_state_dict(synth.make_state_dict(L=1, seed=3))
     net2 = net2.eval().to(DEV)
     with pytest.raises(RuntimeError, match='exceeds the number of keys'):
         net2(synth.make_batch(1, 8, 8, device=DEV))
     # k == M behaves as full attention
     data = synth.make_batch(1, 32, 32, device=DEV)
-    net3 = MDGAT(synth.default_config(L=1, k=[32, 32], sinkhorn_iterations=10))
+    net3 = MDGAT(synth.default_config(L=1, k=[32, 32], sinkhorn_iterations=10)).double()
     net3.load_state_dict(synth.make_state_dict(L=1, seed=3))
     net3 = net3.eval().to(DEV)
     Z = net3.match(data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'],
                    data['scores0'], data['scores1'], return_scores=True)[4]
     assert np.abs(Z.cpu().double().numpy() - g['keqM_Z_dyn']).max() < Z_TOL
     # all-dustbin frame
-    net4 = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=10))
+    net4 = MDGAT(synth.default_config(L=1, k=[], sinkhorn_iterations=10)).double()
     net4.load_state_dict(synth.make_state_dict(L=1, seed=3, bin_score=50.0))
     net4 = net4.eval().to(DEV)
     out = net4(data)
@@ -197,7 +197,7 @@ def test_empty_keypoints_and_errors(golden_dir):
 def test_bench_shape_properties():
     """Full BASELINE size (B=64, N=M=512, L=9, S=100): properties that need no CPU oracle."""
     B, n, L = 64, 512, 9
-    net = MDGAT(synth.default_config(L=L))
+    net = MDGAT(synth.default_config(L=L)).double()
     net.load_state_dict(synth.make_state_dict(L=L, seed=0))
     net = net.eval().to(DEV)
     data = synth.make_batch(B, n, n, device=DEV, dtype=torch.float32)
@@ -238,7 +238,7 @@ def test_full_attention_configs_strict(n, L, S):
     fp32 pipeline must stay within 1e-4 of the fp64 oracle on Z at the BASELINE shapes, matches identical."""
     cfg = synth.default_config(L=L, k=[], sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=0)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     data = synth.make_batch(1, n, n, first_pair=3)
@@ -262,7 +262,7 @@ def test_configs3_per_gpu_workload():
     B, n, L, S = 512, 512, 9, 100
     cfg = synth.default_config(L=L, sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=0)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.eval().to(DEV)
     data = synth.make_batch(B, n, n, device=DEV, dtype=torch.float32)
@@ -302,7 +302,7 @@ def test_f16_attention_mode_configs2():
     d = {k: v.to(DEV) for k, v in data.items()}
     out = {}
     for dt in ('fp32', 'f16'):
-        net = MDGAT(dict(cfg, attention_dtype=dt))
+        net = MDGAT(dict(cfg, attention_dtype=dt)).double()
         net.load_state_dict(sd)
         net = net.double().eval().to(DEV)
         out[dt] = net.match(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'],
@@ -352,7 +352,7 @@ def test_large_frames(n, m, L, S, k):
     inputs: 1e-4 on Z and identical matches, for dynamic configurations in the attributed form of parity_util.py."""
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=0)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     data = synth.make_batch(1, n, m, first_pair=1)
@@ -380,7 +380,7 @@ def test_ragged_shapes_vs_oracle(B, n, m, k):
     L = 2
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=15)
     sd = synth.make_state_dict(L=L, seed=3)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     data = synth.make_batch(B, n, m, first_pair=2)
@@ -404,7 +404,7 @@ def test_forward_falls_back_when_sinkhorn_loses_a_partner(monkeypatch):
     from the streaming kernel's Z inside the same call - with and without a Z requested, sliced batches included - are
     identical to the normal path's, the handle reports the fallback as information and stays usable."""
     cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=40)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=5))
     net = net.eval().to(DEV)
     d = synth.make_batch(100, 512, 512, device=DEV, dtype=torch.float32)          # 100 pairs: two slices of 50
@@ -439,7 +439,7 @@ def test_two_streams_run_forwards_concurrently():
     partners): both must return what they return alone, bit for bit - finite, oracle-consistent (the serial results are
     held to the oracle by the tests above) - whichever path the Sinkhorn launches took."""
     L = 9
-    net = MDGAT(synth.default_config(L=L))
+    net = MDGAT(synth.default_config(L=L)).double()
     net.load_state_dict(synth.make_state_dict(L=L, seed=0))
     net = net.eval().to(DEV)
     batches = [synth.make_batch(64, 512, 512, first_pair=64 * i, device=DEV, dtype=torch.float32) for i in range(2)]
@@ -479,7 +479,7 @@ def test_f16_operand_range_is_guarded():
                         ('gnn.layers.0.attn.proj.0.weight', 1e5)):
         sd = synth.make_state_dict(L=L, seed=1)
         sd[key] = sd[key] * factor
-        net = MDGAT(cfg)
+        net = MDGAT(cfg).double()
         net.load_state_dict(sd)
         net = net.double().eval().to(DEV)
         with pytest.raises(RuntimeError, match='f16 operand range'):
@@ -494,7 +494,7 @@ def test_f16_operand_range_is_guarded():
             net.match(*args)                                 # ... or the next call on the handle finds it
         net.check(DEV)                                       # (reported once: the status is clear again)
     sd = synth.make_state_dict(L=L, seed=1)                  # the unscaled weights pass
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     with torch.no_grad():
@@ -506,7 +506,7 @@ def test_deepcopy_of_a_running_module():
     """copy.deepcopy of a module that has already run: the copy builds its own library handle on first use and gives the
     same bits; the original keeps working and both can be freed independently."""
     import copy
-    net = MDGAT(synth.default_config(L=2, k=[16, None, 8, None], sinkhorn_iterations=10))
+    net = MDGAT(synth.default_config(L=2, k=[16, None, 8, None], sinkhorn_iterations=10)).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=1))
     net = net.eval().to(DEV)
     d = synth.make_batch(2, 64, 48, device=DEV, dtype=torch.float32)
@@ -539,7 +539,7 @@ def test_repeatable_bitwise():
     """Same inputs, same outputs, bit for bit: the cross-workgroup sums of the Sinkhorn kernel are taken in a fixed
     order and nothing else in the path depends on scheduling."""
     cfg = synth.default_config(L=3, k=[64, None, 32, None, None, None], sinkhorn_iterations=50)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=3, seed=5))
     net = net.eval().to(DEV)
     d = synth.make_batch(9, 512, 512, device=DEV, dtype=torch.float32)
@@ -558,7 +558,7 @@ def test_large_batch_runs_in_slices(bin_score):
     batch-wide rule of the reference (mdgat.py:465-467: no frame-0 keypoint matched anywhere -> all scores zero; bin_score 60
     sends every keypoint to the dustbin)."""
     B, n = 130, 512
-    net = MDGAT(synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10))
+    net = MDGAT(synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10)).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=5, bin_score=bin_score))
     net = net.to(DEV).eval()
     data = synth.make_batch(B, n, n, device=DEV)
@@ -582,7 +582,7 @@ def test_two_lanes_equal_one_lane(B, n, m, bin_score):
     ragged slice sizes, the batch-wide all-dustbin rule (mdgat.py:465-467; bin score 60) - and the call stays ordered on the
     caller's stream: the outputs are read right behind it, and a second call reuses both workspaces."""
     cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=5, bin_score=bin_score))
     net = net.to(DEV).eval()
     data = synth.make_batch(B, n, m, device=DEV, dtype=torch.float32)
@@ -618,7 +618,7 @@ def test_forward_is_capturable_as_a_hip_graph():
     stream therefore takes in both lanes.  torch.cuda.CUDAGraph (= hipGraph on ROCm) of a B = 64 forward replays to the
     bits of the eager call, also after the inputs have changed in place."""
     cfg = synth.default_config(L=2, k=[128, None, 64, None], sinkhorn_iterations=10)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=5))
     net = net.to(DEV).eval()
     d = synth.make_batch(64, 512, 512, device=DEV, dtype=torch.float32)
@@ -656,7 +656,7 @@ def test_match_frames_raw_records():
     L, S, B, n, m = 2, 20, 2, 200, 168
     cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=S)
     sd = synth.make_state_dict(L=L, seed=2)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to(DEV)
     rs = np.random.RandomState(11)
@@ -687,7 +687,7 @@ def test_match_frames_vs_reference_loader_outputs(golden_dir):
     g = np.load(os.path.join(golden_dir, 'aux_loader.npz'))
     L = 2
     cfg = synth.default_config(L=L, k=[32, None, 16, None], sinkhorn_iterations=20)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=L, seed=4))
     net = net.double().eval().to(DEV)
     for j in range(int(g['n_items'])):
@@ -708,7 +708,7 @@ def test_replicas_made_by_torch_replicate(golden_dir):
     g = _g(golden_dir, 'fwd_n64_L4_S20')
     B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
     k = [None if x < 0 else int(x) for x in g['k']]
-    net = MDGAT(synth.default_config(L=L, k=k, sinkhorn_iterations=S))
+    net = MDGAT(synth.default_config(L=L, k=k, sinkhorn_iterations=S)).double()
     net.load_state_dict(synth.make_state_dict(L=L, seed=seed))
     net = net.double().eval().to(DEV)
     data = synth.make_batch(B, n, m, first_pair=first_pair, device=DEV)
@@ -728,7 +728,7 @@ def test_load_packed_blob_on_device():
     after the net.double().eval() of test.py:193."""
     L = 3
     cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=30)
-    src = MDGAT(cfg)
+    src = MDGAT(cfg).double()
     src.load_state_dict(synth.make_state_dict(L=L, seed=7))
     src = src.eval().to(DEV)
     d = synth.make_batch(3, 200, 256, device=DEV, dtype=torch.float32)
@@ -769,3 +769,32 @@ def test_bench_two_ranks_one_gpu():
     assert d['config']['pairs_per_gpu'] == 8 and '2-way' in d['config']['parallelism']
     assert abs(d['value'] - 2 * 8 * 5 / (d['ms_per_step'] * 5e-3)) < 1e-6 * d['value']
     assert 'cpu_baseline' not in d                      # rank 0 at N = 1 only
+
+
+@pytest.mark.parametrize('n,m,L,S,k,B', [(512, 512, 9, 100, None, 6), (256, 256, 4, 20, None, 8), (300, 420, 3, 20, [64, 32, 100, None, 17, 48], 4),
+                                         (1024, 640, 2, 20, [128, 64, None, 256], 2)])
+def test_exact_topk_selects_like_fp64_on_the_same_layer_input(n, m, L, S, k, B):
+    """mdgat_config.exact_topk (csrc/repair.hip): `logits.topk(k)` (mdgat.py:202) must select what fp64 arithmetic selects
+    on the layer's OWN input - no flip may be caused inside a dynamic layer any more (what remains against the reference are
+    flips that arrive with the layer input).  Covers the three dynamic kernels (512 keys, generic, split-key) and a dynamic
+    CROSS layer; with the re-decision off the same pairs do show in-layer flips at these sizes (printed, not asserted)."""
+    cfg = synth.default_config(L=L, sinkhorn_iterations=S, **({} if k is None else {'k': k}))
+    sd = synth.make_state_dict(L=L, seed=0)
+    data = synth.make_batch(B, n, m, first_pair=300)
+    res = {}
+    for exact in (True, False):
+        net = MDGAT({**cfg, 'exact_topk': exact}).double()
+        net.load_state_dict(sd)
+        net = net.double().eval().to(DEV)
+        flips, stats = local_flips(net, sd, data, with_stats=True)
+        res[exact] = (sum(flips.values()), stats.sum(0).tolist())
+    print(f'[exact_topk] N={n} M={m} L={L} B={B}: in-layer flips with / without the re-decision {res[True][0]} / {res[False][0]}; '
+          f'near-threshold rows examined {res[True][1][0]}, rewritten {res[True][1][1]}, selection changed {res[True][1][2]}, '
+          f'given up {res[True][1][3]}')
+    assert res[True][0] == 0, res
+    assert res[False][1] == [0, 0, 0, 0]                  # switched off: nothing is examined
+    examined, rewritten, changed, given_up = res[True][1]
+    assert examined > 0 and rewritten <= examined and changed <= rewritten and given_up == 0
+    # ~1-2 rows in 10^3 are listed, a fraction of them rewritten: the re-decision must stay a rare path
+    rows = sum(B * 4 * (n + m) for kk in net._topk_schedule() if kk > 0)
+    assert examined < 0.01 * rows, (examined, rows)

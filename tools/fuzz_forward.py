@@ -37,7 +37,7 @@ def one_case(rs):
     wseed, fp = int(rs.randint(100)), int(rs.randint(1000))
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual)
     sd = synth.make_state_dict(L=L, seed=wseed, bin_score=bin_score)
-    net = MDGAT(cfg)
+    net = MDGAT(cfg).double()
     net.load_state_dict(sd)
     net = net.double().eval().to('cuda:0')
     data = synth.make_batch(B, N, M, first_pair=fp)

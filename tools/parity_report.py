@@ -11,7 +11,10 @@ Round 3 adds the CAUSE of the flips: the HIP path's own fp32 descriptors enterin
 an fp64 q/k projection and an fp64 q.k - the selection that exact arithmetic makes of the HIP path's INPUT.  Rows where
 the HIP selection differs from that one are caused inside the layer (projection + split-f16 q.k products, what an fp64
 re-evaluation of the near-threshold logits could repair); the remaining flips against the fp64 trajectory come with the
-input (error accumulated by the layers before) and no local re-evaluation reaches them."""
+input (error accumulated by the layers before) and no local re-evaluation reaches them.
+
+Round 4: the library re-decides near-threshold rows itself (mdgat_config.exact_topk, csrc/repair.hip): "caused inside the
+layer" must then be 0, and the report prints the repair counters.  MDGAT_TOPK_REPAIR=0 reproduces the round-3 numbers."""
 import os
 import sys
 import time
@@ -23,7 +26,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
-from parity_util import attributed_parity  # noqa: E402
+from parity_util import attributed_parity, local_flips  # noqa: E402
 
 
 def fp32_flips(sd, cfg, data, own64):
@@ -39,41 +42,6 @@ def fp32_flips(sd, cfg, data, own64):
     return rows, cap['Z'].double()
 
 
-def local_flips(net, sd, data, L):
-    """{dynamic layer: rows whose HIP selection differs from the fp64 top-k of the HIP path's OWN fp32 layer input}."""
-    from mdgat_matcher_amd import ops
-    dev = {k: v.to('cuda:0') for k, v in data.items()}
-    k0 = dev['keypoints0']
-    B, N, M = k0.shape[0], k0.shape[1], dev['keypoints1'].shape[1]
-    sched = net._topk_schedule()
-    words = ops.topk_sel_words(B, N, M)
-    sel = torch.zeros(len(sched) * words, dtype=torch.int32, device=k0.device)
-    xl = torch.empty(2 * L, B, N + M, 128, device=k0.device)
-    xe = torch.empty(B, N + M, 128, device=k0.device)
-    net._run(k0, dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=False,
-             taps={'topk_sel': sel, 'x_layers': xl, 'x_enc': xe})
-    torch.cuda.synchronize()
-    xl = torch.cat([xl, xe[None]]).cpu().double()          # index -1 = the encoder output = the input of layer 0
-    out = {}
-    for i, kk in enumerate(sched):
-        if kk <= 0:
-            continue
-        masks = ops.topk_sel_to_masks(sel[i * words:(i + 1) * words], B, N, M, cross=bool(i & 1))
-        rows = 0
-        for side in range(2):
-            x = (xl[i - 1][:, :N] if side == 0 else xl[i - 1][:, N:]).transpose(1, 2)      # [B, 128, n]: the HIP path's input
-            other = (xl[i - 1][:, N:] if side == 0 else xl[i - 1][:, :N]).transpose(1, 2)
-            src = other if (i & 1) else x
-            p = f'gnn.layers.{i}.attn'
-            q = O._pointwise(sd[f'{p}.proj.0.weight'], sd[f'{p}.proj.0.bias'], x).view(B, 32, 4, -1)
-            kk_ = O._pointwise(sd[f'{p}.proj.1.weight'], sd[f'{p}.proj.1.bias'], src).view(B, 32, 4, -1)
-            logits = torch.einsum('bdhn,bdhm->bhnm', q, kk_) / 32 ** 0.5
-            own = torch.zeros_like(logits, dtype=torch.bool).scatter_(3, logits.topk(kk, dim=3).indices, True)
-            rows += int((own ^ masks[side].cpu()).any(-1).sum())
-        out[i] = rows
-    return out
-
-
 def main():
     torch.set_num_threads(synth.effective_cpu_count())
     counts = [int(x) for x in sys.argv[1:4]] + [8, 8, 1][len(sys.argv[1:4]):]
@@ -83,10 +51,11 @@ def main():
     for name, n, L, S, pairs in configs:
         cfg = synth.default_config(L=L, sinkhorn_iterations=S)
         sd = synth.make_state_dict(L=L, seed=0)
-        net = MDGAT(cfg)
+        net = MDGAT(cfg).double()
         net.load_state_dict(sd)
         net = net.double().eval().to('cuda:0')
         tot_rows = tot_flip = tot_flip32 = tot_local = literal = would_pass = 0
+        tot_stats = [0, 0, 0, 0]
         worst = worst_gap = worst_plain = worst32 = 0.0
         all_equal = True
         t0 = time.time()
@@ -100,7 +69,11 @@ def main():
             mm = int((r['out'][0].cpu() != ref['matches0']).sum() + (r['out'][1].cpu() != ref['matches1']).sum())
             f32rows, Z32 = fp32_flips(sd, cfg, data, own64) if n <= 512 else (-1, None)
             e32 = (Z32 - cap['Z']).abs().max().item() if Z32 is not None else float('nan')
-            loc = sum(local_flips(net, sd, data, L).values()) if n <= 512 else -1
+            loc, rstats = local_flips(net, sd, data, with_stats=True)
+            loc = sum(loc.values())
+            rs = rstats.sum(0).tolist()
+            for j in range(4):
+                tot_stats[j] += rs[j]
             tot_local += max(loc, 0)
             literal += plain < 1e-4
             # a pair whose flips are ALL caused inside their layer would meet the literal bar if the near-threshold logits
@@ -109,7 +82,8 @@ def main():
             print(f'{name} pair {100 + p}: forced-selection max|dZ| {r["errZ"]:.2e} matches identical {r["matches_equal"]} | '
                   f'rows differing {r["flip_rows"]}/{r["topk_rows"]} max gap {r["max_gap"]:.2e} kept!=k {r["bad_count"]} | '
                   f'vs plain fp64 oracle: max|dZ| {plain:.2e}, matches differing {mm} | fp32 PyTorch: rows differing {f32rows}, max|dZ| {e32:.2e} | '
-                  f'rows differing from the fp64 selection of the HIP path\'s own layer input (caused inside the layer): {loc}')
+                  f'rows differing from the fp64 selection of the HIP path\'s own layer input (caused inside the layer): {loc} | '
+                  f'exact re-decision: near-threshold rows examined {rs[0]}, rewritten {rs[1]}, selection changed {rs[2]}, given up {rs[3]}')
             tot_rows += r['topk_rows']; tot_flip += r['flip_rows']; tot_flip32 += max(f32rows, 0)
             worst = max(worst, r['errZ']); worst_gap = max(worst_gap, r['max_gap']); worst_plain = max(worst_plain, plain)
             worst32 = max(worst32, e32 if e32 == e32 else 0.0)
@@ -121,7 +95,8 @@ def main():
               f'pairs within the LITERAL 1e-4 against the plain fp64 oracle: {literal}/{pairs}; flips caused inside the dynamic layer '
               f'(q/k projection + q.k products, given the HIP input): {tot_local} of {tot_flip} - the rest arrives with the layer input; '
               f'pairs that WOULD meet the literal bar with an exact re-evaluation of near-threshold logits inside the layer (upper bound: '
-              f'every in-layer flip repaired, none created): {would_pass}/{pairs}')
+              f'every in-layer flip repaired, none created): {would_pass}/{pairs}; exact re-decision (mdgat_config.exact_topk): near-threshold '
+              f'rows examined {tot_stats[0]}, rewritten {tot_stats[1]}, selection changed {tot_stats[2]}, given up {tot_stats[3]}')
 
 
 if __name__ == '__main__':
