@@ -36,7 +36,12 @@ import os
 import sys
 import time
 
-import torch
+# RCCL on this pool's hosts shares device memory between the ranks of a node through dmabuf only: without this variable
+# communicator set-up fails with `hipIpcGetMemHandle: invalid argument`.  It has to be in the environment before the HIP
+# runtime is loaded, and a driver that launches this file with torch.distributed.run may not have exported it.
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -55,6 +60,7 @@ CONFIGS = {
 PEAK_F16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: dense f16/bf16 MFMA peak
 SPLIT_FACTOR = 3.0               # f16 MFMAs executed per fp32-equivalent product (hi.hi, hi.lo, lo.hi)
 PEAK_HBM_GBS = 8000.0
+PEAK_VECTOR_F32_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector (= fp32 matrix) peak
 # HBM traffic per launch is not measurable from inside the process: it comes from the rocprofv3 PMC passes of this same
 # command committed under profiles/ (tools/profile_round.sh; 2 x FETCH_SIZE - gfx950 under-reports wide streaming reads
 # by 2x, MI355X_MICROARCH.md - + WRITE_SIZE).  profiles/pmc_traffic.json: {config: {kernel class: [bytes, source file]}}
@@ -74,8 +80,11 @@ def class_work(B, n, L, S):
         'attention_full': {'flops': att},
         'attention_topk': {'flops': att},
         'scores': {'flops': B * 2.0 * n * n * 128},
-        # log-domain Sinkhorn: 2 x S element visits of the (n+1)^2 matrix, 4 bytes each if it were streamed
-        'sinkhorn': {'bytes': B * 4.0 * (2.0 * S * (n + 1) * (n + 1))},
+        # Sinkhorn (scaling form, the coupling block register-resident for all S iterations): HBM traffic = the scores read once
+        # + what the extraction needs = the on-chip-resident form of SURVEY 8d, 2 (n+1)^2 4 B per pair; the arithmetic is
+        # 2 x S visits of the (n+1)^2 block, one FMA (2 FLOP) each, on the VECTOR pipe (no matrix-core work by nature)
+        'sinkhorn': {'bytes': B * 4.0 * 2.0 * (n + 1) * (n + 1), 'vector_flops': B * 2.0 * (2.0 * S * (n + 1) * (n + 1)),
+                     'streamed_bytes': B * 4.0 * (2.0 * S * (n + 1) * (n + 1))},
         'extract': {'bytes': B * 4.0 * (n + 1) * (n + 1)},
     }
 
@@ -188,6 +197,8 @@ def main():
                     help='the timed window of --steps steps is repeated this many times; value = the median window')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
+    ap.add_argument('--no-dict-api', action='store_true', help='skip the forward(dict) throughput leg')
+    ap.add_argument('--exact-topk', action='store_true', help='mdgat_config.exact_topk (exact re-decision of near-threshold top-k rows)')
     args = ap.parse_args()
 
     c = CONFIGS[args.config]
@@ -196,11 +207,22 @@ def main():
     att = args.attention_dtype or c['att']
 
     rank, world, local = shard.init_distributed(args.gpus)
-    dev = torch.device('cuda', local)
-    torch.cuda.set_device(dev)
+    # tests/bench_stub_runner.py (CPU, no GPU in the build container) replaces MDGAT._run by a recorder to drive THIS file's
+    # multi-rank control flow under gloo; it says so in the environment and the line it prints carries "stub": true.
+    stub = os.environ.get('MDGAT_BENCH_STUB') == '1' and not torch.cuda.is_available()
+    if not torch.cuda.is_available() and not stub:
+        raise SystemExit('bench.py measures the HIP path on an MI355X: no GPU is visible (there is no CPU fallback)')
+    dev = torch.device('cpu') if stub else torch.device('cuda', local)
+    if not stub:
+        torch.cuda.set_device(dev)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     cfg = synth.default_config(L=L, sinkhorn_iterations=S)
     cfg['attention_dtype'] = att
+    cfg['exact_topk'] = bool(args.exact_topk)
     net = MDGAT(cfg).eval()
     if rank == 0:
         net.load_state_dict(synth.make_state_dict(L=L, seed=0, dtype=torch.float32))
@@ -218,23 +240,32 @@ def main():
         # meet a one-off runtime stall (one early step of 25-80 ms, usually the 3rd or 4th: tools/step_times.py)
         for _ in range(8):
             step()
-        torch.cuda.synchronize()
+        sync()
         for _ in range(args.warmup):
             step()
         # EXACTLY --steps steps between barrier + synchronize on both sides, max over ranks: one window.  A window at
         # B = 64 is 20 x 3.3 ms = 67 ms - a single sample on a box whose clocks move - so the window is repeated and the
         # MEDIAN window is reported (all windows are listed in the line).
-        windows = []
+        windows, own_windows = [], []
         for _ in range(max(1, args.windows)):
             shard.barrier(world)
-            torch.cuda.synchronize()
+            sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step()
-            torch.cuda.synchronize()
+            sync()
+            own = time.perf_counter() - t0          # this rank's own time for the window (before it waits for the others)
             shard.barrier(world)
             windows.append(shard.max_over_ranks(time.perf_counter() - t0, dev, world))
+            own_windows.append(own)
     dt = sorted(windows)[len(windows) // 2]
+    # every rank's pair count and own time per step (median window), gathered on all ranks: a straggler shows in the line,
+    # and the partition must add up to the job
+    mine = torch.tensor([float(count), 1e3 * sorted(own_windows)[len(own_windows) // 2] / args.steps], dtype=torch.float64)
+    per_rank = shard.gather_matches(mine[None].to(dev if not stub else 'cpu'), world).cpu()
+    assert int(per_rank[:, 0].sum()) == B * world, (per_rank[:, 0].tolist(), B, world)
+    # asynchronous status of the forwards timed above: an f16 range violation raises here (the outputs would be invalid)
+    status = {'sinkhorn_fallback': False} if stub else net.check(dev)
 
     if rank == 0:
         pairs = B * world * args.steps
@@ -259,10 +290,35 @@ def main():
                                    f' (BASELINE.json {c["name"]}' + ('' if B == c['B'] else f' at batch {B}') + ')',
                        'baseline_config': args.config, 'pairs_per_gpu': B, 'keypoints': n, 'L': L, 'sinkhorn_iterations': S,
                        'parallelism': f'pairs sharded {world}-way, no data-path collective',
-                       'collectives': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none'},
+                       'collectives': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none',
+                       # what the communicator saw (RCCL when collectives == 'nccl'): must equal n_gpus
+                       'rccl_world_size': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
+                       'pairs_per_rank': [int(v) for v in per_rank[:, 0].tolist()],
+                       'exact_topk': bool(net.exact_topk)},
             'timing': {'windows': len(windows), 'value_is': 'median window', 'window_ms': [round(1e3 * w, 3) for w in windows],
-                       'best_pairs_per_s': pairs / min(windows), 'worst_pairs_per_s': pairs / max(windows)},
+                       'best_pairs_per_s': pairs / min(windows), 'worst_pairs_per_s': pairs / max(windows),
+                       'per_rank_ms_per_step': [round(v, 4) for v in per_rank[:, 1].tolist()]},
+            # mdgat_async_status after the timed windows (the timed step is the asynchronous MDGAT._run)
+            'status': {'sinkhorn_fallback': bool(status['sinkhorn_fallback']), 'range_violation': False},
         }
+        if stub:
+            out['stub'] = True
+            args.no_breakdown = args.no_cpu_baseline = True
+        elif not args.no_dict_api:
+            # the reference's dict API on the same batch: forward(dict) -> dict, which synchronises (the host-side test of
+            # mdgat.py:465 and the status check) - what a caller of test.py:201 gets per call
+            ddata = {k: v for k, v in data.items()}
+            with torch.no_grad():
+                for _ in range(3):
+                    net(ddata)
+                sync()
+                k_steps = max(5, min(args.steps, 30))
+                t0 = time.perf_counter()
+                for _ in range(k_steps):
+                    net(ddata)
+                sync()
+                out['dict_api'] = {'pairs_per_s': B * k_steps / (time.perf_counter() - t0), 'steps': k_steps, 'n_gpus': 1,
+                                   'note': 'rank 0 only: net(dict) as test.py:201 calls it - one host synchronisation per call'}
         if not args.no_breakdown:
             rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
             nsl = next((r['launches_per_step'] for r in rows if r['kernel'] == 'sinkhorn'), 1)
@@ -292,7 +348,14 @@ def main():
                     roof = {'kernel': dom['kernel'], 'bound': 'hbm', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                             'frac': ach / PEAK_HBM_GBS, 'traffic': traffic, 'traffic_source': source, 'avg_launch_ms': dom['ms'],
                             'bytes_per_launch': dom['bytes'],
-                            'note': 'bytes = the streamed-form algorithmic traffic 2 S (n+1)^2 4 B per pair (SURVEY 8d)'}
+                            'note': 'bytes = the on-chip-resident algorithmic traffic 2 (n+1)^2 4 B per pair (SURVEY 8d): the kernel keeps '
+                                    'the coupling block in registers for all iterations, so it is bound by neither HBM nor the matrix '
+                                    'cores but by vector issue and the partner hand-off latency - see `vector`'}
+                    if 'vector_flops' in dom:
+                        v = dom['vector_flops'] / (dom['ms'] * 1e-3) / 1e12
+                        roof['vector'] = {'achieved': v, 'peak': PEAK_VECTOR_F32_TFLOPS, 'unit': 'TFLOP/s', 'frac': v / PEAK_VECTOR_F32_TFLOPS,
+                                          'flops_per_launch': dom['vector_flops'],
+                                          'note': '2 S (n+1)^2 FMAs per pair on the vector pipe against the fp32 vector peak'}
                 if roof['bound'] == 'mfma':
                     # the ceiling that exists on this box: the matrix cores under nothing but MFMAs on random operands (the chip
                     # clocks to its power budget: ~1.6 instead of 2.4 GHz on this pool), measured live (mdgat_mfma_probe)

@@ -14,7 +14,12 @@
  *   - all tensors are owned by the caller (PyTorch); the library keeps only its packed weights;
  *   - every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - return 0 on success, a negative mdgat_status otherwise; mdgat_last_error() gives the text;
- *   - a handle is bound to one device and is not re-entrant (the Python wrapper serialises calls).
+ *   - a handle is bound to one device.  Thread safety: mdgat_forward / mdgat_forward_frames on ONE handle may be called from
+ *     several host threads (and streams) - the library serialises the enqueue of a call internally (a mutex in the handle: the
+ *     second lane's stream, its fork / join events and the profiling state are per handle); the device work of calls issued on
+ *     different streams overlaps as far as those streams allow, but the halves that run on the handle's second lane queue on
+ *     that one stream in call order.  Each call needs its own workspace while it is in flight.  mdgat_set_lanes,
+ *     mdgat_load_weights, mdgat_profile and mdgat_destroy must not race with a forward on the same handle.
  *
  * Layouts (fp32, row-major, innermost last)
  *   keypoints  kpts  [B][N][3]      saliency sigma [B][N]      FPFH fpfh [B][N][33]
@@ -71,12 +76,17 @@ typedef struct {
     int32_t extract_mode;              /* mdgat_extract_mode */
     float match_threshold;             /* config['match_threshold'] (322) */
     int32_t attention_mode;            /* mdgat_attention_mode; not a reference key (BASELINE configs[2]) */
-    int32_t exact_topk;                /* != 0 (the Python side's default): rows of a dynamic layer whose k-th and (k+1)-th largest
-                                          logit are closer than the fp32-class arithmetic of the attention kernels resolves are
-                                          re-decided from an fp64 evaluation of those logits (q / k re-projected from the layer's
-                                          input with the fp64 weights), so that `logits.topk(k)` (mdgat.py:202) selects what exact
-                                          arithmetic selects on the same layer input.  Not a reference key (the reference IS fp64);
-                                          fp32 attention mode only; MDGAT_TOPK_REPAIR=0 in the environment switches it off. */
+    int32_t exact_topk;                /* != 0: rows of a dynamic layer whose k-th and (k+1)-th largest logit are closer than the
+                                          fp32-class arithmetic of the attention kernels resolves (or exactly tied) are re-decided
+                                          from an fp64 evaluation of those logits (q / k re-projected from the layer's input with
+                                          the fp64 weights; csrc/repair.hip: one more small launch per dynamic layer), so that
+                                          `logits.topk(k)` (mdgat.py:202) selects what exact arithmetic selects on the same layer
+                                          input.  Not a reference key (the reference IS fp64); fp32 attention mode only;
+                                          MDGAT_TOPK_REPAIR=0 / 1 in the environment overrides it.  Default of the Python side: 0 -
+                                          it removes the flips a layer causes itself but not those that arrive with its input
+                                          (the accumulated fp32-class error of the layers before), which dominate: the number
+                                          of rows selected differently from the fp64 reference does not change
+                                          (profiles/parity_r4.txt), at 3-6 % of the step. */
 } mdgat_config;
 
 typedef struct mdgat_handle mdgat_handle;
@@ -93,8 +103,8 @@ typedef struct {
                            left untouched.  Parity tests feed this selection to the oracle to separate near-tie flips of
                            the discontinuous top-k from arithmetic error. */
     int32_t* repair_stats; /* [2L][4], zeroed by the caller: per dynamic layer the near-threshold rows examined by the exact
-                              re-decision (mdgat_config.exact_topk), rewritten, rewritten with a selection other than the one
-                              the fp32-class logits give, and given up (more than 32 candidates: masses of equal logits) */
+                              re-decision (mdgat_config.exact_topk), corrected (exact arithmetic keeps other keys than the
+                              attention kernel did), unused, and given up (more than 16 candidates: masses of equal logits) */
 } mdgat_taps;
 size_t mdgat_topk_sel_words(int B, int N, int M);
 

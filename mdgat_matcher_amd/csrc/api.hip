@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -61,7 +62,7 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
-    bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk, fp32 attention mode, not MDGAT_TOPK_REPAIR=0
+    bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk (or MDGAT_TOPK_REPAIR in the environment), fp32 attention mode
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard
     // Two lanes (forward_batched): the second lane's stream and the events that fork it off the caller's stream and join it again
     int lanes;            // 1 or 2 (mdgat_set_lanes; default 2, MDGAT_FORWARD_LANES)
@@ -72,6 +73,11 @@ struct mdgat_handle {
     struct ProfLane { std::vector<hipEvent_t> ev; std::vector<int> cls; size_t n = 0; } prof[2];
     double prof_ms[MDGAT_PROF_CLASSES];
     long long prof_launches[MDGAT_PROF_CLASSES];
+    // One forward at a time per handle: the fork / join events, the second lane's stream and the profiling event lists are
+    // per-handle state.  Two host threads calling mdgat_forward on one handle from two streams are serialised HERE (the enqueue
+    // only - microseconds; the device work of the two calls still overlaps as far as their streams allow), so that one call's
+    // lane can never fork off the other call's event record.  (The Python wrapper holds its own lock as well.)
+    std::mutex enqueue;
 };
 
 // split-weight buffer: per layer the LDS images of layer.hip [w1 256 rows x 528 | w2 128 x 528 | qkv 384 x 272]
@@ -104,8 +110,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->wsplit = nullptr;
     h->loaded = false;
     {
-        const char* e = getenv("MDGAT_TOPK_REPAIR");
-        h->repair = cfg->exact_topk != 0 && cfg->attention_mode == MDGAT_ATTENTION_FP32 && !(e && atoi(e) == 0);
+        const char* e = getenv("MDGAT_TOPK_REPAIR");      // (measurements: 0 / 1 override the configuration)
+        h->repair = (e ? atoi(e) != 0 : cfg->exact_topk != 0) && cfg->attention_mode == MDGAT_ATTENTION_FP32;
     }
     h->host_error = nullptr;
     h->prof_on = false;
@@ -361,7 +367,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->mdesc, mdesc, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap mdesc"))) return rc;
     // (the score kernel also clears the exchange slots of the Sinkhorn kernel that follows: no memset launch in between)
     const size_t sk_clear = ws.sk_bytes ? sinkhorn_slots_clear_bytes(B, N, M) : 0;
-    if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s, sk_clear ? ws.sk : nullptr, sk_clear))) return rc;
+    if ((rc = launch_scores(B, N, M, mdesc, ws.scores, 0.08838834764831845f /* 1 / sqrt(128) */, s, sk_clear ? ws.sk : nullptr, sk_clear,
+                            status_dev + MDGAT_STATUS_RANGE))) return rc;
     mark(MDGAT_PROF_SCORES);
     if (taps && taps->scores)
         if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->scores, ws.scores, (size_t)B * N * M * sizeof(float), hipMemcpyDeviceToDevice, s), "tap scores"))) return rc;
@@ -462,7 +469,9 @@ static int forward_batched(mdgat_handle* h, int B, int N, int M, const float* kp
                            int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                            const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     LanePlan p{1, B, 1, 0};
-    if (h && !taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M);
+    if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
+    std::lock_guard<std::mutex> serialise(h->enqueue);
+    if (!taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M);
     if (p.nslices <= 1) {
         const int rc = forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
                                     mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);

@@ -48,8 +48,9 @@ struct AttnArgs {
     float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
     uint32_t* sel;         // TAP kernels only: [B][4][P][selW] bit j of word w = key 32 w + j of the source frame was kept
     int selW;
-    // near-threshold rows of a dynamic layer (repair.hip): a row whose largest DROPPED logit lies within near_eps() of the
-    // threshold is appended here and re-decided by topk_repair_kernel from an fp64 evaluation of the candidates
+    // near-threshold rows of a dynamic layer (repair.hip): a row whose (k + 1)-th largest logit lies within near_eps() of its
+    // threshold (or is tied with the k-th) is appended here and re-decided by topk_repair_kernel from an fp64 evaluation of
+    // the candidates; exact ties at the k-th place are then left to it
     int* near_count;       // NULL: no list
     RepairRec* near_recs;
     int near_cap;
@@ -408,8 +409,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
 // registers before the pass is (re)done, or - attention_topk16_kernel - its share is taken out of the written row again.
 // Key index (within the source frame) of S[jb][r] in this lane = lane_off + Layout::koff(jb, r), the second part a
 // compile-time constant.
-struct KeyLayout32 { static __device__ constexpr int koff(int jb, int r) { return jb * 32 + 16 * (r >> 3) + (r & 7); } };       // 32x32 S^T fragments
-struct KeyLayout16 { static __device__ constexpr int koff(int jb, int r) { return 16 * (4 * jb + (r >> 2)) + (r & 3); } };      // 16x16 S^T fragments
+// (KeyLayout32 / KeyLayout16: common.hpp)
 struct NoDropHook { __device__ __forceinline__ void operator()(int, bool) const {} };
 // SWEEP: write -inf over the dropped logits in the registers (the pass is then run on them).  on_drop(key, active) is
 // called once per dropped key and round (`active` = this lane's row drops `key` in this round).
@@ -610,7 +610,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                     WaveComm comm;
                     thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
                     thr_row = thr; m_row = m;
-                    if (TAP) {      // the TAP build counts first, so that the selection it records is final
+                    if (TAP && !a.near_count) {      // the TAP build counts first, so that the selection it records is final
                         int c = 0;
 #pragma unroll
                         for (int jb = 0; jb < NBLK; ++jb)
@@ -618,7 +618,9 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
                         surplus = comm.rsum(c) - kexp;
                     }
-                    if (redo || TAP) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, c0 * 32 + 8 * hi);
+                    // (with the near-threshold list on, exact ties at the k-th place are left to the re-decision of repair.hip:
+                    // the written row keeps every logit >= thr)
+                    if ((redo || TAP) && !a.near_count) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, c0 * 32 + 8 * hi);
                 }
                 if (TOPK && TAP && qw + l31 < nq) {
                     uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
@@ -683,7 +685,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                     // a row kept more than k logits (exact ties at the k-th place): redo the chunk - the whole row -
                     // once, with the tie-break (topk_break_ties)
                     { const int kc = kept_count(kept); surplus = kc + xor32i(kc) - kexp; }
-                    if (!redo && __any(surplus > 0)) {
+                    if (!redo && !a.near_count && __any(surplus > 0)) {
                         redo = true;
                         c0 -= NBLK;
                         m_run = NEG_INF;
@@ -841,12 +843,15 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         if (near_row && g == 0 && qw + l15 < nq) near_append(a, b, side, head, qw + l15, thr, m);      // -> repair list (rare)
         if (TAP) {
             // the selection the tap records is final: count and break exact ties at the k-th place before the pass
-            int c = 0;
+            // (left to the re-decision of repair.hip when the near-threshold list is on)
+            if (!a.near_count) {
+                int c = 0;
 #pragma unroll
-            for (int jb = 0; jb < 8; ++jb)
+                for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
-            topk_break_ties<KeyLayout16>(S, thr, comm.rsum(c) - a.topk, comm, 4 * g);
+                    for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
+                topk_break_ties<KeyLayout16>(S, thr, comm.rsum(c) - a.topk, comm, 4 * g);
+            }
             if (qw + l15 < nq) {
                 uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l15) * a.selW;
 #pragma unroll
@@ -933,7 +938,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // with the largest key indices are found one at a time and the share of each is taken out of the rows just
         // written:  o <- (o l - P' v) / (l - P'),  l <- l - P'.  (A second pass instead costs the launch 10 % at B = 64.)
         const int surplus = comm.rsum(kept_count(kept)) - a.topk;
-        if (comm.any(surplus > 0)) {
+        if (!a.near_count && comm.any(surplus > 0)) {
             load_q(qw, qh, ql);             // (the fragment registers may have been handed to the prefetch)
             logits(S);
             const float e = __builtin_amdgcn_exp2f(thr - m11);                  // P' of a tied logit, as softmax8 computes it
@@ -1114,7 +1119,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
-            topk_break_ties<KeyLayout32>(S, thr, comm.rsum(c) - kexp, comm, kw * NBLK * 32 + 8 * hi);
+            const int surplus = comm.rsum(c) - kexp;
+            if (!a.near_count) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, kw * NBLK * 32 + 8 * hi);    // (else: repair.hip)
         }
         if (TAP && qw + l31 < nq) {
             uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;

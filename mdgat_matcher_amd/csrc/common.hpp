@@ -40,6 +40,10 @@ __device__ __forceinline__ void mdgat_split_unscaled(float x, _Float16& h, _Floa
 // evaluation of the candidates (q / k re-projected from the fp32 descriptors with the fp64 weights) and rewrites the
 // row's message when a candidate straddles the threshold.
 struct RepairRec { int bsh; int q; float thr; float m; };   // ((pair * 2 + frame) * 4 + head), query row within its frame, threshold, row maximum
+// Key index (within the source frame) of logit register (jb, r) of a lane, relative to the lane's offset, in the S^T = K Q^T
+// fragments of the attention kernels (attention.hip) - repair.hip computes the same fragments again.
+struct KeyLayout32 { static __device__ constexpr int koff(int jb, int r) { return jb * 32 + 16 * (r >> 3) + (r & 7); } };       // 32x32 fragments, + 8 (lane >> 5)
+struct KeyLayout16 { static __device__ constexpr int koff(int jb, int r) { return 16 * (4 * jb + (r >> 2)) + (r & 3); } };      // 16x16 fragments, + 4 (lane >> 4)
 #ifdef __HIPCC__
 // base-2 logit units.  Error of a logit against exact arithmetic on the same layer input: rms 1.9e-6, max 1.4e-5 for
 // logits of standard deviation 2.8 (profiles/NOTES_r3.md), proportional to the logits' scale - (|m| + |thr|) / 10 is ~1 there.
@@ -103,7 +107,9 @@ int launch_gemm(const GemmArgs& a, hipStream_t s);
 // score matrix [B][N][M] = mdesc0 . mdesc1^T * scale from mdesc [B][N + M][128] (scores.hip)
 // zero / zero_bytes (optional, 16-byte granular): memory the kernel clears on the side - the forward hands it the exchange
 // slots of the Sinkhorn kernel that runs next (sinkhorn_slots_clear_bytes) instead of a memset launch
-int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
+// guard (optional, host-mapped): raised when an operand is outside the f16 operand range or not finite
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0,
+                  unsigned* guard = nullptr);
 
 // fused encoders (encoder.hip).  es = split weights [kenc.3 64x2x32 | kenc.6 128x2x64 | denc.0 64x2x48 | denc.3 128x2x64 |
 // last convs 128x2x256]; inputs either as separate arrays or as raw 37-float frame records
@@ -203,7 +209,7 @@ int launch_gt_match(int B, int N, int M, const float* kpts0, const float* kpts1,
 
 // out[b][i][j] = scale <A[b][i], Bm[b][j]> - col_bias[b][j] over 128 channels, split-f16 products (scores.hip)
 int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
-                const float* col_bias, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0);
+                const float* col_bias, hipStream_t s, void* zero = nullptr, size_t zero_bytes = 0, unsigned* guard = nullptr);
 int launch_knn(int B, int C, int N, int M, int k, const float* x, const float* src, int64_t* idx, int64_t* adj,
                void* ws, size_t ws_bytes, hipStream_t s);
 size_t mdgat_knn_ws_bytes_impl(int B, int C, int N, int M);

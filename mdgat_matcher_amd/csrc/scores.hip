@@ -21,6 +21,7 @@ struct ScoreArgs {
     f32x4* zero;              // optional: zero_n 16-byte units cleared on the side (the exchange slots of the Sinkhorn kernel that
     size_t zero_n;            // runs next: spares the forward a memset launch)
     int B, tx, ty;            // pairs; 128-wide tiles per pair along columns / rows
+    unsigned* guard;          // optional, host-mapped: set when an operand is outside the f16 operand range or not finite
 };
 
 // BIAS: subtract col_bias[b][j] (the kNN helper; kept out of the score-matrix instance, whose epilogue is store-bound)
@@ -49,6 +50,10 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     const float* Bm = a.Bm + (size_t)b * a.sB;
 
     // ---- both operand tiles: fp32 rows -> (hi | lo) halves in LDS; 8 x 16-byte loads per thread and operand ----
+    // f16 operand range guard: the largest integer image of the operands on their way to the split (NaN / inf on top).  The
+    // final projection's output is checked HERE - whatever overflowed in the last layer arrives as inf / NaN - for every shape,
+    // the streaming Sinkhorn path (frames beyond 2048 keypoints, which has no guard of its own) included.
+    unsigned gmax = 0u;
     auto stage = [&](const float* src, int r0, int nrows, _Float16* dst) {
         f32x4 x[8];
 #pragma unroll
@@ -56,6 +61,10 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
             const int idx = u * 512 + tid, row = idx >> 5, c = idx & 31;
             x[u] = *reinterpret_cast<const f32x4*>(src + (size_t)min(r0 + row, nrows - 1) * 128 + c * 4);
         }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gmax = max(gmax, __builtin_bit_cast(unsigned, x[u][j]) & 0x7fffffffu);
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = u * 512 + tid, row = idx >> 5, c = idx & 31;
@@ -68,6 +77,7 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
     };
     stage(A, i0, a.N, As);
     stage(Bm, j0, a.M, Bs);
+    if (a.guard && gmax >= __builtin_bit_cast(unsigned, MDGAT_F16_GUARD)) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __syncthreads();
 
     // ---- wave (wr, wc): rows 64 wr .. + 63, columns 32 wc .. + 31 of the tile ----
@@ -111,10 +121,10 @@ __global__ __launch_bounds__(512) void scores_kernel(ScoreArgs a) {
 }  // namespace
 
 int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float* Bm, size_t strideB, float* out, float scale,
-                const float* col_bias, hipStream_t s, void* zero, size_t zero_bytes) {
+                const float* col_bias, hipStream_t s, void* zero, size_t zero_bytes, unsigned* guard) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int tx = (M + 127) / 128, ty = (N + 127) / 128;
-    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias, static_cast<f32x4*>(zero), zero ? zero_bytes / 16 : 0, B, tx, ty};
+    ScoreArgs a{A, Bm, strideA, strideB, out, N, M, scale, col_bias, static_cast<f32x4*>(zero), zero ? zero_bytes / 16 : 0, B, tx, ty, guard};
     const unsigned grid = (unsigned)(((B + 7) / 8) * 8 * tx * ty);
     const size_t lds = (size_t)2 * 128 * SROW * sizeof(_Float16);
     static std::atomic<unsigned long long> optin[2];
@@ -125,7 +135,7 @@ int launch_dots(int B, int N, int M, const float* A, size_t strideA, const float
     return mdgat_check_hip(hipGetLastError(), "scores launch");
 }
 
-int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero, size_t zero_bytes) {
+int launch_scores(int B, int N, int M, const float* mdesc, float* scores, float scale, hipStream_t s, void* zero, size_t zero_bytes, unsigned* guard) {
     const size_t P = (size_t)(N + M) * 128;
-    return launch_dots(B, N, M, mdesc, P, mdesc + (size_t)N * 128, P, scores, scale, nullptr, s, zero, zero_bytes);
+    return launch_dots(B, N, M, mdesc, P, mdesc + (size_t)N * 128, P, scores, scale, nullptr, s, zero, zero_bytes, guard);
 }

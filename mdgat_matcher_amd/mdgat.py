@@ -75,20 +75,32 @@ class _DeviceState:
     """Per-device library handle + packed weights + scratch (one per (module, device)).  The scratch is per STREAM: the
     library only enqueues, so forwards issued on two streams run concurrently on the device and must not share it."""
 
+    MAX_WORKSPACES = 8                  # streams remembered per device (least recently used first out)
+
     def __init__(self, handle, device):
         self.handle = handle
         self.device = device
-        self.workspaces = {}            # stream handle -> uint8 tensor
+        self.workspaces = {}            # stream handle -> uint8 tensor, in order of last use
         self.lock = threading.Lock()
 
     def workspace_for(self, stream: int, need: int, dev):
-        ws = self.workspaces.get(stream)
+        """Scratch of the forward being enqueued on ``stream``.  Cached per raw stream handle, bounded (PyTorch hands stream
+        handles out of a pool: unbounded, the cache would pin ~0.4 GB per handle ever seen).  While a stream is being CAPTURED
+        into a graph the scratch is allocated from the graph's private pool and must live exactly as long as the graph: it is
+        handed back uncached (the graph keeps its allocation alive), and an eager call on a recycled handle can never be given
+        memory a graph still replays into."""
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return torch.empty(need, dtype=torch.uint8, device=dev)
+        ws = self.workspaces.pop(stream, None)
         if ws is None or ws.numel() < need:
-            self.workspaces.pop(stream, None)
-            ws = self.workspaces[stream] = torch.empty(need, dtype=torch.uint8, device=dev)
+            ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.workspaces[stream] = ws    # (most recently used last)
+        while len(self.workspaces) > self.MAX_WORKSPACES:
+            self.workspaces.pop(next(iter(self.workspaces)))
         return ws
 
     def close(self):
+        self.workspaces.clear()
         if self.handle:
             _lib.load().mdgat_destroy(self.handle)
             self.handle = None
@@ -134,8 +146,11 @@ class MDGAT(nn.Module):
         if self.lanes not in (0, 1, 2):
             raise ValueError(f'lanes={self.lanes}: expected 1 or 2 (0: library default)')
         # not a reference key: exact re-decision of near-threshold rows of the dynamic layers (include/mdgat_hip.h:
-        # mdgat_config.exact_topk).  On by default: it is what makes `logits.topk(k)` select like fp64 arithmetic.
-        self.exact_topk = bool(self.config.get('exact_topk', True))
+        # mdgat_config.exact_topk; csrc/repair.hip): `logits.topk(k)` then selects what fp64 arithmetic selects on the
+        # layer's own input.  Off by default: it removes the flips a dynamic layer causes itself (12-19 rows in 262 144 at
+        # BASELINE configs[1]) but not the ones that arrive with the layer's input, which dominate - the number of rows
+        # selected differently from the fp64 reference stays the same (profiles/parity_r4.txt) - and costs 3-6 %.
+        self.exact_topk = bool(self.config.get('exact_topk', False))
         if self.descriptor != 'FPFH':
             raise NotImplementedError(
                 f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
@@ -272,7 +287,7 @@ class MDGAT(nn.Module):
             cfg.extract_mode = self._extract_mode()
             cfg.match_threshold = float(self.config['match_threshold'])
             cfg.attention_mode = 0 if self.attention_dtype == 'fp32' else 1
-            cfg.exact_topk = int(getattr(self, 'exact_topk', True))
+            cfg.exact_topk = int(getattr(self, 'exact_topk', False))
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx)
@@ -374,7 +389,10 @@ class MDGAT(nn.Module):
         if st is None:
             return {'sinkhorn_fallback': False}
         if synchronize:
-            torch.cuda.synchronize(dev)
+            # (the CURRENT stream only - where this thread's forwards were enqueued; a device-wide synchronisation would stall
+            # every other stream of the process.  The status words are per handle: a caller that runs forwards of one module on
+            # several streams synchronises those itself before asking.)
+            torch.cuda.current_stream(dev).synchronize()
         fb, rg = C.c_uint(0), C.c_uint(0)
         _lib.check(_lib.load().mdgat_async_status(st.handle, 1, C.byref(fb), C.byref(rg)), 'mdgat_matcher_amd')
         return {'sinkhorn_fallback': bool(fb.value)}

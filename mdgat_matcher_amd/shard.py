@@ -20,6 +20,13 @@ def _group_active() -> bool:
     return dist.is_available() and dist.is_initialized()
 
 
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
 def init_distributed(n_gpus_requested: int = 1, backend: str | None = None, share_device: bool | None = None):
     """Reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* (torch.distributed.run).  Returns (rank, world, local).
 
@@ -46,8 +53,14 @@ def init_distributed(n_gpus_requested: int = 1, backend: str | None = None, shar
         local, backend = 0, 'gloo'
     launched = 'RANK' in os.environ and 'MASTER_ADDR' in os.environ
     if (world > 1 or launched) and not _group_active():
+        # the host driver of this pool shares device memory between processes through dmabuf only (RCCL communicator set-up
+        # fails with `hipIpcGetMemHandle: invalid argument` otherwise); harmless elsewhere, and only set when nobody chose
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        os.environ.setdefault('MASTER_PORT', '29531')
+        if 'MASTER_PORT' not in os.environ:
+            # (a launcher always sets it; without one the ranks of a multi-rank job cannot agree on a free port by themselves,
+            # a single rank can)
+            os.environ['MASTER_PORT'] = str(_free_port()) if world == 1 else '29531'
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'   # 'nccl' IS RCCL on ROCm
         if backend == 'nccl':
@@ -112,7 +125,12 @@ def gather_matches(local: torch.Tensor, world: int):
     """Optional: concatenate per-rank results on every rank (equal shard sizes)."""
     if world == 1 and not _group_active():
         return local
-    outs = [torch.empty_like(local) for _ in range(world)]
+    if local.is_cuda and dist.get_backend() != 'nccl':         # gloo: through host memory
+        host = local.cpu()
+        outs = [torch.empty_like(host) for _ in range(dist.get_world_size())]
+        dist.all_gather(outs, host)
+        return torch.cat(outs, dim=0).to(local.device)
+    outs = [torch.empty_like(local) for _ in range(dist.get_world_size())]
     dist.all_gather(outs, local)
     return torch.cat(outs, dim=0)
 

@@ -154,7 +154,7 @@ def local_flips(net, sd, data_cpu, device='cuda:0', with_stats=False):
     """{dynamic layer: rows whose HIP selection differs from the fp64 top-k of the HIP path's OWN fp32 layer input}: the flips
     caused INSIDE the layer (q / k projection + q.k products), which the exact re-decision of near-threshold rows
     (mdgat_config.exact_topk, csrc/repair.hip) removes.  ``with_stats``: also the repair counters [2L][4] (rows examined,
-    rewritten, rewritten with another selection than the fp32-class logits give, given up)."""
+    corrected, unused, given up)."""
     dev = {k: v.to(device) for k, v in data_cpu.items()}
     k0 = dev['keypoints0']
     B, N, M = k0.shape[0], k0.shape[1], dev['keypoints1'].shape[1]

@@ -94,9 +94,9 @@ def test_forward_dict_contract_and_variants(golden_dir, name):
         assert np.abs(out['matching_scores1'].cpu().numpy() - g[f'{tag}_mscores1']).max() < Z_TOL, tag
 
 
-@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n512_L9_S100_seed7'])
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b', 'cfg_n512_L9_S100_seed7'])
 def test_config_shapes_golden(golden_dir, name):
-    """BASELINE configs[0] / configs[1] shapes (8 pairs each) and configs[4] (N = 2048, L = 9, 200 iterations: one pair) with the default dynamic schedule, against the REFERENCE's
+    """BASELINE configs[0] / configs[1] shapes (8 pairs each) and configs[4] (N = 2048, L = 9, 200 iterations: 1 + 3 pairs) with the default dynamic schedule, against the REFERENCE's
     own fp64 output (tests/golden/cfg_*.npz) - unconditionally: matches bit-identical, plain |dZ| bounded, the literal
     1e-4 on every pair without a flipped selection - and against the oracle with the HIP selections forced."""
     g = _g(golden_dir, name)
@@ -111,9 +111,10 @@ def test_config_shapes_golden(golden_dir, name):
     # column marginals are exact by construction and independent of the top-k selections
     assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
     ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    sub = int(g['sub']) if 'sub' in g else 8
     assert_plain(res, ref_Z, g['default_matches0'], g['default_matches1'], g['default_mscores0'], g['default_mscores1'],
                  name + ' (reference golden)',
-                 z_index=lambda Zc: np.concatenate([Zc[:, ::8, ::8].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1))
+                 z_index=lambda Zc: np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1))
 
 
 @pytest.mark.parametrize('name', ['var_n256_L4_S20', 'var_n512_L9_S100', 'var_n400m512_L9_S100'])
@@ -282,7 +283,8 @@ def test_configs3_per_gpu_workload():
     cpu = {k: v[idx].cpu().double() for k, v in data.items()}
     res = attributed_parity(net, cfg, sd, cpu, DEV)
     assert_attributed(res, 'configs[3], pairs 63 / 64 / 300 / 511')
-    assert torch.equal(res['out'][0], m0[idx]) and (res['out'][4] - Z[idx]).abs().max() <= 5e-6     # (tapped kernels: parity_util)
+    from parity_util import TAP_EPS
+    assert torch.equal(res['out'][0], m0[idx]) and (res['out'][4] - Z[idx]).abs().max() <= TAP_EPS     # (tapped kernels: parity_util)
     assert_plain_vs_oracle(res, cfg, sd, cpu, 'configs[3], pairs 63 / 64 / 300 / 511')
 
 
@@ -789,12 +791,11 @@ def test_exact_topk_selects_like_fp64_on_the_same_layer_input(n, m, L, S, k, B):
         flips, stats = local_flips(net, sd, data, with_stats=True)
         res[exact] = (sum(flips.values()), stats.sum(0).tolist())
     print(f'[exact_topk] N={n} M={m} L={L} B={B}: in-layer flips with / without the re-decision {res[True][0]} / {res[False][0]}; '
-          f'near-threshold rows examined {res[True][1][0]}, rewritten {res[True][1][1]}, selection changed {res[True][1][2]}, '
-          f'given up {res[True][1][3]}')
+          f'near-threshold rows examined {res[True][1][0]}, corrected {res[True][1][1]}, given up {res[True][1][3]}')
     assert res[True][0] == 0, res
     assert res[False][1] == [0, 0, 0, 0]                  # switched off: nothing is examined
-    examined, rewritten, changed, given_up = res[True][1]
-    assert examined > 0 and rewritten <= examined and changed <= rewritten and given_up == 0
-    # ~1-2 rows in 10^3 are listed, a fraction of them rewritten: the re-decision must stay a rare path
+    examined, corrected, _, given_up = res[True][1]
+    assert examined > 0 and corrected <= examined and given_up == 0
+    # ~1 row in 10^3 is listed, ~1 in 50 of those corrected: the re-decision must stay a rare path
     rows = sum(B * 4 * (n + m) for kk in net._topk_schedule() if kk > 0)
-    assert examined < 0.01 * rows, (examined, rows)
+    assert examined < 0.005 * rows and corrected <= max(8, examined // 10), (examined, corrected, rows)

@@ -438,3 +438,51 @@ def _saved(net):
     buf = io.BytesIO()
     torch.save(net, buf)
     return buf.getvalue()
+
+
+def test_two_device_dataparallel_with_stubbed_library():
+    """torch.nn.DataParallel over two devices (test.py:158, train.py:192-196: replicate -> scatter -> parallel_apply in threads
+    -> gather), with the library replaced by the recorder: the owner packs once when it is replicated, each device gets ONE
+    handle loaded with the owner's blob (never a replica's own state), the two replicas run concurrently in threads on their own
+    handle, and their outputs concatenate along dim 0 like DataParallel.gather does."""
+    import threading
+    from unittest import mock
+    fake, stream = _FakeLib(), [7]
+    L = 1
+    net = MDGAT(synth.default_config(L=L, k=[])).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=6))
+    net = net.eval()
+    expect = net.packed_weights()
+    d = synth.make_batch(4, 8, 8)
+    keys = ('keypoints0', 'scores0', 'descriptors0', 'keypoints1', 'scores1', 'descriptors1')
+    shards = [{k: d[k][2 * i:2 * i + 2] for k in keys} for i in range(2)]          # DataParallel.scatter: dim 0
+    tl = threading.local()
+    with _stubbed(fake, stream), \
+            mock.patch.object(torch.Tensor, 'device', new=property(lambda self: torch.device('cuda', getattr(tl, 'dev', 0)))), \
+            mock.patch.object(torch.Tensor, 'to', new=lambda self, *a, **k: self), \
+            mock.patch.object(torch, 'empty', new=lambda *a, **k: torch.zeros(*a, **{kk: v for kk, v in k.items() if kk != 'device'})):
+        packed_before = net._blob_holder[0] is not None
+        replicas = [_emulate_replicate(net) for _ in range(2)]                      # the owner's _replicate_for_data_parallel hook runs
+        assert not packed_before and net._blob_holder[0] is not None               # packed once, by the owner, when replicated
+        outs, errs = [None, None], []
+
+        def worker(i):
+            try:
+                tl.dev = i
+                with torch.no_grad():
+                    outs[i] = replicas[i]._run(*[shards[i][k] for k in keys])
+            except Exception as e:                                                  # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=worker, args=(i,)) for i in range(2)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errs, errs
+        assert sorted(c for c in fake.calls if c[0] == 'create') == [('create', 0), ('create', 1)]
+        assert len(fake.loaded) == 2 and all(np.array_equal(b, expect) for b in fake.loaded)
+        assert sorted(net._states) == [0, 1] and all(r._states is net._states for r in replicas)
+        assert sum(1 for c in fake.calls if c[0] == 'forward') == 2 and all(c[1] == 2 for c in fake.calls if c[0] == 'forward')
+        gathered = torch.cat([o[0] for o in outs], dim=0)                           # DataParallel.gather of matches0
+        assert gathered.shape == (4, 8)
+        net._invalidate()

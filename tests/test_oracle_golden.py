@@ -63,7 +63,7 @@ def test_extraction_variants(golden_dir, name):
         np.testing.assert_allclose(s1.numpy(), g[f'{tag}_mscores1'], atol=TOL, err_msg=tag)
 
 
-@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n512_L9_S100_seed7'])
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b', 'cfg_n512_L9_S100_seed7'])
 def test_config_shapes(golden_dir, name):
     g = _load(golden_dir, name)
     sd, data, k, L, S, n, m = _setup(g)
@@ -71,7 +71,8 @@ def test_config_shapes(golden_dir, name):
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
     out = O.mdgat_forward(sd, cfg, data, cap)
     Z = cap['Z']
-    assert np.abs(Z.numpy()[:, ::8, ::8] - g['Z_sub']).max() < 1e-8
+    sub = int(g['sub']) if 'sub' in g else 8
+    assert np.abs(Z.numpy()[:, ::sub, ::sub] - g['Z_sub']).max() < 1e-8
     assert np.abs(Z.numpy()[:, -1, :] - g['Z_lastrow']).max() < 1e-8
     assert np.abs(Z.numpy()[:, :, -1] - g['Z_lastcol']).max() < 1e-8
     assert np.abs(torch.logsumexp(Z, 2).numpy() - g['Z_row_lse']).max() < 1e-8

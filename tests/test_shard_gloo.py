@@ -200,3 +200,53 @@ def test_share_device_hook_is_announced_and_needs_a_single_gpu(capsys, monkeypat
     import pytest
     with pytest.raises(RuntimeError, match='single-GPU test hook'):
         shard.init_distributed(1)
+
+
+def test_bench_eight_ranks_gloo_stub(tmp_path):
+    """bench.py --gpus 8 --config 3 the way the driver launches it (torch.distributed.run, 8 ranks) - on CPU: gloo stands for
+    RCCL and a recorder for the library (tests/bench_stub_runner.py), everything else is bench.py's own code: BASELINE
+    configs[3] = 4096 pairs sharded 8-way = 512 per rank, ONE JSON line from rank 0, value = all pairs / the slowest rank's
+    window, the communicator's world size and every rank's pair count and own time in the line."""
+    import json
+    import subprocess
+    port = 29611 + (os.getpid() % 300)
+    log = str(tmp_path / 'calls')
+    env = dict(os.environ, MDGAT_BENCH_STUB_LOG=log, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY'):
+        env.pop(k, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '8', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.join(ROOT, 'tests', 'bench_stub_runner.py'), '--gpus', '8', '--config', '3',
+           '--steps', '3', '--warmup', '1', '--windows', '2']
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout                                     # rank 0 only
+    d = json.loads(lines[0])
+    assert d['stub'] is True and d['n_gpus'] == 8 and d['scaling'] == 'weak' and d['steps'] == 3
+    c = d['config']
+    assert c['rccl_world_size'] == 8 and c['collectives'] == 'gloo' and c['pairs_per_rank'] == [512] * 8 and c['baseline_config'] == 3
+    t = d['timing']
+    assert len(t['per_rank_ms_per_step']) == 8 and max(range(8), key=lambda r: t['per_rank_ms_per_step'][r]) == 3     # the straggler
+    assert abs(d['value'] - 4096 * 3 / (sorted(t['window_ms'])[len(t['window_ms']) // 2] * 1e-3)) < 1e-3 * d['value']      # (window_ms is rounded)
+    assert d['ms_per_step'] >= max(t['per_rank_ms_per_step']) * 0.999        # the whole job waits for its slowest rank
+    assert d['status'] == {'sinkhorn_fallback': False, 'range_violation': False}
+    # every rank ran its own 512 pairs, and only those: 8 + warmup + windows x steps forwards of 512 x 512 x 512
+    for r in range(8):
+        calls = open(f'{log}.{r}').read().split('\n')[:-1]
+        assert calls and set(calls) == {'512 512 512'} and len(calls) == 8 + 1 + 2 * 3, (r, len(calls))
+
+
+def test_env_defaults_for_rccl_on_this_pool(monkeypatch):
+    """bench.py and shard.init_distributed put HSA_ENABLE_IPC_MODE_LEGACY=0 into the environment when nobody chose (RCCL on
+    this pool's hosts needs it: INTEGRATION.md) and never override a choice."""
+    import importlib
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k != 'HSA_ENABLE_IPC_MODE_LEGACY'}
+    code = ('import os, sys; sys.argv=["bench.py", "--help"]\n'
+            'try:\n    import bench\nexcept SystemExit:\n    pass\n'
+            'print("IPC", os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"))')
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=env, capture_output=True, text=True, timeout=300).stdout
+    assert 'IPC 0' in out, out
+    out = subprocess.run([sys.executable, '-c', code], cwd=ROOT, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY='1'), capture_output=True,
+                         text=True, timeout=300).stdout
+    assert 'IPC 1' in out, out

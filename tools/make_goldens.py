@@ -153,7 +153,7 @@ def gen_forward(M, name, B, n, m, L, S, k, seed=0, bin_score=1.0, first_pair=0):
     print('wrote', name, {k2: v.shape for k2, v in arrays.items() if k2 in ('Z', 'scores')})
 
 
-def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0, bin_score=1.0):
+def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0, bin_score=1.0, sub=8):
     sd = synth.make_state_dict(L=L, seed=seed, bin_score=bin_score)
     data = synth.make_batch(B, n, m, first_pair=first_pair)
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
@@ -163,12 +163,14 @@ def gen_config(M, name, B, n, m, L, S, k, seed=0, first_pair=0, bin_score=1.0):
     arrays = {'meta': np.array([B, n, m, L, S, seed, first_pair], dtype=np.int64),
               'k': np.array([-1 if x is None else x for x in k], dtype=np.int64), 'bin_score': np.array(bin_score)}
     arrays.update(out_arrays(out, 'default'))
-    arrays['Z_sub'] = Z[:, ::8, ::8].copy()
+    if sub != 8:
+        arrays['sub'] = np.array(sub)            # stride of the Z / score sub-samples (8 where the key is absent)
+    arrays['Z_sub'] = Z[:, ::sub, ::sub].copy()
     arrays['Z_lastrow'] = Z[:, -1, :].copy()
     arrays['Z_lastcol'] = Z[:, :, -1].copy()
     arrays['Z_row_lse'] = torch.logsumexp(cap['Z'], dim=2).numpy()
     arrays['Z_col_lse'] = torch.logsumexp(cap['Z'], dim=1).numpy()
-    arrays['scores_sub'] = cap['scores'].numpy()[:, ::8, ::8].copy()
+    arrays['scores_sub'] = cap['scores'].numpy()[:, ::sub, ::sub].copy()
     np.savez_compressed(os.path.join(OUT, name + '.npz'), **arrays)
     print('wrote', name, Z.shape)
 
@@ -277,24 +279,36 @@ def gen_edges(M):
 
 
 def main():
+    """python tools/make_goldens.py [fixture name ...]  (no names: all of them)"""
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     M = import_reference()
     small_k = [16, None, 16, None, 8, None, 8, None]
-    gen_forward(M, 'fwd_n64_L1_S1', 1, 64, 64, 1, 1, small_k)
-    gen_forward(M, 'fwd_n64_L4_S20', 1, 64, 64, 4, 20, small_k)
-    gen_forward(M, 'fwd_n64_L5_S20', 2, 64, 64, 5, 20, small_k)
-    gen_forward(M, 'fwd_n48m64_L4_S20', 1, 48, 64, 4, 20, small_k, bin_score=0.37, first_pair=5)
-    # BASELINE configs[0] / configs[1] shapes, 8 reference-held pairs each (round 3: the headline shape had 2)
-    gen_config(M, 'cfg_n256_L4_S20', 8, 256, 256, 4, 20, synth.DEFAULT_K)
-    gen_config(M, 'cfg_n512_L9_S100', 8, 512, 512, 9, 100, synth.DEFAULT_K)
-    gen_config(M, 'cfg_n2048_L9_S200', 1, 2048, 2048, 9, 200, synth.DEFAULT_K)      # BASELINE configs[4]
-    gen_config(M, 'cfg_n512_L9_S100_seed7', 4, 512, 512, 9, 100, synth.DEFAULT_K, seed=7, first_pair=40, bin_score=0.37)   # other weights, other bin score
-    gen_config_variants(M, 'var_n256_L4_S20', 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)
-    gen_config_variants(M, 'var_n512_L9_S100', 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)
-    gen_config_variants(M, 'var_n400m512_L9_S100', 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)
-    gen_ops(M)
-    gen_edges(M)
+    only = set(sys.argv[1:])
+    jobs = [
+        ('fwd_n64_L1_S1', lambda nm: gen_forward(M, nm, 1, 64, 64, 1, 1, small_k)),
+        ('fwd_n64_L4_S20', lambda nm: gen_forward(M, nm, 1, 64, 64, 4, 20, small_k)),
+        ('fwd_n64_L5_S20', lambda nm: gen_forward(M, nm, 2, 64, 64, 5, 20, small_k)),
+        ('fwd_n48m64_L4_S20', lambda nm: gen_forward(M, nm, 1, 48, 64, 4, 20, small_k, bin_score=0.37, first_pair=5)),
+        # BASELINE configs[0] / configs[1] shapes, 8 reference-held pairs each (round 3: the headline shape had 2)
+        ('cfg_n256_L4_S20', lambda nm: gen_config(M, nm, 8, 256, 256, 4, 20, synth.DEFAULT_K)),
+        ('cfg_n512_L9_S100', lambda nm: gen_config(M, nm, 8, 512, 512, 9, 100, synth.DEFAULT_K)),
+        # BASELINE configs[4]: one pair (round 3) + three more (round 4; sub-sampled every 16th entry to stay small)
+        ('cfg_n2048_L9_S200', lambda nm: gen_config(M, nm, 1, 2048, 2048, 9, 200, synth.DEFAULT_K)),
+        ('cfg_n2048_L9_S200_b', lambda nm: gen_config(M, nm, 3, 2048, 2048, 9, 200, synth.DEFAULT_K, first_pair=1, sub=16)),
+        # other weights, other bin score
+        ('cfg_n512_L9_S100_seed7', lambda nm: gen_config(M, nm, 4, 512, 512, 9, 100, synth.DEFAULT_K, seed=7, first_pair=40, bin_score=0.37)),
+        ('var_n256_L4_S20', lambda nm: gen_config_variants(M, nm, 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)),
+        ('var_n512_L9_S100', lambda nm: gen_config_variants(M, nm, 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)),
+        ('var_n400m512_L9_S100', lambda nm: gen_config_variants(M, nm, 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)),
+        ('op_vectors', lambda nm: gen_ops(M)),
+        ('edge_cases', lambda nm: gen_edges(M)),
+    ]
+    unknown = only - {nm for nm, _ in jobs}
+    assert not unknown, f'unknown fixtures {sorted(unknown)}'
+    for nm, fn in jobs:
+        if not only or nm in only:
+            fn(nm)
 
 
 if __name__ == '__main__':
