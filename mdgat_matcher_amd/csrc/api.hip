@@ -142,6 +142,14 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     return MDGAT_OK;
 }
 
+// largest integer image of |w| over the blob (NaN / inf on top): the weights become f16 head + f16 residual like every operand
+__global__ __launch_bounds__(256) void blob_absmax_kernel(const float* w, size_t n, unsigned* out) {
+    unsigned m = 0u;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) m = max(m, __builtin_bit_cast(unsigned, w[i]) & 0x7fffffffu);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device) {
     if (!h || !blob) { mdgat_set_error("mdgat_load_weights: null argument"); return MDGAT_ERR_BAD_ARG; }
     if (n_floats != h->bl.total) {
@@ -159,6 +167,27 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
     (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(h->device), "hipSetDevice");
     const BlobLayout& bl = h->bl;
+    h->loaded = false;
+    if (!rc) {
+        // f16 operand range of the WEIGHTS (the kernels guard activations): a weight beyond 6e4 would become an infinite f16 head,
+        // and what that makes of the activations a ReLU can turn back into finite garbage (max(NaN, 0) = 0).  The packer brings
+        // every rescalable channel to unit scale (pack.py: gauge fixing), so this only fires for checkpoints that are broken or
+        // hold non-finite values.
+        unsigned* dmax = reinterpret_cast<unsigned*>(h->wsplit);       // (scratch: the split images are written below)
+        rc = mdgat_check_hip(hipMemset(dmax, 0, sizeof(unsigned)), "hipMemset(weight range)");
+        unsigned hmax = 0;
+        if (!rc) {
+            hipLaunchKernelGGL(blob_absmax_kernel, dim3(256), dim3(256), 0, nullptr, h->weights, n_floats, dmax);
+            rc = mdgat_check_hip(hipMemcpy(&hmax, dmax, sizeof(unsigned), hipMemcpyDeviceToHost), "hipMemcpy(weight range)");
+        }
+        if (!rc && hmax >= __builtin_bit_cast(unsigned, MDGAT_F16_GUARD)) {
+            (void)hipSetDevice(prev);
+            mdgat_set_error("mdgat_load_weights: a packed weight is not finite or beyond the f16 operand range (|w| >= 6e4; largest image 0x%08x): "
+                            "this checkpoint does not fit the split-f16 arithmetic", hmax);
+            return MDGAT_ERR_UNSUPPORTED;
+        }
+        if (!rc) rc = mdgat_check_hip(hipMemset(dmax, 0, sizeof(unsigned)), "hipMemset(weight range)");
+    }
     for (int i = 0; i < 2 * h->cfg.L && !rc; ++i) {
         const float* lw = h->weights + bl.layer0 + (size_t)i * bl.layer_stride;
         _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;

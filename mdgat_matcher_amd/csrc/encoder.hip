@@ -131,7 +131,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
             acc = fmaf(wv[1], xyzs[1], acc);
             acc = fmaf(wv[2], xyzs[2], acc);
             acc = fmaf(wv[3], xyzs[3], acc);
-            v[j] = fmaxf(acc, 0.f);
+            v[j] = acc < 0.f ? 0.f : acc;       // (ReLU that lets NaN through: max(NaN, 0) = 0 would hide an overflow from the range guard)
         }
         split8s(v, k0h[t], k0l[t]);
     }
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
             float bv[8], v[8];
             load8(bias + 16 * t + 8 * hi, bv);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = fmaxf(o[8 * t + j] + bv[j], 0.f);
+            for (int j = 0; j < 8; ++j) { const float y = o[8 * t + j] + bv[j]; v[j] = y < 0.f ? 0.f : y; }     // (NaN passes)
             split8s(v, dh[t], dl[t]);
         }
     };

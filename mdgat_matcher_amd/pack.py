@@ -14,6 +14,14 @@ All folding is done in fp64 and rounded to fp32 once:
 * the q and k rows of that matrix (and their biases) are followed by their fp32 residuals ``w - fp32(w)``
   (``qk_lo_w``, ``qk_lo_b``): the exact re-decision of near-threshold top-k rows (``csrc/repair.hip``) rebuilds the
   fp64 weights from head + residual;
+* GAUGE FIXING.  The network's function does not change when a hidden channel is scaled by s > 0 and the weights that
+  read it by 1 / s - behind a ReLU (positively homogeneous), between v and ``merge`` (linear), and, dimension by
+  dimension, between q and k (the logits are bilinear).  A checkpoint may sit anywhere in that family; the kernels carry
+  every operand as two f16 halves (|value| < 65504, values below ~10^-3 lose bits to the f16 denormal floor).  Each such
+  channel that is 32x or more away from weight-row norm 1 (q against k: from equal norms) is therefore brought there by a
+  power of two - exact in binary floating point, so the packed network computes the same numbers as the checkpoint's -
+  before the blob is rounded
+  (``tools/fuzz_checkpoint.py``: rescalings by 10^-3 ... 10^3 leave the results unchanged);
 * the last layers of the two encoders are summed (``mdgat.py:392-393``) by concatenating them along K:
   ``[denc.6 | kenc.9] [hd ; hk]``.
 """
@@ -89,6 +97,34 @@ def _plain(sd, conv):
 HEAD_MAJOR = np.array([d * H + h for h in range(H) for d in range(DH)])
 
 
+GAUGE_SLACK = 5         # a channel is rescaled only when it is 2^5 = 32x or more away from unit scale
+
+
+def _pow2(x):
+    """Nearest power of two of every (positive, finite) entry - 1 where the entry is zero, not finite or within 2^-GAUGE_SLACK ...
+    2^GAUGE_SLACK of one: the f16 halves span nine orders of magnitude, a channel a few octaves off unit scale is as good
+    as one at it, and leaving it alone keeps the packed weights of an ordinary checkpoint the plain fp32 roundings."""
+    x = np.asarray(x, dtype=np.float64)
+    ok = np.isfinite(x) & (x > 0)
+    e = np.round(np.log2(np.where(ok, x, 1.0)))
+    return np.where(ok & (np.abs(e) >= GAUGE_SLACK), np.exp2(e), 1.0)
+
+
+def _row_scale(w, b=None):
+    """Power-of-two scale per output channel that brings the channel's weight row (and bias) to norm ~1."""
+    n2 = (w ** 2).sum(axis=1) + (0.0 if b is None else b ** 2)
+    return _pow2(1.0 / np.sqrt(np.where(n2 > 0, n2, 1.0)))
+
+
+def _fix_hidden(w, b, w_next, cols=None):
+    """Gauge of a hidden layer: rows of (w, b) x s, the columns ``cols`` of ``w_next`` that read the layer / s."""
+    s = _row_scale(w, b)
+    cols = slice(None) if cols is None else cols
+    w_next = w_next.copy()
+    w_next[:, cols] = w_next[:, cols] / s[None, :]
+    return w * s[:, None], b * s, w_next
+
+
 def check_supported(sd, L):
     shapes = {
         'kenc.encoder.0.weight': (32, 4, 1), 'kenc.encoder.3.weight': (64, 32, 1),
@@ -115,14 +151,25 @@ def pack_state_dict(sd, L: int) -> np.ndarray:
         a = np.ascontiguousarray(arr, dtype=np.float64).reshape(-1)
         blob[off:off + a.size] = a
 
-    w, b = _fold_bn(sd, 'kenc.encoder.0', 'kenc.encoder.1'); put(lay['kenc0_w'], w); put(lay['kenc0_b'], b)
-    w, b = _fold_bn(sd, 'denc.encoder.0', 'denc.encoder.1'); put(lay['denc0_w'], w); put(lay['denc0_b'], b)
-    w, b = _fold_bn(sd, 'kenc.encoder.3', 'kenc.encoder.4'); put(lay['kenc1_w'], w); put(lay['kenc1_b'], b)
-    w, b = _fold_bn(sd, 'kenc.encoder.6', 'kenc.encoder.7'); put(lay['kenc2_w'], w); put(lay['kenc2_b'], b)
-    w, b = _fold_bn(sd, 'denc.encoder.3', 'denc.encoder.4'); put(lay['denc1_w'], w); put(lay['denc1_b'], b)
-    wd, bd = _plain(sd, 'denc.encoder.6')
-    wk, bk = _plain(sd, 'kenc.encoder.9')
-    put(lay['encl_w'], np.concatenate([wd, wk], axis=1)); put(lay['encl_b'], bd + bk)
+    # encoders: BN folded, then the gauge of every hidden layer fixed (module docstring)
+    wk0, bk0 = _fold_bn(sd, 'kenc.encoder.0', 'kenc.encoder.1')
+    wk1, bk1 = _fold_bn(sd, 'kenc.encoder.3', 'kenc.encoder.4')
+    wk2, bk2 = _fold_bn(sd, 'kenc.encoder.6', 'kenc.encoder.7')
+    wk3, bk3 = _plain(sd, 'kenc.encoder.9')
+    wd0, bd0 = _fold_bn(sd, 'denc.encoder.0', 'denc.encoder.1')
+    wd1, bd1 = _fold_bn(sd, 'denc.encoder.3', 'denc.encoder.4')
+    wd2, bd2 = _plain(sd, 'denc.encoder.6')
+    wk0, bk0, wk1 = _fix_hidden(wk0, bk0, wk1)
+    wk1, bk1, wk2 = _fix_hidden(wk1, bk1, wk2)
+    wk2, bk2, wk3 = _fix_hidden(wk2, bk2, wk3)
+    wd0, bd0, wd1 = _fix_hidden(wd0, bd0, wd1)
+    wd1, bd1, wd2 = _fix_hidden(wd1, bd1, wd2)
+    put(lay['kenc0_w'], wk0); put(lay['kenc0_b'], bk0)
+    put(lay['denc0_w'], wd0); put(lay['denc0_b'], bd0)
+    put(lay['kenc1_w'], wk1); put(lay['kenc1_b'], bk1)
+    put(lay['kenc2_w'], wk2); put(lay['kenc2_b'], bk2)
+    put(lay['denc1_w'], wd1); put(lay['denc1_b'], bd1)
+    put(lay['encl_w'], np.concatenate([wd2, wk3], axis=1)); put(lay['encl_b'], bd2 + bk3)
 
     for i in range(2 * L):
         base = lay['layer0'] + i * lay['layer_stride']
@@ -131,6 +178,15 @@ def pack_state_dict(sd, L: int) -> np.ndarray:
         for j in range(3):
             w, b = _plain(sd, f'{p}.attn.proj.{j}')
             ws.append(w[HEAD_MAJOR]); bs.append(b[HEAD_MAJOR])
+        # q against k, dimension by dimension: equal row norms (the logits see the product of the two)
+        nq = np.sqrt((ws[0] ** 2).sum(axis=1) + bs[0] ** 2)
+        nk = np.sqrt((ws[1] ** 2).sum(axis=1) + bs[1] ** 2)
+        sq = _pow2(np.sqrt(np.where((nq > 0) & (nk > 0), nk / np.where(nq > 0, nq, 1.0), 1.0)))
+        ws[0], bs[0] = ws[0] * sq[:, None], bs[0] * sq
+        ws[1], bs[1] = ws[1] / sq[:, None], bs[1] / sq
+        # v against merge, channel by channel
+        sv = _row_scale(ws[2], bs[2])
+        ws[2], bs[2] = ws[2] * sv[:, None], bs[2] * sv
         put(base + lay['qkv_w'], np.concatenate(ws, axis=0)); put(base + lay['qkv_b'], np.concatenate(bs))
         # fp32 residuals of the q and k rows: the library's exact top-k re-decision (csrc/repair.hip) evaluates
         # near-threshold logits with the fp64 weights, carried as fp32 head + fp32 residual (48 bits)
@@ -138,11 +194,13 @@ def pack_state_dict(sd, L: int) -> np.ndarray:
             full = np.concatenate(arrs[:2], axis=0).reshape(-1)
             put(base + lay[wname], full - full.astype(np.float32).astype(np.float64))
         wm, bm = _plain(sd, f'{p}.attn.merge')
-        wm = wm[:, HEAD_MAJOR]                     # input columns in head-major message order
+        wm = wm[:, HEAD_MAJOR] / sv[None, :]       # input columns in head-major message order, the v gauge undone
         w1, b1 = _fold_bn(sd, f'{p}.mlp.0', f'{p}.mlp.1')
         w1x, w1m = w1[:, :D], w1[:, D:]
-        put(base + lay['mlp1_w'], np.concatenate([w1x, w1m @ wm], axis=1)); put(base + lay['mlp1_b'], b1 + w1m @ bm)
+        w1f, b1f = np.concatenate([w1x, w1m @ wm], axis=1), b1 + w1m @ bm
         w2, b2 = _plain(sd, f'{p}.mlp.3')
+        w1f, b1f, w2 = _fix_hidden(w1f, b1f, w2)
+        put(base + lay['mlp1_w'], w1f); put(base + lay['mlp1_b'], b1f)
         put(base + lay['mlp2_w'], w2); put(base + lay['mlp2_b'], b2)
     w, b = _plain(sd, 'final_proj'); put(lay['final_w'], w); put(lay['final_b'], b)
     blob[lay['bin_score']] = float(_np(sd['bin_score']))

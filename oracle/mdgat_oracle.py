@@ -95,7 +95,8 @@ def dynamic_attention(q, k, v, topk: int, forced=None, report=None):
     ``report`` (a list) receives one dict per call describing every row where the two selections differ:
     ``rows`` = number of such rows (``rows_per_pair``: the same count per batch element), ``max_gap`` = largest
     |logit - k-th largest logit| over the keys in the symmetric difference (how far from a tie the disagreement is, in
-    the units of the logits), ``bad_count`` = rows whose forced selection does not hold exactly ``topk`` keys."""
+    the units of the logits; ``max_rel_gap``: relative to the row's largest |logit|, at least 1), ``bad_count`` = rows
+    whose forced selection does not hold exactly ``topk`` keys."""
     dh = q.shape[1]
     m = k.shape[3]
     if topk > m:
@@ -117,9 +118,11 @@ def dynamic_attention(q, k, v, topk: int, forced=None, report=None):
             diff = own ^ forced
             kth = top.values[..., -1:]
             gap = torch.where(diff, (logits - kth).abs(), torch.zeros_like(logits))
+            scale = logits.abs().amax(-1, keepdim=True).clamp(min=1.0)      # (of the row: for networks with large logits)
             report.append({'rows': int(diff.any(-1).sum()), 'total_rows': diff[..., 0].numel(),
                            'rows_per_pair': diff.any(-1).sum(dim=(1, 2)),
-                           'max_gap': float(gap.max()), 'bad_count': int((forced.sum(-1) != topk).sum()),
+                           'max_gap': float(gap.max()), 'max_rel_gap': float((gap / scale).max()),
+                           'bad_count': int((forced.sum(-1) != topk).sum()),
                            'row_gaps': gap.amax(-1)[diff.any(-1)]})
     return torch.einsum('bhnm,bdhm->bdhn', prob, v), prob
 

@@ -477,8 +477,8 @@ def test_f16_operand_range_is_guarded():
     cfg = synth.default_config(L=L, k=[16, None, 16, None], sinkhorn_iterations=10)
     data = synth.make_batch(2, 64, 64, device=DEV)
     args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
-    for key, factor in (('kenc.encoder.9.weight', 3e5), ('gnn.layers.1.mlp.3.weight', 1e6), ('gnn.layers.2.attn.proj.2.weight', 1e6),
-                        ('gnn.layers.0.attn.proj.0.weight', 1e5)):
+    # (weights below the range check of mdgat_load_weights - test_weights_beyond_the_f16_range_are_refused -, activations beyond)
+    for key, factor in (('kenc.encoder.9.weight', 3e4), ('gnn.layers.1.mlp.3.weight', 1e5), ('final_proj.weight', 3e4)):      # (final_proj: caught by the score kernel's operand guard)
         sd = synth.make_state_dict(L=L, seed=1)
         sd[key] = sd[key] * factor
         net = MDGAT(cfg).double()
@@ -495,6 +495,16 @@ def test_f16_operand_range_is_guarded():
         with pytest.raises(RuntimeError, match='f16 operand range'):
             net.match(*args)                                 # ... or the next call on the handle finds it
         net.check(DEV)                                       # (reported once: the status is clear again)
+    # a gain of 10^5 on q alone is no overflow any more: the packer balances q against k (pack.py, gauge fixing), the logits
+    # grow a 10^5-fold and the rows become one-hot - finite, and the same matches as the fp64 oracle's
+    sd = synth.make_state_dict(L=L, seed=1)
+    sd['gnn.layers.0.attn.proj.0.weight'] = sd['gnn.layers.0.attn.proj.0.weight'] * 1e5
+    net = MDGAT(cfg).double()
+    net.load_state_dict(sd)
+    net = net.eval().to(DEV)
+    with torch.no_grad():
+        out = net(data)
+    assert torch.isfinite(out['matching_scores0']).all() and net.check(DEV) == {'sinkhorn_fallback': False}
     sd = synth.make_state_dict(L=L, seed=1)                  # the unscaled weights pass
     net = MDGAT(cfg).double()
     net.load_state_dict(sd)
@@ -799,3 +809,51 @@ def test_exact_topk_selects_like_fp64_on_the_same_layer_input(n, m, L, S, k, B):
     # ~1 row in 10^3 is listed, ~1 in 50 of those corrected: the re-decision must stay a rare path
     rows = sum(B * 4 * (n + m) for kk in net._topk_schedule() if kk > 0)
     assert examined < 0.005 * rows and corrected <= max(8, examined // 10), (examined, corrected, rows)
+
+
+def test_fuzz_checkpoint_short():
+    """15 s of tools/fuzz_checkpoint.py - the forward-level robustness sweep standing in for the checkpoint the reference tree
+    does not hold (pre-trained/best_model.pth is a missing blob): function-preserving rescalings of q against k, v against
+    merge and of every hidden layer by 10^-3 ... 10^3 (the packer's gauge fixing must neutralise them), real gains on logits /
+    messages / updates / scores, bin scores -5 ... 5, sparse FPFH rows, duplicated keypoints.  Every case ends EXACT (Z within
+    max(1e-4, 8 x the error of a plain fp32 PyTorch run) of the fp64 oracle, k keys per dynamic row, near-tie selections only,
+    matches = the extraction rules applied to the HIP path's own Z) or GUARDED (the f16 range guard raises) - never in
+    silent garbage."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('fuzz_checkpoint', os.path.join(root, 'tools', 'fuzz_checkpoint.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    cases, guarded, exact, fails, worst = fz.run(15.0, seed=5, verbose=True)
+    assert cases >= 30 and fails == 0 and exact >= cases // 2
+
+
+def test_weights_beyond_the_f16_range_are_refused():
+    """mdgat_load_weights checks the packed weights: a value beyond the f16 operand range (or non-finite) would become an
+    infinite f16 head whose damage a ReLU can turn back into finite garbage - the load fails instead.  Rescalings the packer
+    can undo (gauge fixing, pack.py) do not trip it."""
+    L = 1
+    cfg = synth.default_config(L=L, k=[], sinkhorn_iterations=5)
+    d = synth.make_batch(1, 32, 32, device=DEV)
+    args = (d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1'])
+    sd = synth.make_state_dict(L=L, seed=2)
+    ref_net = MDGAT(cfg).double()
+    ref_net.load_state_dict(sd)
+    ref = ref_net.eval().to(DEV).match(*args, return_scores=True)[4]
+    # a hidden layer blown up by 10^6 against the convolution that reads it: the same network, and the packer says so
+    sd2 = {k: v.clone() for k, v in sd.items()}
+    for t in ('weight', 'bias'):
+        sd2[f'gnn.layers.0.mlp.1.{t}'] = sd2[f'gnn.layers.0.mlp.1.{t}'] * 1e6
+    sd2['gnn.layers.0.mlp.3.weight'] = sd2['gnn.layers.0.mlp.3.weight'] / 1e6
+    net = MDGAT(cfg).double()
+    net.load_state_dict(sd2)
+    Z = net.eval().to(DEV).match(*args, return_scores=True)[4]
+    assert (Z - ref).abs().max().item() < 1e-4
+    # a weight that no rescaling can tame / a non-finite one: refused at load
+    for bad in (1e9, float('nan')):
+        sd3 = {k: v.clone() for k, v in sd.items()}
+        sd3['final_proj.weight'][3, 5, 0] = bad
+        net = MDGAT(cfg).double()
+        net.load_state_dict(sd3)
+        with pytest.raises(RuntimeError, match='f16 operand range'):
+            net.eval().to(DEV).match(*args)
