@@ -21,5 +21,13 @@ for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_A
   ( cd $R; python tools/pmc_summary.py /tmp/pr_$n/p_results.db ) > $O/${TAG}_pmc_$n.txt 2>&1
 done
 cat $O/${TAG}_pmc_FETCH_SIZE.txt $O/${TAG}_pmc_WRITE_SIZE.txt >> $O/${TAG}_pmc_fetch_write_kb.txt
+# the same two traffic passes with every launch on one stream (what bench.py's `roofline` block - measured under
+# mdgat_set_lanes(1) - cites: profiles/pmc_traffic.json key "<config>:single_lane")
+( echo "# MDGAT_FORWARD_LANES=1 rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown $BENCH_ARGS; KB per launch, averages" ) > $O/${TAG}_single_lane_pmc_fetch_write_kb.txt
+for n in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pr1_$n && MDGAT_FORWARD_LANES=1 rocprofv3 --kernel-trace --pmc $n -d /tmp/pr1_$n -o p -- $CMD > /dev/null 2>&1
+  ( cd $R; python tools/pmc_summary.py /tmp/pr1_$n/p_results.db ) > $O/${TAG}_single_lane_pmc_$n.txt 2>&1
+done
+cat $O/${TAG}_single_lane_pmc_FETCH_SIZE.txt $O/${TAG}_single_lane_pmc_WRITE_SIZE.txt >> $O/${TAG}_single_lane_pmc_fetch_write_kb.txt
 ( echo "# rocprofv3 --kernel-trace --pmc SQ_* (one pass) -- the same command; per-launch averages"; cat $O/${TAG}_pmc_SQ_WAVE_CYCLES.txt ) > $O/${TAG}_pmc_sq_counters.txt
 ls -la $O/${TAG}_*
