@@ -193,6 +193,13 @@ int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
  * after changing it. */
 int mdgat_set_lanes(mdgat_handle* h, int lanes);
 
+/* Which kernel runs the layer tail (mlp + residual + next q|k|v; models/mdgat.py:227-232, 246-248, 274, 397) of a launch.
+ * Launches of at most `tiles` tiles of 128 keypoints (default 16; MDGAT_LAYER_SPLIT_TILES in the environment) run the
+ * channel-split kernel of csrc/layer_split.hip (32-keypoint workgroups, the eight waves share the output channels: the
+ * latency shape, test.py:132 runs batch_size = 1), larger ones the keypoint-split kernels of csrc/layer.hip.  Process-wide;
+ * results are bit-identical either way.  tiles = 0: never; tiles < 0: back to the default.  Returns the previous value. */
+int mdgat_set_layer_split_tiles(int tiles);
+
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
 
 /* log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308): scores [B][N][M] -> Z. */

@@ -87,6 +87,11 @@ static constexpr size_t WS_ROW256 = 528, WS_ROW128 = 272;
 static constexpr size_t WS_W1 = 0, WS_W2 = 256 * WS_ROW256, WS_QKV = WS_W2 + 128 * WS_ROW256, WS_LAYER = WS_QKV + 384 * WS_ROW128;
 static constexpr size_t WS_FINAL = 128 * WS_ROW128 + 512;
 static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + WS_FINAL + MDGAT_ENC_SPLIT_HALVES; }
+// behind them, the same GNN / final_proj matrices once more in FRAGMENT order for layer_split.hip, whose waves load their
+// slice of the weights straight into registers: [row block of 16][k-step of 32][plane hi / lo][lane (row l15, column g)] x 16 B,
+// so that a wave's load instruction reads one contiguous KB (launch_frag_image; no pads)
+static constexpr size_t WF_W1 = 0, WF_W2 = 256 * 512, WF_QKV = WF_W2 + 128 * 512, WF_LAYER = WF_QKV + 384 * 256, WF_FINAL = 128 * 256;
+static size_t wfrag_halves(int L) { return WF_LAYER * (size_t)(2 * L) + WF_FINAL; }
 
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
@@ -126,8 +131,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
-    if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMalloc(split weights)");
-    if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, wsplit_halves(cfg->L) * sizeof(_Float16)), "hipMemset(split weights)");
+    if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMalloc(split weights)");
+    if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMemset(split weights)");
     if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
     if (!rc) for (int i = 0; i < MDGAT_STATUS_WORDS; ++i) h->host_error[i] = 0;
     if (!rc) rc = mdgat_check_hip(hipStreamCreateWithFlags(&h->lane_stream, hipStreamNonBlocking), "hipStreamCreate(lane)");
@@ -194,8 +199,14 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
         rc = launch_split_rows(lw + bl.mlp1_w, ls + WS_W1, 256, 256, WS_ROW256, 256, nullptr);
         if (!rc) rc = launch_split_rows(lw + bl.mlp2_w, ls + WS_W2, 128, 256, WS_ROW256, 128, nullptr);
         if (!rc) rc = launch_split_rows(lw + bl.qkv_w, ls + WS_QKV, 384, 128, WS_ROW128, 256, nullptr);
+        _Float16* lf = h->wsplit + wsplit_halves(h->cfg.L) + WF_LAYER * (size_t)i;
+        if (!rc) rc = launch_frag_image(ls + WS_W1, lf + WF_W1, 256, 256, WS_ROW256, nullptr);
+        if (!rc) rc = launch_frag_image(ls + WS_W2, lf + WF_W2, 128, 256, WS_ROW256, nullptr);
+        if (!rc) rc = launch_frag_image(ls + WS_QKV, lf + WF_QKV, 384, 128, WS_ROW128, nullptr);
     }
     if (!rc) rc = launch_split_rows(h->weights + bl.final_w, h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), 128, 128, WS_ROW128, 128, nullptr);
+    if (!rc) rc = launch_frag_image(h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L), h->wsplit + wsplit_halves(h->cfg.L) + WF_LAYER * (size_t)(2 * h->cfg.L),
+                                    128, 128, WS_ROW128, nullptr);
     {
         _Float16* es = h->wsplit + WS_LAYER * (size_t)(2 * h->cfg.L) + WS_FINAL;
         if (!rc) rc = launch_split_rows(h->weights + bl.kenc1_w, es, 64, 32, 64, 0, nullptr);
@@ -356,11 +367,13 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
     float* mdesc = ws.hid;
     const _Float16* wfinal = h->wsplit + WS_LAYER * (size_t)L2;
+    const _Float16* wfrag = h->wsplit + wsplit_halves(h->cfg.L);      // fragment-order copies (layer_split.hip)
+    const _Float16* ffinal = wfrag + WF_LAYER * (size_t)L2;
     {
         LayerLaunch p{};
         p.x = ws.x; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 0; p.guard = status_dev + MDGAT_STATUS_RANGE;
-        if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
-        else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
+        if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.w3f = wfrag + WF_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
+        else { p.mode3 = 2; p.w3s = wfinal; p.w3f = ffinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
         mark(MDGAT_PROF_LAYER_FIRST);
     }
@@ -383,8 +396,10 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1; p.guard = status_dev + MDGAT_STATUS_RANGE;
         p.w1s = ls + WS_W1; p.b1 = lw + bl.mlp1_b; p.w2s = ls + WS_W2; p.b2 = lw + bl.mlp2_b;
-        if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
-        else { p.mode3 = 2; p.w3s = wfinal; p.b3 = w + bl.final_b; }
+        const _Float16* lf = wfrag + WF_LAYER * (size_t)i;
+        p.w1f = lf + WF_W1; p.w2f = lf + WF_W2;
+        if (i + 1 < L2) { p.mode3 = 1; p.w3s = ls + WS_LAYER + WS_QKV; p.w3f = lf + WF_LAYER + WF_QKV; p.b3 = lw + bl.layer_stride + bl.qkv_b; }
+        else { p.mode3 = 2; p.w3s = wfinal; p.w3f = ffinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
         mark(i + 1 < L2 ? MDGAT_PROF_LAYER : MDGAT_PROF_LAYER_LAST);
         if (taps && taps->x_layers)

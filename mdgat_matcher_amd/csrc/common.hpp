@@ -164,6 +164,7 @@ int launch_qk_phase_probe(int B, int N, int M, int cross, int nq_sets, const Qkv
 struct LayerLaunch {
     float* x; const float* msg;
     const _Float16 *w1s, *w2s, *w3s;   // split weight images [rows][hi K | lo K | 8 pad]
+    const _Float16 *w1f, *w2f, *w3f;   // the same matrices in fragment order (launch_frag_image), read by layer_split.hip
     const float *b1, *b2, *b3;
     Qkv16 out;                         // mode3 == 1
     float* mdesc;                      // mode3 == 2
@@ -176,6 +177,8 @@ struct LayerLaunch {
 int launch_layer(const LayerLaunch& p, hipStream_t s);
 // rowh >= 2 K: row pitch (halves); the first nperm rows are written in the P/Q row order of layer.hip
 int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, int nperm, hipStream_t s);
+// row image [rows][rowh] (launch_split_rows) -> fragment order [rows / 16][K / 32][plane][lane = row l15 + 16 g][8 halves] (layer_split.hip)
+int launch_frag_image(const _Float16* img, _Float16* out, int rows, int K, int rowh, hipStream_t s);
 
 struct SkExtract {   // match extraction to run after (or fused into) the Sinkhorn kernel
     int mode; float thr;

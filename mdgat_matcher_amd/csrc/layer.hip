@@ -37,6 +37,7 @@
 #include <utility>
 #include <cstdlib>
 #include "common.hpp"
+#include "layer_image.hpp"
 #ifdef LAYER_TRACE
 __device__ long long g_dbg[8192];
 extern "C" int mdgat_debug_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), n * sizeof(long long)); }
@@ -60,11 +61,7 @@ __device__ __forceinline__ void trace_point(int slot) {
 #include "mma_chain.hpp"
 namespace {
 
-// LDS / image row pitch (halves): hi plane | lo plane | 32 B pad.  A ds_read_b128 is served in four groups of 16
-// lanes ({0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ...; MI355X guide, LDS section): with lane (row l15, 16-byte
-// column g) a pitch of 32 B mod 256 B puts the 16 lanes of every group on 16 different 16-byte bank groups.
-constexpr int ROWH256 = 528;                 // K = 256
-constexpr int ROWH128 = 272;                 // K = 128
+// (image row pitches ROWH256 / ROWH128 and the kernel arguments: layer_image.hpp)
 // A stage = 16 image rows of K = 256 (one row block, 16896 B) or 32 rows of K = 128 (one unit, 17408 B): 17 copies
 // of 1 KB.  Ring of NSLOT slots; stages are consumed in pairs (the two row blocks of a K = 256 unit, two K = 128 units)
 // with one barrier per pair; the copy of stage h + LOOKAHEAD is issued during stage h (the stage copies take
@@ -87,23 +84,6 @@ constexpr int VROW = 24;                     // halves per row of the V^T store 
 typedef f16x8 __attribute__((may_alias)) f16x8_a;
 typedef f16x4 __attribute__((may_alias)) f16x4_a;
 typedef f32x4 __attribute__((may_alias)) f32x4_a;
-
-struct LayerArgs {
-    float* x;               // [R][128] descriptors, updated in place by phase 2
-    const float* msg;       // [R][128] attention output (head-major channels)
-    const _Float16* w1s;    // [256][ROWH256] split image (rows in P/Q order)
-    const float* b1;        // [256]
-    const _Float16* w2s;    // [128][ROWH256]
-    const float* b2;        // [128]
-    const _Float16* w3s;    // [384][ROWH128] (q|k|v of the next layer; v rows in natural order) or [128][ROWH128] (final_proj)
-    const float* b3;        // [384] or [128]
-    _Float16* q16;          // outputs of phase 3 (mode 1)
-    _Float16* k16;
-    _Float16* vt16;
-    float* mdesc;           // [R][128] output of phase 3 (mode 2)
-    int R, N, M, Npad, PP;
-    unsigned* guard;        // optional, host-mapped: set when an input value is outside the f16 operand range or not finite
-};
 
 // One stage: chunk c (1 KB) is moved by wave c & 7; the LDS address comes from M0, the lanes supply consecutive
 // 16-byte pieces.  Inline asm: the compiler must not know that LDS is written (it would order every later ds_read
@@ -676,13 +656,21 @@ int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, 
     return mdgat_check_hip(hipGetLastError(), "split_rows launch");
 }
 
+// launches of at most this many 128-keypoint tiles run layer_split.hip (MDGAT_LAYER_SPLIT_TILES; 0: never)
+static std::atomic<int> g_split_tiles{[] { const char* e = getenv("MDGAT_LAYER_SPLIT_TILES"); return e ? atoi(e) : MDGAT_LAYER_SPLIT_TILES_DEFAULT; }()};
+extern "C" int mdgat_set_layer_split_tiles(int tiles) { return g_split_tiles.exchange(tiles < 0 ? MDGAT_LAYER_SPLIT_TILES_DEFAULT : tiles); }
+
 int launch_layer(const LayerLaunch& p, hipStream_t s) {
     if (p.R <= 0) return MDGAT_OK;
     LayerArgs a{};
     a.x = p.x; a.msg = p.msg;
     a.w1s = p.w1s; a.b1 = p.b1; a.w2s = p.w2s; a.b2 = p.b2; a.w3s = p.w3s; a.b3 = p.b3;
+    a.w1f = p.w1f; a.w2f = p.w2f; a.w3f = p.w3f;
     a.q16 = p.out.q16; a.k16 = p.out.k16; a.vt16 = p.out.vt16; a.mdesc = p.mdesc;
     a.R = p.R; a.N = p.N; a.M = p.M; a.Npad = p.out.Npad; a.PP = p.out.PP; a.guard = p.guard;
+    // launches of a few tiles (one pair, small batches): the channel-split kernel of layer_split.hip - 32-keypoint workgroups
+    // whose eight waves share the output channels; bit-identical results (mdgat_set_layer_split_tiles: tuning / A-B hook)
+    if ((p.R + 127) / 128 <= g_split_tiles.load(std::memory_order_relaxed)) return launch_layer_split(a, p.do_mlp, p.mode3, s);
     // small launches (fewer 128-keypoint tiles than half the CUs of the part): 64-keypoint workgroups, one wave per SIMD
     static const int small_tiles = [] { const char* e = getenv("MDGAT_LAYER_SMALL_TILES"); return e ? atoi(e) : 128; }();
     if ((p.R + 127) / 128 <= small_tiles) {

@@ -857,3 +857,39 @@ def test_weights_beyond_the_f16_range_are_refused():
         net.load_state_dict(sd3)
         with pytest.raises(RuntimeError, match='f16 operand range'):
             net.eval().to(DEV).match(*args)
+
+
+@pytest.mark.parametrize('B,n,m,L,k', [(1, 256, 256, 4, None), (1, 512, 512, 2, [128, None, 64, None]), (3, 100, 77, 2, [16, None, 8, None]),
+                                       (2, 37, 53, 1, []), (1, 1, 9, 1, []), (5, 130, 75, 2, []), (16, 512, 512, 1, [])])
+def test_layer_split_equals_layer_kernel(B, n, m, L, k):
+    """csrc/layer_split.hip (32-keypoint workgroups, output channels split over the waves: launches of a few tiles) against
+    csrc/layer.hip (a wave owns 16 keypoints): every stage tensor and every output of the forward bit for bit - the two kernels
+    run the same split-f16 products in the same order (mdgat.py:227-232, 246-248, 274, 397)."""
+    from mdgat_matcher_amd import _lib
+    lib = _lib.load()
+    cfg = synth.default_config(L=L, sinkhorn_iterations=10) if k is None else synth.default_config(L=L, k=k, sinkhorn_iterations=10)
+    net = MDGAT(cfg)
+    net.load_state_dict(synth.make_state_dict(L=L, seed=5))
+    net = net.eval().to(DEV)
+    data = synth.make_batch(B, n, m, first_pair=11, device=DEV)
+    P = n + m
+
+    def run():
+        taps = {'x_enc': torch.empty(B, P, 128, device=DEV), 'x_layers': torch.empty(2 * L, B, P, 128, device=DEV),
+                'mdesc': torch.empty(B, P, 128, device=DEV), 'scores': torch.empty(B, n, m, device=DEV)}
+        out = net._run(data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'],
+                       data['descriptors1'], want_Z=True, taps=taps)
+        torch.cuda.synchronize()
+        return [t.clone() for t in out] + [taps[key].clone() for key in ('x_layers', 'mdesc', 'scores')]
+
+    prev = lib.mdgat_set_layer_split_tiles(1 << 20)      # every launch on the channel-split kernel
+    try:
+        split = run()
+        lib.mdgat_set_layer_split_tiles(0)               # never
+        whole = run()
+    finally:
+        lib.mdgat_set_layer_split_tiles(prev)
+    net.check()                                         # raises on a range violation
+    for a, b in zip(split, whole):
+        assert torch.equal(a, b)
+    assert torch.isfinite(split[4]).all()
