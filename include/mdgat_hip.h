@@ -194,7 +194,7 @@ int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
 int mdgat_set_lanes(mdgat_handle* h, int lanes);
 
 /* Which kernel runs the layer tail (mlp + residual + next q|k|v; models/mdgat.py:227-232, 246-248, 274, 397) of a launch.
- * Launches of at most `tiles` tiles of 128 keypoints (default 16; MDGAT_LAYER_SPLIT_TILES in the environment) run the
+ * Launches of at most `tiles` tiles of 128 keypoints (default 64; MDGAT_LAYER_SPLIT_TILES in the environment) run the
  * channel-split kernel of csrc/layer_split.hip (32-keypoint workgroups, the eight waves share the output channels: the
  * latency shape, test.py:132 runs batch_size = 1), larger ones the keypoint-split kernels of csrc/layer.hip.  Process-wide;
  * results are bit-identical either way.  tiles = 0: never; tiles < 0: back to the default.  Returns the previous value. */
