@@ -41,9 +41,21 @@ struct CsLds {
 struct CAcc4 { f32x4 pm, px, qm, qx; };
 struct CAcc2 { f32x4 m, x; };
 
+// knock-outs (measurement builds: tools/ab_build.sh layer_cs <name> -DCS_KNOCK_MFMA | _FRAG | _WLOAD | _STORE): the kernel
+// without its matrix instructions / LDS fragment reads / weight loads beyond the first steps / global stores
 __device__ __forceinline__ f32x4 cmma(const f16x8& a, const f16x8& b, const f32x4& c) {
+#ifdef CS_KNOCK_MFMA
+    asm volatile("" :: "v"(a), "v"(b));
+    return c;
+#else
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#endif
 }
+#ifdef CS_KNOCK_STORE
+#define CS_STORE_OK(a) ((a).R == -12345)
+#else
+#define CS_STORE_OK(a) true
+#endif
 
 template <typename F, int... I>
 __device__ __forceinline__ void for_const_impl(F&& f, std::integer_sequence<int, I...>) { (f(std::integral_constant<int, I>{}), ...); }
@@ -63,6 +75,12 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
     float* bias3 = S.bias + 384;
     constexpr int NB3 = MODE3 == 1 ? 384 : 128;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // Two workgroups share a CU and do identical work: started together they stay in lockstep - both in their matrix
+    // instructions, then both in their epilogues.  The second resident of a CU (workgroups are dispatched breadth first: the
+    // first `stagger_mod` of them one per CU) starts late by `stagger` x ~3.9 us (s_sleep 127), once per launch.
+    if (a.stagger > 0 && ((blockIdx.x / a.stagger_mod) & 1)) {
+        for (int i = 0; i < a.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
 
     constexpr int S1 = DO_MLP ? 16 : 0, S2 = DO_MLP ? 8 : 0, S3 = MODE3 == 1 ? 8 : 4, NS = S1 + S2 + S3;
     constexpr int NF = MODE3 == 1 ? 6 : 4, S12 = S1 + S2, A3 = MODE3 == 1 ? CS_A6 : CS_A4;
@@ -79,6 +97,13 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
     // request the weight fragments of step s (nothing beyond the last step)
     auto wload = [&](auto sc) __attribute__((always_inline)) {
         constexpr int s = decltype(sc)::value;
+#ifdef CS_KNOCK_WLOAD
+        if constexpr (s < NS) {         // zero weights, no loads (the outputs are the biases: finite)
+#pragma unroll
+            for (int i = 0; i < NF; ++i) { f16x8 z = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(z)); W[s][i] = z; }
+            return;
+        }
+#endif
         if constexpr (s < S1) wunit(W[s], a.w1f, 8, s < 8 ? wave : wave + 4, s & 7);
         else if constexpr (s < S1 + S2) wunit(W[s], a.w2f, 8, wave, s - S1);
         else if constexpr (s < NS) {
@@ -98,7 +123,11 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
         if constexpr (s + A3 >= S12 && s + A3 < NS) wload(std::integral_constant<int, s + A3>{});
         __builtin_amdgcn_sched_barrier(0);
     };
+#ifdef CS_KNOCK_FRAG
+    auto frag_ld = [&](const _Float16* p) __attribute__((always_inline)) { f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0}; asm volatile("" : "+v"(v)); return v; };
+#else
     auto frag_ld = [&](const _Float16* p) __attribute__((always_inline)) { return *reinterpret_cast<const f16x8_c*>(p + lane * 8); };
+#endif
     auto frag_st = [&](_Float16* p, const f16x8& v) __attribute__((always_inline)) { *reinterpret_cast<f16x8_c*>(p + lane * 8) = v; };
 
     // ---- the first steps' weights, then this wave's share of the input rows: lane (keypoint l15, g) of wave w
@@ -240,7 +269,7 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
                 combine8(c2[kpb], pv);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) { pv[j] += pb[j]; pv[j] += res[kpb][j >> 2][j & 3]; }
-                if (gp < a.R) {
+                if (gp < a.R && CS_STORE_OK(a)) {
                     float* xr = a.x + (size_t)gp * 128 + 32 * wave + 8 * g;
                     *reinterpret_cast<f32x4*>(xr) = f32x4{pv[0], pv[1], pv[2], pv[3]};
                     *reinterpret_cast<f32x4*>(xr + 4) = f32x4{pv[4], pv[5], pv[6], pv[7]};
@@ -314,7 +343,7 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
                         l[j] = (_Float16)(pv[j] - (float)h[j]);
                     }
                     const int gp = pt0 + kpb * 16 + l15;
-                    if (gp < a.R) {
+                    if (gp < a.R && CS_STORE_OK(a)) {
                         *reinterpret_cast<f16x8*>(dst0 + (size_t)gp * 256) = h;
                         *reinterpret_cast<f16x8*>(dst0 + (size_t)gp * 256 + 32) = l;
                     }
@@ -330,7 +359,7 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
 #pragma unroll
                 for (int kpb = 0; kpb < CS_KPB; ++kpb) {
                     const int p0 = pt0 + kpb * 16 + 4 * g;
-                    if (p0 >= a.R) continue;
+                    if (p0 >= a.R || !CS_STORE_OK(a)) continue;
                     _Float16 h[4], l[4];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) mdgat_split_unscaled(fmaf(cv[kpb].x[r], MDGAT_SPLIT_INV, cv[kpb].m[r]) + bias, h[r], l[r]);
@@ -373,7 +402,7 @@ __global__ __launch_bounds__(64 * CS_NW, 2) void layer_cs_kernel(LayerArgs a) {
             combine8(c[kpb], pv);
 #pragma unroll
             for (int j = 0; j < 8; ++j) pv[j] += pb[j];
-            if (gp < a.R) {
+            if (gp < a.R && CS_STORE_OK(a)) {
                 float* dst = a.mdesc + (size_t)gp * 128 + 32 * wave + 8 * g;
                 *reinterpret_cast<f32x4*>(dst) = f32x4{pv[0], pv[1], pv[2], pv[3]};
                 *reinterpret_cast<f32x4*>(dst + 4) = f32x4{pv[4], pv[5], pv[6], pv[7]};
@@ -392,7 +421,11 @@ int launch_cs_t(const LayerArgs& a, hipStream_t s) {
 
 }  // namespace
 
-int launch_layer_cs(const LayerArgs& a, int do_mlp, int mode3, hipStream_t s) {
+int launch_layer_cs(const LayerArgs& a0, int do_mlp, int mode3, hipStream_t s) {
+    LayerArgs a = a0;
+    static const int stagger = [] { const char* e = getenv("MDGAT_CS_STAGGER"); return e ? atoi(e) : 0; }();
+    static const int stagger_mod = [] { const char* e = getenv("MDGAT_CS_STAGGER_MOD"); return e ? atoi(e) : 256; }();
+    a.stagger = stagger; a.stagger_mod = stagger_mod;
     if (do_mlp) return mode3 != 1 ? launch_cs_t<1, 2>(a, s) : launch_cs_t<1, 1>(a, s);
     return mode3 != 1 ? launch_cs_t<0, 2>(a, s) : launch_cs_t<0, 1>(a, s);
 }

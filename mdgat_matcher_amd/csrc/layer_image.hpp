@@ -25,6 +25,7 @@ struct LayerArgs {
     float* mdesc;           // [R][128] output of phase 3 (mode 2)
     int R, N, M, Npad, PP;
     unsigned* guard;        // optional, host-mapped: set when an input value is outside the f16 operand range or not finite
+    int stagger, stagger_mod;   // layer_cs.hip only
 };
 
 // layer_split.hip: the same layer for launches of a few tiles (one pair, small batches)
