@@ -658,8 +658,6 @@ int launch_split_rows(const float* w, _Float16* out, int rows, int K, int rowh, 
 
 // launches of at most this many 128-keypoint tiles run layer_split.hip (MDGAT_LAYER_SPLIT_TILES; 0: never)
 static std::atomic<int> g_split_tiles{[] { const char* e = getenv("MDGAT_LAYER_SPLIT_TILES"); return e ? atoi(e) : MDGAT_LAYER_SPLIT_TILES_DEFAULT; }()};
-static std::atomic<int> g_layer_cs{[] { const char* e = getenv("MDGAT_LAYER_CS"); return e ? atoi(e) : 0; }()};
-extern "C" int mdgat_set_layer_cs(int on) { return g_layer_cs.exchange(on); }
 extern "C" int mdgat_set_layer_split_tiles(int tiles) { return g_split_tiles.exchange(tiles < 0 ? MDGAT_LAYER_SPLIT_TILES_DEFAULT : tiles); }
 
 int launch_layer(const LayerLaunch& p, hipStream_t s) {
@@ -673,8 +671,6 @@ int launch_layer(const LayerLaunch& p, hipStream_t s) {
     // launches of a few tiles (one pair, small batches): the channel-split kernel of layer_split.hip - 32-keypoint workgroups
     // whose eight waves share the output channels; bit-identical results (mdgat_set_layer_split_tiles: tuning / A-B hook)
     if ((p.R + 127) / 128 <= g_split_tiles.load(std::memory_order_relaxed)) return launch_layer_split(a, p.do_mlp, p.mode3, s);
-    if (const int cs = g_layer_cs.load(std::memory_order_relaxed); cs == 1 || (cs == 2 && p.do_mlp) || (cs == 3 && !p.do_mlp) || (cs == 4 && p.do_mlp && p.mode3 == 2))
-        return launch_layer_cs(a, p.do_mlp, p.mode3, s);      // experiment: layer_cs.hip (2 - 4: debugging subsets)
     // small launches (fewer 128-keypoint tiles than half the CUs of the part): 64-keypoint workgroups, one wave per SIMD
     static const int small_tiles = [] { const char* e = getenv("MDGAT_LAYER_SMALL_TILES"); return e ? atoi(e) : 128; }();
     if ((p.R + 127) / 128 <= small_tiles) {

@@ -25,11 +25,8 @@ struct LayerArgs {
     float* mdesc;           // [R][128] output of phase 3 (mode 2)
     int R, N, M, Npad, PP;
     unsigned* guard;        // optional, host-mapped: set when an input value is outside the f16 operand range or not finite
-    int stagger, stagger_mod;   // layer_cs.hip only
 };
 
 // layer_split.hip: the same layer for launches of a few tiles (one pair, small batches)
 constexpr int MDGAT_LAYER_SPLIT_TILES_DEFAULT = 64;   // measured (tools/split_threshold.sh, N = M = 512): wins up to 64 tiles (B = 8), ties at 96-128, loses beyond
 int launch_layer_split(const LayerArgs& a, int do_mlp, int mode3, hipStream_t s);
-// layer_cs.hip (experiment): the channel-split layer for large launches, 64-keypoint workgroups, two per CU
-int launch_layer_cs(const LayerArgs& a, int do_mlp, int mode3, hipStream_t s);
