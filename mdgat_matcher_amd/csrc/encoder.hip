@@ -40,26 +40,23 @@ constexpr int OFF_END = OFF_EL + 2 * 32 * RH256;   // then fp32: kenc0 w [32][4]
 
 // Eight waves = 256 keypoints per workgroup, one workgroup per CU (the weights fill the LDS): two waves per SIMD, so that one
 // wave's matrix instructions run beside the other's loads, splits and 32-byte row stores (four waves: 64 -> see DESIGN.md)
-// Small launches (one pair, small batches: fewer 256-keypoint tiles than a quarter of the CUs) run 64-keypoint workgroups of two
-// waves instead - four times the workgroups, and a wave that has its SIMD to itself walks its chain of 318 products sooner.
-constexpr int ENC_THREADS = 512, ENC_THREADS_SMALL = 128;
+constexpr int ENC_THREADS = 512;
 // copy `rows` rows of 2K halves (contiguous in memory) into padded LDS rows
-template <int K, int NT>
+template <int K>
 __device__ __forceinline__ void copy_rows(const _Float16* g, _Float16* dst, int rows, int tid) {
     constexpr int CPR = 2 * K * 2 / 16, ROWH = 2 * K + 8;
-    for (int c = tid; c < rows * CPR; c += NT)
+    for (int c = tid; c < rows * CPR; c += ENC_THREADS)
         *reinterpret_cast<f32x4*>(dst + (c / CPR) * ROWH + (c % CPR) * 8) = *reinterpret_cast<const f32x4*>(g + (size_t)c * 8);
 }
 
-template <int NT>
-__global__ __launch_bounds__(NT, NT == 512 ? 2 : 1) void encoder_kernel(EncArgs a) {
+__global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int wrow = perm32(l31);
-    const int pt = min(blockIdx.x * (NT / 2) + wave * 32 + l31, a.R - 1);
+    const int pt = min(blockIdx.x * (ENC_THREADS / 2) + wave * 32 + l31, a.R - 1);
     float* fl = reinterpret_cast<float*>(smem + OFF_END);
     float* k0w = fl;            // [32][4]
     float* k0b = fl + 128;      // [32]
@@ -70,11 +67,11 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 1) void encoder_kernel(EncArgs 
     float* bel = fl + 544;      // [128]
 
     // ---- stage every weight but the last product's, the first two row blocks of the last one, the biases ----
-    copy_rows<32, NT>(a.k1s, smem + OFF_K1, 64, tid);
-    copy_rows<64, NT>(a.k2s, smem + OFF_K2, 128, tid);
-    copy_rows<48, NT>(a.d0s, smem + OFF_D0, 64, tid);
-    copy_rows<64, NT>(a.d1s, smem + OFF_D1, 128, tid);
-    copy_rows<256, NT>(a.els, smem + OFF_EL, 64, tid);
+    copy_rows<32>(a.k1s, smem + OFF_K1, 64, tid);
+    copy_rows<64>(a.k2s, smem + OFF_K2, 128, tid);
+    copy_rows<48>(a.d0s, smem + OFF_D0, 64, tid);
+    copy_rows<64>(a.d1s, smem + OFF_D1, 128, tid);
+    copy_rows<256>(a.els, smem + OFF_EL, 64, tid);
     if (tid < 128) k0w[tid] = a.w[a.kenc0_w + tid];
     if (tid < 32) k0b[tid] = a.w[a.kenc0_b + tid];
     if (tid < 64) { bk1[tid] = a.w[a.kenc1_b + tid]; bd0[tid] = a.w[a.denc0_b + tid]; }
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(NT, NT == 512 ? 2 : 1) void encoder_kernel(EncArgs 
     for (int ob = 0; ob < 4; ++ob) {
         if (ob == 2) {
             __syncthreads();                 // blocks 0 and 1 consumed by every wave
-            copy_rows<256, NT>(a.els + (size_t)64 * 512, smem + OFF_EL, 64, tid);
+            copy_rows<256>(a.els + (size_t)64 * 512, smem + OFF_EL, 64, tid);
             __syncthreads();
         }
         f32x16 o;
@@ -243,15 +240,8 @@ int launch_encoder(const EncoderLaunch& p, hipStream_t s) {
     a.k1s = p.es; a.k2s = a.k1s + 64 * 64; a.d0s = a.k2s + 128 * 128; a.d1s = a.d0s + 64 * 96; a.els = a.d1s + 128 * 128;
     a.x = p.x; a.B = p.B; a.N = p.N; a.M = p.M; a.R = p.B * (p.N + p.M);
     const size_t lds = (size_t)OFF_END * sizeof(_Float16) + 672 * sizeof(float);
-    static const int small_tiles = [] { const char* e = getenv("MDGAT_ENCODER_SMALL_TILES"); return e ? atoi(e) : 64; }();
-    if ((a.R + 255) / 256 <= small_tiles) {
-        static std::atomic<unsigned long long> optin;
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(encoder_kernel<ENC_THREADS_SMALL>), lds, optin, "encoder LDS attribute")) return rc;
-        hipLaunchKernelGGL(encoder_kernel<ENC_THREADS_SMALL>, dim3((a.R + ENC_THREADS_SMALL / 2 - 1) / (ENC_THREADS_SMALL / 2)), dim3(ENC_THREADS_SMALL), lds, s, a);
-    } else {
-        static std::atomic<unsigned long long> optin;
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(encoder_kernel<ENC_THREADS>), lds, optin, "encoder LDS attribute")) return rc;
-        hipLaunchKernelGGL(encoder_kernel<ENC_THREADS>, dim3((a.R + ENC_THREADS / 2 - 1) / (ENC_THREADS / 2)), dim3(ENC_THREADS), lds, s, a);
-    }
+    static std::atomic<unsigned long long> optin;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(encoder_kernel), lds, optin, "encoder LDS attribute")) return rc;
+    hipLaunchKernelGGL(encoder_kernel, dim3((a.R + ENC_THREADS / 2 - 1) / (ENC_THREADS / 2)), dim3(ENC_THREADS), lds, s, a);
     return mdgat_check_hip(hipGetLastError(), "encoder launch");
 }
