@@ -713,15 +713,18 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
     }
 }
 
-// Dynamic attention for exactly 512 keys per frame, one wave = 16 queries, no cross-wave traffic at all:
+// Dynamic attention for exactly NKEY = 512 (or 256: one pair of 256 keypoints, BASELINE configs[0]) keys per frame, one wave = 16
+// queries, no cross-wave traffic at all:
 // S^T = K Q^T on v_mfma_f32_16x16x32_f16 (the whole 32-dim head in one k-step) puts the logits of a query in the
 // four lanes (q, q + 16, q + 32, q + 48): lane (q, g) holds keys 16 b + 4 g + r of every 16-key block b, 128 registers
-// for 512 keys, two waves per SIMD.  Row statistics and top-k counts are two lane shuffles (QuadComm), so the 8 waves
+// for 512 keys (64 for 256), two waves per SIMD.  Row statistics and top-k counts are two lane shuffles (QuadComm), so the 8 waves
 // of the workgroup search independently.  K sits in LDS as [plane][dim chunk g][key] 16-byte units (conflict free for
 // this fragment shape), V^T as in the other kernels; P.V pairs two key blocks per k-step.
 // FAST (mdgat_attention_mode F16): hi planes only, one MFMA per product.
-template <bool FAST, bool TAP = false>
+template <bool FAST, bool TAP = false, int NKEY = 512>
 __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
+    static_assert(NKEY == 512 || NKEY == 256, "whole 64-key register blocks, at most 128 logit registers");
+    constexpr int NC = NKEY / 64;           // f32x16 logit registers blocks per lane
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -732,18 +735,18 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     const int nq = side ? a.M : a.N;
     const int q_off = side ? a.N : 0;
     const int src = a.cross ? (1 - side) : side;
-    const int nk = 512;
+    const int nk = NKEY;
     const int k_off = src ? a.N : 0;
-    constexpr int VSTR = 512 + 8;
+    constexpr int VSTR = NKEY + 8;
 
     // K: [512 keys][8 chunks of 16 B: hi dims 0-7, 8-15, 16-23, 24-31, lo ...], chunk c of key k stored at position
     // c ^ (k & 7): the staging writes (8 lanes = the 8 chunks of a key) and the fragment reads (lane = (key, chunk))
     // are both free of bank conflicts for the lane groups the LDS serves together
     _Float16* Ks = smem;
-    _Float16* Vs = smem + 2 * 4 * 512 * 8;        // [2 planes][32 dims][VSTR]
+    _Float16* Vs = smem + 2 * 4 * NKEY * 8;       // [2 planes][32 dims][VSTR]
     {
         const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;
-        for (int base = tid; base < 512 * 8; base += 4 * 512) {
+        for (int base = tid; base < NKEY * 8; base += 4 * 512) {
             f32x4 x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -758,17 +761,18 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             }
         }
         const _Float16* vg = a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0);
-        for (int base = tid; base < 64 * 64; base += 4 * 512) {
+        constexpr int CPR = NKEY / 8;       // 16-byte pieces per V^T row
+        for (int base = tid; base < 64 * CPR; base += 4 * 512) {
             f32x4 x[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * 512;
-                x[u] = *reinterpret_cast<const f32x4*>(vg + (size_t)(idx >> 6) * a.PP + (idx & 63) * 8);
+                x[u] = *reinterpret_cast<const f32x4*>(vg + (size_t)(idx / CPR) * a.PP + (idx % CPR) * 8);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int idx = base + u * 512;
-                *reinterpret_cast<f32x4*>(Vs + (idx >> 6) * VSTR + (idx & 63) * 8) = x[u];
+                *reinterpret_cast<f32x4*>(Vs + (idx / CPR) * VSTR + (idx % CPR) * 8) = x[u];
             }
         }
     }
@@ -804,13 +808,12 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         const int qw = qw_next;
         if (qw < 0) break;                  // wave-uniform; no barrier inside the loop
         f16x8 qh = qh_next, ql = ql_next;
-        // ---- S^T: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
+        // ---- S^T: NKEY / 16 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r ----
         const _Float16* kfrag_h = Ks + l15 * 64 + (g ^ (l15 & 7)) * 8;
         const _Float16* kfrag_l = Ks + l15 * 64 + ((4 + g) ^ (l15 & 7)) * 8;
-        // logits of the tile: 32 blocks of 16 keys; S[c][4 j + r] = logit of key 16 (4 c + j) + 4 g + r
-        auto logits = [&](f32x16 (&S)[8]) {
+        auto logits = [&](f32x16 (&S)[NC]) {
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
+            for (int c = 0; c < NC; ++c) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int blk = 4 * c + j;
@@ -830,16 +833,16 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
                 }
             }
         };
-        f32x16 S[8];
+        f32x16 S[NC];
         logits(S);
         float m = -__builtin_inff();
 #pragma unroll
-        for (int c = 0; c < 8; ++c)
+        for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[c][r]);
         m = comm.rmax(m);
         bool near_row = false;
-        const float thr = topk_threshold<8, true>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
+        const float thr = topk_threshold<NC, true>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
         if (near_row && g == 0 && qw + l15 < nq) near_append(a, b, side, head, qw + l15, thr, m);      // -> repair list (rare)
         if (TAP) {
             // the selection the tap records is final: count and break exact ties at the k-th place before the pass
@@ -847,7 +850,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             if (!a.near_count) {
                 int c = 0;
 #pragma unroll
-                for (int jb = 0; jb < 8; ++jb)
+                for (int jb = 0; jb < NC; ++jb)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
                 topk_break_ties<KeyLayout16>(S, thr, comm.rsum(c) - a.topk, comm, 4 * g);
@@ -855,7 +858,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
             if (qw + l15 < nq) {
                 uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l15) * a.selW;
 #pragma unroll
-                for (int c2 = 0; c2 < 8; ++c2)
+                for (int c2 = 0; c2 < NC; ++c2)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         unsigned bits = 0;
@@ -875,7 +878,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) Om[t] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
+        for (int c = 0; c < NC; ++c) {
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {             // key blocks 4 c + 2 jj and 4 c + 2 jj + 1
                 float p[8], s8[8];
@@ -1345,31 +1348,31 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
         hipLaunchKernelGGL(kern, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(threads), lds, s, a);
     };
     const bool mult32 = (N % 32 == 0) && (M % 32 == 0);
+    // exactly 512 (or 256) keys in both frames: one wave = 16 queries, the row in four lanes
+    auto launch16 = [&](auto nkc) {
+        constexpr int NKEY = decltype(nkc)::value;
+        int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
+        if (qsplit > 4) qsplit = 4;
+        const size_t lds3 = ((size_t)2 * 4 * NKEY * 8 + (size_t)64 * (NKEY + 8)) * sizeof(_Float16) + 16;    // + the tile counter
+        auto run = [&](auto kern) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
+            hipLaunchKernelGGL(kern, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+        };
+        if (a.sel) { if (mode == 1) run(attention_topk16_kernel<true, true, NKEY>); else run(attention_topk16_kernel<false, true, NKEY>); }
+        else if (mode == 1) run(attention_topk16_kernel<true, false, NKEY>);
+        else run(attention_topk16_kernel<false, false, NKEY>);
+    };
     if (dyn) {
         // the whole row in one chunk
-        if (a.sel && !(N == 512 && M == 512) && nblk <= 16) {
+        if (N == 256 && M == 256) launch16(std::integral_constant<int, 256>{});
+        else if (a.sel && !(N == 512 && M == 512) && nblk <= 16) {
             if (nblk <= 4) go(attention_kernel<true, 4, false, false, true>, 512);
-            else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false, true>, 512); else go(attention_kernel<true, 8, false, false, true>, 512); }
+            else if (nblk <= 8) go(attention_kernel<true, 8, false, false, true>, 512);
             else go(attention_kernel<true, 16, false, false, true>, 256);
         } else if (nblk <= 4) go(attention_kernel<true, 4, false, false>, 512);
-        else if (nblk <= 8) { if (mult32 && N == 256 && M == 256) go(attention_kernel<true, 8, true, false>, 512); else go(attention_kernel<true, 8, false, false>, 512); }
-        else if (N == 512 && M == 512) {
-            // 512 keys in both frames: one wave = 16 queries, the row in four lanes
-            int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
-            if (qsplit > 4) qsplit = 4;
-            const size_t lds3 = ((size_t)2 * 4 * 512 * 8 + (size_t)64 * 520) * sizeof(_Float16) + 16;    // + the tile counter
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            if (a.sel) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(attention_topk16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-                if (mode == 1) hipLaunchKernelGGL((attention_topk16_kernel<true, true>), dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
-                else hipLaunchKernelGGL((attention_topk16_kernel<false, true>), dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
-            } else if (mode == 1) hipLaunchKernelGGL(attention_topk16_kernel<true>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
-            else hipLaunchKernelGGL(attention_topk16_kernel<false>, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
-        } else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
+        else if (nblk <= 8) go(attention_kernel<true, 8, false, false>, 512);
+        else if (N == 512 && M == 512) launch16(std::integral_constant<int, 512>{});
+        else if (nblk <= 16) go(attention_kernel<true, 16, false, false>, 256);
         else return launch_attention_topk_wide(a, B, nk_max, s);
     } else {
         // chunks of 8 blocks (256 keys), two waves per SIMD

@@ -101,7 +101,7 @@ __device__ __forceinline__ void offer(NearRow& R, int key, float s, float thr) {
     if (pos < NEAR_MAXC) { R.key[pos] = (unsigned)key | (s >= thr ? 0x80000000u : 0u); R.s[pos] = s; }
 }
 
-// The logits of row r.q's query tile again, as the attention kernel formed them (M16: frames of exactly 512 keys -
+// The logits of row r.q's query tile again, as the attention kernel formed them (M16: frames of exactly 512 or 256 keys -
 // attention_topk16_kernel, 16-query tiles, 16x16x32 products; else the 32-query tiles and 32x32x16 products of
 // attention_kernel / attention_topk_wide_kernel), handed to f(key, logit) by the lanes that hold the row.
 template <bool M16, typename F>
@@ -126,7 +126,7 @@ __device__ __forceinline__ void row_logits(const RepairArgs& a, const RepairRec&
         }
         const _Float16* kbase = a.k16 + (((size_t)b * P + k_off + l15) * 4 + head) * 64 + 8 * g;
 #pragma unroll 1
-        for (int half = 0; half < 2; ++half) {          // 16 blocks of 16 keys per batch of loads
+        for (int half = 0; half < nk / 256; ++half) {   // 16 blocks of 16 keys per batch of loads (nk = 512 or 256)
             f16x8 kh[16], kl[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -322,8 +322,8 @@ int launch_topk_repair(const RepairLaunch& p, hipStream_t s) {
     int blocks = (int)((rows / 256 + RP_WAVES - 1) / RP_WAVES);
     if (blocks < 4) blocks = 4;
     if (blocks > 1024) blocks = 1024;
-    // which fragments the attention kernel formed (launch_attention: the 512-key kernel for N = M = 512)
-    if (p.N == 512 && p.M == 512) hipLaunchKernelGGL(topk_repair_kernel<true>, dim3(blocks), dim3(64 * RP_WAVES), 0, s, a);
+    // which fragments the attention kernel formed (launch_attention: the 16-query kernel for N = M = 512 and N = M = 256)
+    if ((p.N == 512 && p.M == 512) || (p.N == 256 && p.M == 256)) hipLaunchKernelGGL(topk_repair_kernel<true>, dim3(blocks), dim3(64 * RP_WAVES), 0, s, a);
     else hipLaunchKernelGGL(topk_repair_kernel<false>, dim3(blocks), dim3(64 * RP_WAVES), 0, s, a);
     return mdgat_check_hip(hipGetLastError(), "top-k repair launch");
 }
