@@ -1351,8 +1351,11 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
     // exactly 512 (or 256) keys in both frames: one wave = 16 queries, the row in four lanes
     auto launch16 = [&](auto nkc) {
         constexpr int NKEY = decltype(nkc)::value;
+        // a workgroup is 8 waves = 8 query tiles per pass: NKEY / 128 workgroups per (pair, frame, head) keep every wave busy;
+        // more (every workgroup stages all keys: up to 4, half the waves idle at 256 keys) only while the launch is smaller than the part
         int qsplit = (512 + B * 2 * MDGAT_HEADS - 1) / (B * 2 * MDGAT_HEADS);
-        if (qsplit > 4) qsplit = 4;
+        const int qmax = B * 2 * MDGAT_HEADS * (NKEY / 128) >= 256 ? NKEY / 128 : 4;
+        if (qsplit > qmax) qsplit = qmax;
         const size_t lds3 = ((size_t)2 * 4 * NKEY * 8 + (size_t)64 * (NKEY + 8)) * sizeof(_Float16) + 16;    // + the tile counter
         auto run = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
