@@ -25,8 +25,14 @@ __device__ long long g_sk_trace[2 * 8 * 12];
 extern "C" int mdgat_sk_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sk_trace), n * sizeof(long long)); }
 #define SK_TP(k) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7) && it >= 40 && it < 48) \
     g_sk_trace[((wave == 7) * 8 + (it - 40)) * 12 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// coarse phases of the whole kernel (workgroup 0, waves 0 and 7; tools/sinkhorn_phases.py): start | scores loaded | row maxima
+// absorbed | XCD handshake | iterations done | Z rows + row arg-maxes | end
+__device__ long long g_sk_phase[2 * 8];
+extern "C" int mdgat_sk_phase_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sk_phase), n * sizeof(long long)); }
+#define SK_PH(k) do { if (blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) g_sk_phase[(wave == 7) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define SK_TP(k) do {} while (0)
+#define SK_PH(k) do {} while (0)
 #endif
 namespace {
 
@@ -446,6 +452,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
 
     for (int pair = group; pair < a.B; pair += a.ngroups) {
         const float* S = a.scores + (size_t)pair * N * M;
+        SK_PH(0);
         // ---- this lane's RPW x 8 block of scores (base-2 log units); invalid entries -> exp2 gives 0 ----
         float K[RPW][8];
         const bool vec_ok = (M & 3) == 0 && gcol0 + 8 <= M;
@@ -463,6 +470,11 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     K[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
                     K[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
                 }
+            } else if (gcol0 >= M) {
+                // a lane whose eight columns all lie beyond M loads nothing (M = 256: half of every wave - as clamped scalar
+                // loads, 128 per lane, they cost the launch of one pair 10 us: tools/sinkhorn_phases.py)
+#pragma unroll
+                for (int c = 0; c < 8; ++c) K[r][c] = NEG_BIG;
             } else {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
@@ -473,6 +485,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
         }
         if (a.range_guard && gmax >= 0x7f800000u) __hip_atomic_store(a.range_guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        SK_PH(1);
         // ---- absorb the row maximum (all column slabs, dustbin column included): every row of K has largest entry <= 1 ----
         float u0r = 0.f, kbr = 0.f, ar = 0.f;     // lane r: absorbed potential, dustbin-column entry, scaling of row r
         {
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         // state of the columns this thread finalises: local column tid (global 512 jc + tid); thread 0 also the dustbin column
         const bool tcol_valid = jc * 512 + tid < M;
         float krt = 1.f, v0t = 0.f, bt = 1.f;
+        SK_PH(2);
         __syncthreads();                  // previous pair's readers of the LDS vectors are done
         if (tid == 0) flags[0] = 0;
         // do all row-slab partners of this pair sit on one XCD?  (slot 513 of the parity-0 buffer, agent scope)
@@ -548,6 +562,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             same_xcd = flags[1] != 0;
         }
 
+        SK_PH(3);
         for (int it = 0; it < a.iters; ++it) {
             // ---- row update (mdgat.py:283): a_i = mu_i / sum_j K_ij b_j ----
             SK_TP(0);
@@ -734,6 +749,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
             }
         }
 
+        SK_PH(4);
         // ---- Z = couplings + u + v - norm (mdgat.py:285, 307), natural-log units; fused arg-max ----
         float* Zp = a.Z ? a.Z + (size_t)pair * (N + 1) * (M + 1) : nullptr;
         const bool partner_lost = (__hip_atomic_load(a.error_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) != 0 ||
@@ -826,6 +842,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 }
             }
         }
+        SK_PH(5);
         const float UN = ran ? u0N + lg2(aN) : 0.f;
         const float zNt = (alpha + UN + (ran ? v0t + lg2(bt) + poison : 0.f)) * MDGAT_LN2 - norm;   // Z[N][512 jc + tid]
         if (last_r && Zp) {
@@ -858,6 +875,7 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 a.cbest_idx[((size_t)pair * GR + jr) * M + jc * 512 + tid] = bi;
             }
         }
+        SK_PH(6);
     }
 }
 
