@@ -198,6 +198,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-dict-api', action='store_true', help='skip the forward(dict) throughput leg')
+    ap.add_argument('--no-latency', action='store_true', help='skip the one-pair-per-call latency block')
     ap.add_argument('--exact-topk', action='store_true', help='mdgat_config.exact_topk (exact re-decision of near-threshold top-k rows)')
     args = ap.parse_args()
 
@@ -319,6 +320,34 @@ def main():
                 sync()
                 out['dict_api'] = {'pairs_per_s': B * k_steps / (time.perf_counter() - t0), 'steps': k_steps, 'n_gpus': 1,
                                    'note': 'rank 0 only: net(dict) as test.py:201 calls it - one host synchronisation per call'}
+        if not stub and not args.no_latency and B > 1:
+            # ms per pair when the matcher is called the way test.py:132 calls it - ONE pair per call (batch_size = 1) - on the
+            # same network: the asynchronous _run back to back, and the dict API with its host synchronisation.  The other half
+            # of BASELINE.json's metric ("keypoint-pairs/sec + ms/pair"); never `value`.
+            one = synth.make_batch(1, n, n, first_pair=first, dtype=torch.float32, device=dev)
+            one_in = (one['keypoints0'], one['scores0'], one['descriptors0'], one['keypoints1'], one['scores1'], one['descriptors1'])
+            with torch.no_grad():
+                for _ in range(10):
+                    net._run(*one_in)
+                sync()
+                reps = []
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    for _ in range(50):
+                        net._run(*one_in)
+                    sync()
+                    reps.append((time.perf_counter() - t0) / 50)
+                for _ in range(3):
+                    net(one)
+                t0 = time.perf_counter()
+                for _ in range(30):
+                    net(one)
+                sync()
+                t_dict = (time.perf_counter() - t0) / 30
+            out['latency'] = {'pairs_per_call': 1, 'ms_per_pair': 1e3 * sorted(reps)[len(reps) // 2], 'ms_per_pair_dict_api': 1e3 * t_dict,
+                              'note': f'one pair per call (test.py:132 runs batch_size = 1), N=M={n}, L={L}, {S} Sinkhorn iterations: '
+                                      'median of 5 loops of 50 back-to-back asynchronous forwards; dict API = net(dict) with its host '
+                                      'synchronisation per call'}
         if not args.no_breakdown:
             rows = kernel_breakdown(net, dev, inputs, B, n, L, S)
             nsl = next((r['launches_per_step'] for r in rows if r['kernel'] == 'sinkhorn'), 1)

@@ -9,7 +9,8 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CLASSES = (('layer_kernelILi0ELi1E', 'layer_first'), ('layer_kernelILi1ELi1E', 'layer'), ('layer_kernelILi1ELi2E', 'layer_last'),
+CLASSES = (('layer_split_kernelILi0ELi1E', 'layer_first'), ('layer_split_kernelILi1ELi1E', 'layer'), ('layer_split_kernelILi1ELi2E', 'layer_last'),
+           ('layer_kernelILi0ELi1E', 'layer_first'), ('layer_kernelILi1ELi1E', 'layer'), ('layer_kernelILi1ELi2E', 'layer_last'),
            ('attention_stream_kernel', 'attention_full'), ('attention_topk', 'attention_topk'), ('attention_kernelILb1E', 'attention_topk'),
            ('attention_kernelILb0E', 'attention_full'), ('sinkhorn_scaling_kernel', 'sinkhorn'), ('scores_kernel', 'scores'),
            ('encoder_kernel', 'encoder'), ('extract_kernel', 'extract'))

@@ -7,13 +7,13 @@ TAG=${1:-rX}
 CONFIG=${CONFIG:-1}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 python bench.py --config $CONFIG --steps 20 --warmup 5 $BENCH_ARGS 2>/dev/null | tail -1 > $O/${TAG}_bench_line.json
-CMD="python $R/bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown $BENCH_ARGS"
+CMD="python $R/bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown --no-latency $BENCH_ARGS"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pr_stats && rocprofv3 --kernel-trace --stats -d /tmp/pr_stats -o s -- $CMD > /dev/null 2>&1
-( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown $BENCH_ARGS"; cd $R; python tools/rocpd_summary.py /tmp/pr_stats/s_results.db ) > $O/${TAG}_bench_kernel_stats.txt 2>&1
+( echo "# rocprofv3 --kernel-trace --stats -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown --no-latency $BENCH_ARGS"; cd $R; python tools/rocpd_summary.py /tmp/pr_stats/s_results.db ) > $O/${TAG}_bench_kernel_stats.txt 2>&1
 # the same command with every kernel of the batch on one stream (no two launches overlap: what bench.py's `roofline` block measures)
 rm -rf /tmp/pr_stats1 && MDGAT_FORWARD_LANES=1 rocprofv3 --kernel-trace --stats -d /tmp/pr_stats1 -o s -- $CMD > /dev/null 2>&1
-( echo "# MDGAT_FORWARD_LANES=1 rocprofv3 --kernel-trace --stats -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown $BENCH_ARGS"; cd $R; python tools/rocpd_summary.py /tmp/pr_stats1/s_results.db ) > $O/${TAG}_single_lane_bench_kernel_stats.txt 2>&1
+( echo "# MDGAT_FORWARD_LANES=1 rocprofv3 --kernel-trace --stats -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown --no-latency $BENCH_ARGS"; cd $R; python tools/rocpd_summary.py /tmp/pr_stats1/s_results.db ) > $O/${TAG}_single_lane_bench_kernel_stats.txt 2>&1
 ( echo "# rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) -- python bench.py --config $CONFIG --steps 5 --warmup 2 --no-cpu-baseline --no-breakdown $BENCH_ARGS; KB per launch, averages" ) > $O/${TAG}_pmc_fetch_write_kb.txt
 for pass in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_LDS_BANK_CONFLICT"; do
   n=$(echo $pass | cut -d' ' -f1)
