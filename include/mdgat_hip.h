@@ -162,6 +162,12 @@ int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* fram
  * call; the results are valid.  The reference has no counterpart (ATen raises nothing either: it returns inf / NaN). */
 int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation);
 
+/* After the caller's synchronisation: *matched = 1 when the LAST forward enqueued on this handle matched at least one frame-0
+ * keypoint anywhere in its batch (matches0 >= 0), else 0.  This is the reference's host-side test `valid0.sum() == 0`
+ * (models/mdgat.py:464-467: integer zero scores when nothing matched) without a reduction kernel and a device-to-host copy: the
+ * extraction kernels write the call's token into a host-mapped word.  Per handle, like the status words above. */
+int mdgat_matched_any(mdgat_handle* h, unsigned* matched);
+
 /* Per-kernel-class timing of mdgat_forward, measured with HIP events on the launch stream (bench.py's
  * roofline leg).  mdgat_profile(h, enable, ms, launches) returns the time (ms) and launch count
  * accumulated per class since the previous call in ms[MDGAT_PROF_CLASSES] / launches[...] (either may

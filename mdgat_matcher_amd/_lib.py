@@ -60,6 +60,7 @@ SIGNATURES = {
     'mdgat_forward_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
                              [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_async_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
+    'mdgat_matched_any': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
     'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     'mdgat_set_lanes': (C.c_int, [C.c_void_p, C.c_int]),
     'mdgat_set_layer_split_tiles': (C.c_int, [C.c_int]),

@@ -63,7 +63,9 @@ struct mdgat_handle {
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     bool loaded;
     bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk (or MDGAT_TOPK_REPAIR in the environment), fp32 attention mode
-    unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard
+    unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard,
+                          // token of the last forward that matched a frame-0 keypoint
+    unsigned match_token; // the running forward's token (a new one per mdgat_forward / mdgat_forward_frames call, never 0)
     // Two lanes (forward_batched): the second lane's stream and the events that fork it off the caller's stream and join it again
     int lanes;            // 1 or 2 (mdgat_set_lanes; default 2, MDGAT_FORWARD_LANES)
     hipStream_t lane_stream;
@@ -119,6 +121,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
         h->repair = (e ? atoi(e) != 0 : cfg->exact_topk != 0) && cfg->attention_mode == MDGAT_ATTENTION_FP32;
     }
     h->host_error = nullptr;
+    h->match_token = 0;
     h->prof_on = false;
     h->lane_stream = nullptr;
     h->ev_fork = h->ev_join = nullptr;
@@ -421,7 +424,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     // (Z is only materialised when the caller asks for it or the streaming Sinkhorn needs it for the extraction)
     const bool fused = ws.sk_bytes != 0;   // N, M <= 2048: the cluster kernel, arg-maxes fused
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
-    const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust};
+    const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust,
+                       status_dev + MDGAT_STATUS_MATCHED, h->match_token};
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, status_dev,
                               Z ? Z : ws.Z, sk_clear != 0))) return rc;
     mark(MDGAT_PROF_SINKHORN);
@@ -515,6 +519,7 @@ static int forward_batched(mdgat_handle* h, int B, int N, int M, const float* kp
     LanePlan p{1, B, 1, 0};
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     std::lock_guard<std::mutex> serialise(h->enqueue);
+    if (++h->match_token == 0) h->match_token = 1;      // this call's token (mdgat_matched_any): every slice / lane of the call writes the same one
     if (!taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M);
     if (p.nslices <= 1) {
         const int rc = forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
@@ -586,6 +591,14 @@ extern "C" int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn
                         "the calls since the last check are invalid (this checkpoint / input does not fit the split-f16 arithmetic)");
         return MDGAT_ERR_UNSUPPORTED;
     }
+    return MDGAT_OK;
+}
+
+extern "C" int mdgat_matched_any(mdgat_handle* h, unsigned* matched) {
+    if (!h || !matched) { mdgat_set_error("mdgat_matched_any: null argument"); return MDGAT_ERR_BAD_ARG; }
+    // the extraction kernels of the LAST forward enqueued on this handle write that call's token when a frame-0 keypoint is
+    // matched (host-mapped word; stream order makes the last call's write the last one)
+    *matched = static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_MATCHED] == h->match_token ? 1u : 0u;
     return MDGAT_OK;
 }
 

@@ -186,11 +186,15 @@ struct SkExtract {   // match extraction to run after (or fused into) the Sinkho
     float *s0, *s1;
     int defer_alldust;   // the batch-wide "no keypoint of frame 0 matched" rule (mdgat.py:465-467) is applied later by
                          // launch_alldust_fixup() over the whole batch (the forward runs large batches in slices)
+    unsigned* matched;   // optional (host-mapped): receives matched_token when some frame-0 keypoint of the launch is matched
+    unsigned matched_token;
 };
 int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float* s1, hipStream_t s);
 // Asynchronous status words of a handle (host-mapped memory the kernels write; read by the host after a synchronisation).
 constexpr int MDGAT_STATUS_SK_FALLBACK = 0;   // the Sinkhorn cluster kernel lost a partner workgroup: the launch was redone by the streaming kernel
 constexpr int MDGAT_STATUS_RANGE = 1;         // an activation left the f16 operand range or is not finite: the outputs are invalid
+constexpr int MDGAT_STATUS_MATCHED = 2;       // token of the last forward whose extraction matched at least one frame-0 keypoint (mdgat.py:465: the
+                                              // reference tests valid0.sum() on the host; mdgat_matched_any reads this word instead of a reduction + copy)
 constexpr int MDGAT_STATUS_WORDS = 4;
 constexpr float MDGAT_F16_GUARD = 6.0e4f;     // f16 max is 65504; the split's hi plane must stay finite
 // status (optional, device pointer to MDGAT_STATUS_WORDS host-mapped words).  Zfb: where the streaming fallback puts Z when

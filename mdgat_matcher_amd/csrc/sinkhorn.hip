@@ -898,6 +898,9 @@ struct ExArgs {
     // Z == NULL: the arg-maxes were computed by the Sinkhorn kernel (row bests per column slab [B][GC][N], column bests
     // per row slab [B][GR][M])
     const int* rbest_idx; const float* rbest_val; const int* cbest_idx; const float* cbest_val; int GR, GC;
+    // optional (host-mapped word): set to matched_token when a frame-0 keypoint of this pair is matched - what the host-side test
+    // of mdgat.py:465 (`valid0.sum() == 0`) needs to know, without a reduction kernel and a copy (mdgat_matched_any)
+    unsigned* matched; unsigned matched_token;
 };
 
 __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
@@ -974,6 +977,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
     float* s0 = a.s0 + (size_t)blockIdx.x * N;
     float* s1 = a.s1 + (size_t)blockIdx.x * M;
 
+    int nmatch = 0;          // frame-0 keypoints of this thread with a match (matches0 >= 0)
     if (a.mode == MDGAT_EXTRACT_DUSTBIN || a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL) {
         const bool mutual = a.mode == MDGAT_EXTRACT_DUSTBIN_MUTUAL;
         int nvalid = 0;
@@ -992,6 +996,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             m1[j] = valid ? i : -1;
             s1[j] = keep ? expf(val1[j]) : 0.f;
         }
+        nmatch = nvalid;
         if (a.alldust_counters) {
             // mdgat.py:465-467 over the whole batch: one ticket word = (workgroups that matched anything) << 16 | workgroups done;
             // the last workgroup to arrive decides
@@ -1015,6 +1020,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             const bool valid = e > a.thr;
             m0[i] = valid ? idx0[i] : -1;
             s0[i] = valid ? e : 0.f;
+            nmatch += valid;
         }
         for (int j = tid; j < M; j += 1024) {
             const float e = expf(val1[j]);
@@ -1029,6 +1035,7 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             const bool valid0 = mutual0 && ms0 > a.thr;
             m0[i] = valid0 ? idx0[i] : -1;
             s0[i] = ms0;
+            nmatch += valid0;
         }
         for (int j = tid; j < M; j += 1024) {
             const int i = idx1[j];
@@ -1040,6 +1047,10 @@ __global__ __launch_bounds__(1024) void extract_kernel(ExArgs a) {
             m1[j] = valid1 ? i : -1;
             s1[j] = ms1;
         }
+    }
+    if (a.matched) {
+        const int any = __syncthreads_or(nmatch > 0);
+        if (any && tid == 0) __hip_atomic_store(a.matched, a.matched_token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1175,7 +1186,7 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
         // (header words 2, 3 of the workspace: the all-dustbin counters of the extraction, cleared with the slots)
         ExArgs x{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, can_fall_back ? a.error_word : nullptr, zfb, a.pair_flags,
                  (ex->defer_alldust || B >= 65536) ? nullptr : a.error_word + 2, B,
-                 a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC};
+                 a.rbest_idx, a.rbest_val, a.cbest_idx, a.cbest_val, GR, GC, ex->matched, ex->matched_token};
         return launch_extract_impl(B, N, M, x, s, ex->defer_alldust != 0);
     }
     return MDGAT_OK;
@@ -1202,7 +1213,8 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr, nullptr};
     const int rc = launch_streaming(a, B, s);
     if (rc || !ex) return rc;
-    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs xa{Z, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1,
+              ex->matched, ex->matched_token};
     return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
 }
 
@@ -1226,6 +1238,6 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, boo
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;
-    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1};
+    ExArgs a{Z, N, M, mode, thr, m0, m1, s0, s1, nullptr, nullptr, nullptr, nullptr, B, nullptr, nullptr, nullptr, nullptr, 1, 1, nullptr, 0u};
     return launch_extract_impl(B, N, M, a, s);
 }

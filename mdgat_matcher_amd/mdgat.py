@@ -361,8 +361,11 @@ class MDGAT(nn.Module):
             # mdgat.py:464-467: `if valid0.sum() == 0` - a host-side test in the reference too (it synchronises) - returns
             # INTEGER zero scores (torch.zeros_like(indices)) when no frame-0 keypoint of the whole batch is matched.  The
             # kernels have already zeroed the scores; the dtype follows here.
-            nothing_matched = not bool((m0 >= 0).any())
-            self.check(m0.device, synchronize=False)        # (the .any() above synchronised: report this call's status now)
+            # (the library answers from a host-mapped word its extraction kernels write - mdgat_matched_any - so the test costs a
+            # stream synchronisation, as in the reference, but no reduction kernel and no copy)
+            torch.cuda.current_stream(m0.device).synchronize()
+            nothing_matched = not self._matched_any(m0.device)
+            self.check(m0.device, synchronize=False)        # (synchronised above: report this call's status now)
             if nothing_matched:
                 s0, s1 = torch.zeros_like(m0), torch.zeros_like(m1)
         else:
@@ -374,6 +377,15 @@ class MDGAT(nn.Module):
             'matching_scores1': s1,
             'loss': m0.new_zeros((), dtype=out_dtype),     # losses are training-only: not computed
         }
+
+    def _matched_any(self, device) -> bool:
+        """Did the last forward on ``device`` (already synchronised by the caller) match any frame-0 keypoint?  (mdgat.py:465)"""
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        with self._states_lock:
+            st = self._states.get(idx)
+        flag = C.c_uint(0)
+        _lib.check(_lib.load().mdgat_matched_any(st.handle, C.byref(flag)), 'mdgat_matched_any')
+        return bool(flag.value)
 
     def check(self, device=None, synchronize=True):
         """Status of the asynchronous forwards on ``device`` since the last check.  Raises ``RuntimeError`` if an

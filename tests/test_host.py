@@ -268,7 +268,7 @@ class _FakeLib:
     """Records what reaches the C ABI; `status` = (sinkhorn_fallback, range_violation) the next mdgat_async_status reports."""
 
     def __init__(self):
-        self.calls, self.loaded, self.status = [], [], (0, 0)
+        self.calls, self.loaded, self.status, self.matched = [], [], (0, 0), 0
 
     def mdgat_create(self, cfg, idx, handle):
         self.calls.append(('create', idx))
@@ -296,6 +296,10 @@ class _FakeLib:
         if clear:
             self.status = (0, 0)
         return _lib.ERR_UNSUPPORTED if rg._obj.value else 0
+
+    def mdgat_matched_any(self, handle, matched):
+        matched._obj.value = self.matched
+        return 0
 
     def mdgat_destroy(self, handle):
         self.calls.append(('destroy',))
@@ -342,12 +346,14 @@ def test_workspace_per_stream_and_status_check():
         with pytest.raises(RuntimeError, match='f16 operand range'):
             net.check('cuda:0')
         assert net.check('cuda:0') == {'sinkhorn_fallback': False}          # reported once
-        # forward(): matches0 is uninitialised memory under the recorder; force "nothing matched"
-        from unittest import mock
-        with mock.patch.object(torch, 'empty', lambda *a, **k: torch.full(a[0] if a else k['size'], -1 if k.get('dtype') == torch.int64 else 0,
-                                                                             dtype=k.get('dtype', torch.float32))):
-            out = net(d)
+        # forward(): the library says whether the call matched anything (mdgat_matched_any); "nothing matched" -> integer zeros
+        fake.matched = 0
+        out = net(d)
         assert out['matching_scores0'].dtype == torch.int64 and out['matching_scores1'].dtype == torch.int64      # mdgat.py:465-467
+        assert not out['matching_scores0'].any() and not out['matching_scores1'].any()
+        fake.matched = 1
+        out = net(d)
+        assert out['matching_scores0'].dtype == torch.float32 and out['matching_scores1'].dtype == torch.float32
         fake.status = (0, 1)
         with pytest.raises(RuntimeError, match='f16 operand range'):
             net(d)                                                          # the failing call raises, not the next one
