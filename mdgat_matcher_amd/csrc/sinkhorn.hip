@@ -486,11 +486,13 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
         float K[RPW][8];
         const bool vec_ok = (M & 3) == 0 && gcol0 + 8 <= M;
         unsigned gmax = 0;                // largest |score| of this lane as an integer image: NaN / inf on top
+        // (the path is chosen per LANE, outside the row loop: chosen per row, the three-way branch kept the loads of different rows
+        // in different basic blocks - the ragged path then ran its 128 loads one round trip at a time)
+        if (vec_ok) {
 #pragma unroll
-        for (int r = 0; r < RPW; ++r) {
-            const int i = row0 + r;
-            const float* row = S + (size_t)min(i, N - 1) * M;
-            if (vec_ok) {
+            for (int r = 0; r < RPW; ++r) {
+                const int i = row0 + r;
+                const float* row = S + (size_t)min(i, N - 1) * M;
                 const f32x4 x0 = *reinterpret_cast<const f32x4*>(row + gcol0);
                 const f32x4 x1 = *reinterpret_cast<const f32x4*>(row + gcol0 + 4);
 #pragma unroll
@@ -499,19 +501,31 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                     K[r][c] = i < N ? x0[c] * MDGAT_LOG2E : NEG_BIG;
                     K[r][4 + c] = i < N ? x1[c] * MDGAT_LOG2E : NEG_BIG;
                 }
-            } else if (gcol0 >= M) {
-                // a lane whose eight columns all lie beyond M loads nothing (M = 256: half of every wave - as clamped scalar
-                // loads, 128 per lane, they cost the launch of one pair 10 us: tools/sinkhorn_phases.py)
+            }
+        } else if (gcol0 >= M) {
+            // a lane whose eight columns all lie beyond M loads nothing (M = 256: half of every wave - as clamped scalar
+            // loads, 128 per lane, they cost the launch of one pair 10 us: tools/sinkhorn_phases.py)
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) K[r][c] = NEG_BIG;
-            } else {
+        } else {
+            // ragged columns (M not a multiple of 4, or the lane that holds the last valid columns): every load first ...
+#pragma unroll
+            for (int r = 0; r < RPW; ++r) {
+                const float* row = S + (size_t)min(row0 + r, N - 1) * M;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) K[r][c] = row[min(gcol0 + c, M - 1)];
+            }
+            // ... then the guard, the scale and the mask
+#pragma unroll
+            for (int r = 0; r < RPW; ++r)
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                    const float x = row[min(gcol0 + c, M - 1)];
+                    const float x = K[r][c];
                     gmax = max(gmax, __builtin_bit_cast(unsigned, x) & 0x7fffffffu);
-                    K[r][c] = (i < N && gcol0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
+                    K[r][c] = (row0 + r < N && gcol0 + c < M) ? x * MDGAT_LOG2E : NEG_BIG;
                 }
-            }
         }
         if (a.range_guard && gmax >= 0x7f800000u) __hip_atomic_store(a.range_guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         SK_PH(1);
