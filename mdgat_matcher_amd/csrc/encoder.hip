@@ -41,13 +41,28 @@ constexpr int OFF_END = OFF_EL + 2 * 32 * RH256;   // then fp32: kenc0 w [32][4]
 // Eight waves = 256 keypoints per workgroup, one workgroup per CU (the weights fill the LDS): two waves per SIMD, so that one
 // wave's matrix instructions run beside the other's loads, splits and 32-byte row stores (four waves: 64 -> see DESIGN.md)
 constexpr int ENC_THREADS = 512;
-// copy `rows` rows of 2K halves (contiguous in memory) into padded LDS rows
-template <int K>
-__device__ __forceinline__ void copy_rows(const _Float16* g, _Float16* dst, int rows, int tid) {
-    constexpr int CPR = 2 * K * 2 / 16, ROWH = 2 * K + 8;
-    for (int c = tid; c < rows * CPR; c += ENC_THREADS)
-        *reinterpret_cast<f32x4*>(dst + (c / CPR) * ROWH + (c % CPR) * 8) = *reinterpret_cast<const f32x4*>(g + (size_t)c * 8);
-}
+// copy ROWS rows of 2K halves (contiguous in memory) into padded LDS rows, in two steps: every 16-byte piece of a thread is
+// REQUESTED first (copy_issue) and stored once all of them are on their way (copy_commit).  As one loop with a run-time trip
+// count - as until round 4 - the compiler emitted load / wait / store per iteration: the five weight matrices arrived in ~19
+// consecutive L2 round trips at the top of every launch.
+template <int K, int ROWS> struct CopyRows {
+    static constexpr int CPR = 2 * K * 2 / 16, ROWH = 2 * K + 8, N = ROWS * CPR, IT = (N + ENC_THREADS - 1) / ENC_THREADS;
+    f32x4 x[IT];
+    __device__ __forceinline__ void issue(const _Float16* g, int tid) {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = tid + i * ENC_THREADS;
+            if (N % ENC_THREADS == 0 || c < N) x[i] = *reinterpret_cast<const f32x4*>(g + (size_t)c * 8);
+        }
+    }
+    __device__ __forceinline__ void commit(_Float16* dst, int tid) const {
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const int c = tid + i * ENC_THREADS;
+            if (N % ENC_THREADS == 0 || c < N) *reinterpret_cast<f32x4*>(dst + (c / CPR) * ROWH + (c % CPR) * 8) = x[i];
+        }
+    }
+};
 
 __global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
@@ -67,11 +82,13 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
     float* bel = fl + 544;      // [128]
 
     // ---- stage every weight but the last product's, the first two row blocks of the last one, the biases ----
-    copy_rows<32>(a.k1s, smem + OFF_K1, 64, tid);
-    copy_rows<64>(a.k2s, smem + OFF_K2, 128, tid);
-    copy_rows<48>(a.d0s, smem + OFF_D0, 64, tid);
-    copy_rows<64>(a.d1s, smem + OFF_D1, 128, tid);
-    copy_rows<256>(a.els, smem + OFF_EL, 64, tid);
+    {
+        CopyRows<32, 64> c1; CopyRows<64, 128> c2; CopyRows<48, 64> c3; CopyRows<64, 128> c4; CopyRows<256, 64> c5;
+        c1.issue(a.k1s, tid); c2.issue(a.k2s, tid); c3.issue(a.d0s, tid); c4.issue(a.d1s, tid); c5.issue(a.els, tid);
+        __builtin_amdgcn_sched_barrier(0);
+        c1.commit(smem + OFF_K1, tid); c2.commit(smem + OFF_K2, tid); c3.commit(smem + OFF_D0, tid); c4.commit(smem + OFF_D1, tid);
+        c5.commit(smem + OFF_EL, tid);
+    }
     if (tid < 128) k0w[tid] = a.w[a.kenc0_w + tid];
     if (tid < 32) k0b[tid] = a.w[a.kenc0_b + tid];
     if (tid < 64) { bk1[tid] = a.w[a.kenc1_b + tid]; bd0[tid] = a.w[a.denc0_b + tid]; }
@@ -191,7 +208,9 @@ __global__ __launch_bounds__(ENC_THREADS, 2) void encoder_kernel(EncArgs a) {
     for (int ob = 0; ob < 4; ++ob) {
         if (ob == 2) {
             __syncthreads();                 // blocks 0 and 1 consumed by every wave
-            copy_rows<256>(a.els + (size_t)64 * 512, smem + OFF_EL, 64, tid);
+            CopyRows<256, 64> c6;
+            c6.issue(a.els + (size_t)64 * 512, tid);
+            c6.commit(smem + OFF_EL, tid);
             __syncthreads();
         }
         f32x16 o;
