@@ -241,10 +241,14 @@ __global__ __launch_bounds__(64 * NW) void layer_kernel(LayerArgs a) {
         if (h + LOOKAHEAD < NSTAGE) stage_dma_slice<NW>(stage_src(h + LOOKAHEAD), ldsb(h + LOOKAHEAD), wave, lane, i);
     };
     TR(0);
+    // (unrolled: as run-time loops the 64-keypoint variant's two rounds of b3 went load / wait / store, one round trip each)
     if (DO_MLP) {
+#pragma unroll
         for (int i = tid; i < 256; i += NT) bias1[i] = a.b1[i];
+#pragma unroll
         for (int i = tid; i < 128; i += NT) bias2[i] = a.b2[i];
     }
+#pragma unroll
     for (int i = tid; i < NB3 * 32; i += NT) bias3[i] = a.b3[i];
 
     // [R][128] fp32 rows of this wave's 16 keypoints <-> tile: half a wave per 512-byte row; all 8 loads of a
