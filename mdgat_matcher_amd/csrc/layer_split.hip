@@ -44,6 +44,14 @@ struct SpLds {
     float bias[768];                         // b1 [256] | b2 [128] | b3 [384]
 };
 
+#ifdef SPLIT_TRACE
+// s_memtime stamps of waves 0 and 7 of workgroup 0 (tools/ab_build.sh layer_split sptrace -DSPLIT_TRACE; mdgat_split_trace_read)
+__device__ long long g_split_trace[2 * 16];
+#define SPT(k) do { if (DO_MLP && MODE3 == 1 && blockIdx.x == 0 && lane == 0 && (wave == 0 || wave == 7)) g_split_trace[(wave == 7) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define SPT(k) do {} while (0)
+#endif
+
 struct Acc2 { f32x4 m, x; };                 // one row block: hi.hi and hi.lo + lo.hi (x 1/2048 when combined)
 struct Acc4 { f32x4 pm, px, qm, qx; };       // a 32-channel unit: row blocks P and Q
 
@@ -65,6 +73,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
     constexpr int NB3 = MODE3 == 1 ? 384 : 128;
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    SPT(0);
     // fragment (row block rb, k-step ks, plane) of a weight matrix with NK k-steps, as lane (row l15, 16-byte column g) holds it:
     // the fragment-order images (launch_frag_image) keep it as 64 consecutive 16-byte pieces - one contiguous KB per load
     auto wfrag = [&](const _Float16* img, int NK, int rb, int ks, int plane) __attribute__((always_inline)) {
@@ -73,6 +82,22 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
     auto frag_ld = [&](const _Float16* p) __attribute__((always_inline)) { return *reinterpret_cast<const f16x8_m*>(p + lane * 8); };
     auto frag_st = [&](_Float16* p, const f16x8& v) __attribute__((always_inline)) { *reinterpret_cast<f16x8_m*>(p + lane * 8) = v; };
 
+    // ---- biases first: vector memory operations return in order, so a bias requested BEHIND the rows and the 32 KB of W1 would
+    //      make its LDS store - and with it the first barrier - wait for all of W1 (phase trace: 5 900 of 25 000 ticks) ----
+    {
+        float bv1 = 0.f, bv2 = 0.f, bv3 = 0.f;
+        if (DO_MLP) {
+            if (tid < 256) bv1 = a.b1[tid];
+            if (tid < 128) bv2 = a.b2[tid];
+        }
+        if (tid < NB3) bv3 = a.b3[tid];
+        __builtin_amdgcn_sched_barrier(0);
+        if (DO_MLP) {
+            if (tid < 256) bias1[tid] = bv1;
+            if (tid < 128) bias2[tid] = bv2;
+        }
+        if (tid < NB3) bias3[tid] = bv3;
+    }
     // ---- input rows: thread t takes row t >> 4, 16-byte pieces (t & 15) and (t & 15) + 16 of it (whole 256-byte half
     //      rows per 16 threads); rows past the end are copies of the last keypoint and are never written back ----
     const int irow = tid >> 4, ic = tid & 15;
@@ -96,11 +121,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
             w1[ks][3] = wfrag(a.w1f, 8, 2 * wave + 1, ks, 1);
         }
     }
-    if (DO_MLP) {
-        for (int i = tid; i < 256; i += 64 * SP_NW) bias1[i] = a.b1[i];
-        for (int i = tid; i < 128; i += 64 * SP_NW) bias2[i] = a.b2[i];
-    }
-    for (int i = tid; i < NB3; i += 64 * SP_NW) bias3[i] = a.b3[i];
+    SPT(1);
     __builtin_amdgcn_sched_barrier(0);
     *reinterpret_cast<f32x4_m*>(&S.xt[irow][ic * 4]) = tx0;
     *reinterpret_cast<f32x4_m*>(&S.xt[irow][64 + ic * 4]) = tx1;
@@ -118,7 +139,9 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
         }
         if (gm >= __builtin_bit_cast(unsigned, MDGAT_F16_GUARD)) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
+    SPT(2);
     __syncthreads();
+    SPT(3);
     // ---- rows -> split fragments: lane (keypoint l15, g) holds channels 32 ks + 8 g .. + 7 ----
     if (DO_MLP) {
         const float (*src)[SP_TROW] = wave < 4 ? S.xt : S.mt;
@@ -140,6 +163,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
         frag_st(S.xnF[wave >> 1][wave & 1][1], l);
     }
     __syncthreads();
+    SPT(4);
 
     // ---- this wave's slices of the phase-3 weights: q / k unit `wave` (row blocks 2 wave, 2 wave + 1) and row block 16 + wave
     //      of v (mode 1), or row block `wave` of final_proj (mode 2) ----
@@ -188,6 +212,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
 #pragma unroll
             for (int kpb = 0; kpb < SP_KPB; ++kpb) { c1[kpb].px = mma(w1[ks][1], xh[kpb], c1[kpb].px); c1[kpb].qx = mma(w1[ks][3], xh[kpb], c1[kpb].qx); }
         }
+        SPT(5);
         // the slice of W3 is requested here: it lands behind the epilogue, the barrier and phase 2
         load_w3();
         __builtin_amdgcn_sched_barrier(0);
@@ -207,7 +232,9 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
             frag_st(S.hidF[wave][kpb][0], h);       // lane (n, g): channels 8 g .. 8 g + 7 of unit `wave` = k-step `wave` of phase 2
             frag_st(S.hidF[wave][kpb][1], l);
         }
+        SPT(6);
         __syncthreads();
+        SPT(7);
 
         // ---- phase 2: row block `wave` (unit ob = wave >> 1, half P / Q = wave & 1) of x += W2 hid + b2 ----
         Acc2 c2[SP_KPB];
@@ -225,6 +252,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
 #pragma unroll
             for (int kpb = 0; kpb < SP_KPB; ++kpb) c2[kpb].x = mma(w2[ks][1], hh[kpb], c2[kpb].x);
         }
+        SPT(8);
         {
             const int ob = wave >> 1, half = wave & 1;
             const int ch = ob * 32 + 8 * g + 4 * half;     // rows 4 g .. 4 g + 3 of block P / Q are channels 8 g (+ 4) .. + 3 of the unit
@@ -247,7 +275,9 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
                 *reinterpret_cast<f16x4_m*>(S.xnF[ob][kpb][1] + lane * 8 + 4 * half) = l;
             }
         }
+        SPT(9);
         __syncthreads();
+        SPT(10);
         // new x rows out (the same thread -> row piece map as the input)
         if (pt0 + irow < a.R) {
             *reinterpret_cast<f32x4*>(a.x + igp + ic * 4) = *reinterpret_cast<const f32x4_m*>(&S.xt[irow][ic * 4]);
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
         load_w3();
     }
 
+    SPT(11);
     // ---- phase 3 ----
     if constexpr (MODE3 == 1) {
         // q / k unit `wave` (head wave & 3; swapped product: lane = keypoint) and row block (head wave >> 1, dims 16 (wave & 1) ..)
@@ -293,6 +324,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
                 cv[kpb].x = mma(xh[kpb], w3[ks][V + 1], cv[kpb].x);
             }
         }
+        SPT(12);
         // q / k: [pt][head][plane][32 dims]; q pre-scaled by log2(e) / sqrt(32); residual plane unscaled (common.hpp)
         {
             float pb[8];
@@ -354,6 +386,7 @@ __global__ __launch_bounds__(64 * SP_NW) void layer_split_kernel(LayerArgs a) {
                 }
             }
         }
+        SPT(13);
     } else {
         // final_proj: row block `wave` (unit wave >> 1, half wave & 1) of mdesc = Wf x + bf
         Acc2 c3[SP_KPB];
@@ -407,6 +440,10 @@ int launch_split_t(const LayerArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef SPLIT_TRACE
+extern "C" int mdgat_split_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_split_trace), n * sizeof(long long)); }
+#endif
 
 int launch_frag_image(const _Float16* img, _Float16* out, int rows, int K, int rowh, hipStream_t s) {
     const size_t pieces = (size_t)(rows / 16) * (K / 32) * 2 * 64;
