@@ -30,7 +30,7 @@
 #ifdef WIDE_TRACE
 __device__ long long g_wide_trace[4 * 8];
 extern "C" int mdgat_wide_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wide_trace), n * sizeof(long long)); }
-#define WT(k) do { if (blockIdx.x == 5 && blockIdx.y == 1 && blockIdx.z == 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7)) \
+#define WT(k) do { if (blockIdx.x == 8 * 5 + 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 7)) \
     g_wide_trace[((threadIdx.x >> 6) == 7) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WT(k) do {} while (0)
@@ -54,6 +54,7 @@ struct AttnArgs {
     int* near_count;       // NULL: no list
     RepairRec* near_recs;
     int near_cap;
+    int wide_npg, wide_units;   // attention_topk_wide_kernel: query passes per (pair, frame, head) in the grid, number of such units
 };
 
 // append a near-threshold row (one lane per row calls this; rare: ~1 row in 10^3)
@@ -1028,8 +1029,15 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     const int qgroup = wave / NW, kw = wave % NW;
-    const int head = blockIdx.y;
-    const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    // 1-D grid, XCD aware: workgroups i, i + 8, i + 16, ... (one XCD under round-robin dispatch) walk the query tiles of ONE
+    // (pair, frame, head), whose K and V^T they read straight from L2 - with the plain (pass, head, frame) grid every XCD
+    // fetched every unit's keys: PMC 377 MB per launch at 8 x 2048 against 67 MB of q, k, v and messages
+    const int slot = blockIdx.x >> 3, npg = a.wide_npg;
+    // blockIdx.x = slot * 8 + xcd with slot = ugroup * npg + pass0: unit = ugroup * 8 + xcd (the grid is padded to 8 units)
+    const int unit = (slot / npg) * 8 + (blockIdx.x & 7);
+    if (unit >= a.wide_units) return;
+    const int pass0 = slot % npg;
+    const int head = unit & 3, side = (unit >> 2) & 1, b = unit >> 3;
     const int P = a.N + a.M;
     const int nq = side ? a.M : a.N;
     const int q_off = side ? a.N : 0;
@@ -1046,7 +1054,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     WideComm<NW> comm{xbuf, wave, lane, 0};
     const int npass = (nq + 32 * NG - 1) / (32 * NG);
 
-    for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    for (int pass = pass0; pass < npass; pass += npg) {
         const int qw = (pass * NG + qgroup) * 32;
         f16x8 qh[2], ql[2];
         {
@@ -1219,14 +1227,19 @@ static int launch_attention_topk_wide(const AttnArgs& a, int B, int nk_max, hipS
         return MDGAT_ERR_UNSUPPORTED;
     }
     const size_t lds = (size_t)(1040 + 8 * 17 * 64) * sizeof(float);
+    AttnArgs w = a;
+    w.wide_units = B * 2 * MDGAT_HEADS;
+    const int ugroups = (w.wide_units + 7) / 8;
     if (nblk <= 32) {
-        const int npass = (nk_max + 63) / 64;
-        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<4, true>), dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL(attention_topk_wide_kernel<4>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        w.wide_npg = (nk_max + 63) / 64;
+        const dim3 grid(8 * w.wide_npg * ugroups);
+        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<4, true>), grid, dim3(512), lds, s, w);
+        else hipLaunchKernelGGL(attention_topk_wide_kernel<4>, grid, dim3(512), lds, s, w);
     } else {
-        const int npass = (nk_max + 31) / 32;
-        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<8, true>), dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
-        else hipLaunchKernelGGL(attention_topk_wide_kernel<8>, dim3(npass, MDGAT_HEADS, B * 2), dim3(512), lds, s, a);
+        w.wide_npg = (nk_max + 31) / 32;
+        const dim3 grid(8 * w.wide_npg * ugroups);
+        if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<8, true>), grid, dim3(512), lds, s, w);
+        else hipLaunchKernelGGL(attention_topk_wide_kernel<8>, grid, dim3(512), lds, s, w);
     }
     return mdgat_check_hip(hipGetLastError(), "wide dynamic attention launch");
 }
