@@ -54,7 +54,10 @@ struct AttnArgs {
     int* near_count;       // NULL: no list
     RepairRec* near_recs;
     int near_cap;
-    int wide_npg, wide_units;   // attention_topk_wide_kernel: query passes per (pair, frame, head) in the grid, number of such units
+    // XCD-aware 1-D grids (attention_topk16_kernel, attention_topk_wide_kernel): workgroup blockIdx.x = (ugroup * grid_split + part) * 8 + xcd
+    // works on part `part` of the query tiles of unit ugroup * 8 + xcd, unit = (pair * 2 + frame) * 4 + head: the parts of a unit share
+    // an XCD (round-robin dispatch), so its K and V^T are fetched into one L2 only.  The grid is padded to 8 units.
+    int grid_split, grid_units;
 };
 
 // append a near-threshold row (one lane per row calls this; rare: ~1 row in 10^3)
@@ -729,9 +732,13 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
     extern __shared__ __attribute__((aligned(16))) _Float16 smem[];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-        const int l15 = lane & 15, g = lane >> 4;
-    const int head = blockIdx.y;
-    const int b = blockIdx.z >> 1, side = blockIdx.z & 1;
+    const int l15 = lane & 15, g = lane >> 4;
+    // (XCD-aware 1-D grid: AttnArgs.grid_split.  With the (part, head, pair x frame) grid the two or four parts of a unit sat on
+    // different XCDs and each fetched the unit's keys: PMC 104 MB per 32-pair launch against 67 MB of q, k, v and messages)
+    const int bslot = blockIdx.x >> 3;
+    const int unit = (bslot / a.grid_split) * 8 + (blockIdx.x & 7), part = bslot % a.grid_split;
+    if (unit >= a.grid_units) return;
+    const int head = unit & 3, side = (unit >> 2) & 1, b = unit >> 3;
     const int P = a.N + a.M;
     const int nq = side ? a.M : a.N;
     const int q_off = side ? a.N : 0;
@@ -785,7 +792,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 
     QuadComm comm;
     const int tiles_all = (nq + 15) >> 4;
-    const int tiles_wg = (tiles_all + gridDim.x - 1) / gridDim.x;      // this workgroup: tiles [blockIdx.x tiles_wg, ...)
+    const int tiles_wg = (tiles_all + a.grid_split - 1) / a.grid_split;  // this workgroup: tiles [part tiles_wg, ...)
     // the next 16-query tile of this wave (wave-uniform; -1: none left) and its query fragment: dims 8 g .. 8 g + 7 of query
     // l15 (B operand), planes hi / lo
     auto claim_tile = [&]() -> int {
@@ -793,7 +800,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         if (lane == 0) t = atomicAdd(next_tile, 1);
         t = __builtin_amdgcn_readfirstlane(t);
         if (t >= tiles_wg) return -1;
-        const int q0 = (blockIdx.x * tiles_wg + t) * 16;
+        const int q0 = (part * tiles_wg + t) * 16;
         return q0 < nq ? q0 : -1;
     };
     auto load_q = [&](int q0, f16x8& h, f16x8& l) {
@@ -1032,10 +1039,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     // 1-D grid, XCD aware: workgroups i, i + 8, i + 16, ... (one XCD under round-robin dispatch) walk the query tiles of ONE
     // (pair, frame, head), whose K and V^T they read straight from L2 - with the plain (pass, head, frame) grid every XCD
     // fetched every unit's keys: PMC 377 MB per launch at 8 x 2048 against 67 MB of q, k, v and messages
-    const int slot = blockIdx.x >> 3, npg = a.wide_npg;
+    const int slot = blockIdx.x >> 3, npg = a.grid_split;
     // blockIdx.x = slot * 8 + xcd with slot = ugroup * npg + pass0: unit = ugroup * 8 + xcd (the grid is padded to 8 units)
     const int unit = (slot / npg) * 8 + (blockIdx.x & 7);
-    if (unit >= a.wide_units) return;
+    if (unit >= a.grid_units) return;
     const int pass0 = slot % npg;
     const int head = unit & 3, side = (unit >> 2) & 1, b = unit >> 3;
     const int P = a.N + a.M;
@@ -1228,16 +1235,16 @@ static int launch_attention_topk_wide(const AttnArgs& a, int B, int nk_max, hipS
     }
     const size_t lds = (size_t)(1040 + 8 * 17 * 64) * sizeof(float);
     AttnArgs w = a;
-    w.wide_units = B * 2 * MDGAT_HEADS;
-    const int ugroups = (w.wide_units + 7) / 8;
+    w.grid_units = B * 2 * MDGAT_HEADS;
+    const int ugroups = (w.grid_units + 7) / 8;
     if (nblk <= 32) {
-        w.wide_npg = (nk_max + 63) / 64;
-        const dim3 grid(8 * w.wide_npg * ugroups);
+        w.grid_split = (nk_max + 63) / 64;
+        const dim3 grid(8 * w.grid_split * ugroups);
         if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<4, true>), grid, dim3(512), lds, s, w);
         else hipLaunchKernelGGL(attention_topk_wide_kernel<4>, grid, dim3(512), lds, s, w);
     } else {
-        w.wide_npg = (nk_max + 31) / 32;
-        const dim3 grid(8 * w.wide_npg * ugroups);
+        w.grid_split = (nk_max + 31) / 32;
+        const dim3 grid(8 * w.grid_split * ugroups);
         if (a.sel) hipLaunchKernelGGL((attention_topk_wide_kernel<8, true>), grid, dim3(512), lds, s, w);
         else hipLaunchKernelGGL(attention_topk_wide_kernel<8>, grid, dim3(512), lds, s, w);
     }
@@ -1370,9 +1377,12 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
         const int qmax = B * 2 * MDGAT_HEADS * (NKEY / 128) >= 256 ? NKEY / 128 : 4;
         if (qsplit > qmax) qsplit = qmax;
         const size_t lds3 = ((size_t)2 * 4 * NKEY * 8 + (size_t)64 * (NKEY + 8)) * sizeof(_Float16) + 16;    // + the tile counter
+        AttnArgs w = a;
+        w.grid_split = qsplit;
+        w.grid_units = B * 2 * MDGAT_HEADS;
         auto run = [&](auto kern) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3);
-            hipLaunchKernelGGL(kern, dim3(qsplit, MDGAT_HEADS, B * 2), dim3(512), lds3, s, a);
+            hipLaunchKernelGGL(kern, dim3(8 * qsplit * ((w.grid_units + 7) / 8)), dim3(512), lds3, s, w);
         };
         if (a.sel) { if (mode == 1) run(attention_topk16_kernel<true, true, NKEY>); else run(attention_topk16_kernel<false, true, NKEY>); }
         else if (mode == 1) run(attention_topk16_kernel<true, false, NKEY>);
