@@ -183,6 +183,29 @@ def pmc_traffic(config, kernel):
         return None, None
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` must produce N ranks or fail (the reference's multi-GPU is one line, test.py:158).  Started
+    without a launcher and asked for more than one GPU, this process becomes the launcher: it re-executes the same command
+    line under torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1 at a free port) and exits with its status.
+    Started BY a launcher, the world it was given must be the one asked for."""
+    launched = 'RANK' in os.environ or 'WORLD_SIZE' in os.environ
+    if launched:
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if world != args.gpus:
+            raise SystemExit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks: refusing to print a '
+                             f'{world}-rank number under an n_gpus={args.gpus} request')
+        return
+    if args.gpus <= 1:
+        return
+    if torch.cuda.is_available() and torch.cuda.device_count() < args.gpus and not os.environ.get('MDGAT_SHARE_DEVICE'):
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but this box has {torch.cuda.device_count()} GPU(s)')
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(shard._free_port()), os.path.abspath(sys.argv[0])] + sys.argv[1:]
+    print(f'[bench] --gpus {args.gpus} without a launcher: starting {args.gpus} ranks: {" ".join(cmd)}', file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '1'))))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -200,7 +223,11 @@ def main():
     ap.add_argument('--no-dict-api', action='store_true', help='skip the forward(dict) throughput leg')
     ap.add_argument('--no-latency', action='store_true', help='skip the one-pair-per-call latency block')
     ap.add_argument('--exact-topk', action='store_true', help='mdgat_config.exact_topk (exact re-decision of near-threshold top-k rows)')
+    ap.add_argument('--arithmetic', default='fp32', choices=['fp32', 'fp64'],
+                    help="'fp64': time the reference-exact mode (MDGAT(arithmetic='fp64')) as the step; never the headline")
+    ap.add_argument('--no-exact-mode', action='store_true', help='skip the exact_mode block (reference-exact fp64 mode on a bounded batch)')
     args = ap.parse_args()
+    self_launch(args)
 
     c = CONFIGS[args.config]
     B = args.batch if args.batch is not None else c['B']
@@ -208,6 +235,8 @@ def main():
     att = args.attention_dtype or c['att']
 
     rank, world, local = shard.init_distributed(args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but the process group has {world} rank(s)')
     # tests/bench_stub_runner.py (CPU, no GPU in the build container) replaces MDGAT._run by a recorder to drive THIS file's
     # multi-rank control flow under gloo; it says so in the environment and the line it prints carries "stub": true.
     stub = os.environ.get('MDGAT_BENCH_STUB') == '1' and not torch.cuda.is_available()

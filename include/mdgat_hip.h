@@ -66,6 +66,16 @@ typedef enum {
  * and ignored elsewhere. */
 typedef enum { MDGAT_ATTENTION_FP32 = 0, MDGAT_ATTENTION_F16 = 1 } mdgat_attention_mode;
 
+/* Arithmetic of the forward.  MDGAT_ARITH_FP32 (default): fp32-class products everywhere (split-f16 on the matrix cores) -
+ * Z within 1e-4 of the fp64 reference wherever the top-k selections of the dynamic layers agree with the reference's, which
+ * near-ties below fp32 resolution do not always (about 1.5 rows per pair at 512 keypoints).
+ * MDGAT_ARITH_FP64: the reference's own arithmetic (the reference runs net.double(), test.py:193) where it decides anything
+ * discontinuous: the encoders (mdgat.py:392-393) and the propagation layers up to and including the LAST dynamic layer
+ * (mdgat.py:259-276 with dynamic_attention 196-210) run in fp64 on v_mfma_f64_16x16x4_f64 from fp64 inputs and fp64 weights
+ * (mdgat_load_weights_f64, mdgat_forward_f64; csrc/f64.hip), so that logits.topk(k) selects what the reference selects; the
+ * layers behind it, final_proj, the score matrix and Sinkhorn are continuous and stay on the fp32-class kernels. */
+typedef enum { MDGAT_ARITH_FP32 = 0, MDGAT_ARITH_FP64 = 1 } mdgat_arithmetic;
+
 /* Replaces the config dict of MDGAT.__init__ (mdgat.py:325-367) for descriptor == 'FPFH'. */
 typedef struct {
     int32_t L;                         /* config['L']: 2L alternating self/cross layers (352-353) */
@@ -87,6 +97,10 @@ typedef struct {
                                           (the accumulated fp32-class error of the layers before), which dominate: the number
                                           of rows selected differently from the fp64 reference does not change
                                           (profiles/parity_r4.txt), at 3-6 % of the step. */
+    int32_t arithmetic;                /* mdgat_arithmetic; not a reference key (the reference IS fp64) */
+    int32_t f64_layers;                /* MDGAT_ARITH_FP64: how many leading propagation layers run in fp64; < 0 (default):
+                                          up to and including the last layer with topk > 0 (0 layers when there is none: the
+                                          encoders only); 2L: all of them */
 } mdgat_config;
 
 typedef struct mdgat_handle mdgat_handle;
@@ -123,6 +137,13 @@ int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out);
 int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device);
 size_t mdgat_blob_floats(int L);
 
+/* MDGAT_ARITH_FP64: the same blob in fp64 - the folded weights BEFORE their rounding to fp32 (pack.py computes them in fp64;
+ * same layout, mdgat_blob_floats(L) doubles).  Needed in addition to mdgat_load_weights (the layers behind the last dynamic
+ * one run on the fp32 blob).  Fails with MDGAT_ERR_BAD_ARG on a handle created with another arithmetic. */
+int mdgat_load_weights_f64(mdgat_handle* h, const double* blob, size_t n_doubles, int on_device);
+/* Device pointer to the handle's fp64 blob (NULL before mdgat_load_weights_f64; for an RCCL broadcast). */
+double* mdgat_weights_f64_device_ptr(mdgat_handle* h);
+
 /* Device pointer to the handle's packed weights (for an RCCL broadcast from rank 0). */
 float* mdgat_weights_device_ptr(mdgat_handle* h);
 
@@ -143,6 +164,17 @@ int mdgat_forward(mdgat_handle* h, int B, int N, int M,
                   float* Z, const mdgat_taps* taps,
                   void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward in the reference's arithmetic (handle created with MDGAT_ARITH_FP64, both blobs loaded): inputs in fp64 as
+ * the reference receives them (test.py:194-199 moves the loader's float64 tensors to the device; layouts as above), outputs as
+ * mdgat_forward (Z and the matching scores come from the fp32 Sinkhorn: within 1e-4 of the reference's fp64 values).  The taps
+ * receive fp32 roundings of the fp64 stages. */
+int mdgat_forward_f64(mdgat_handle* h, int B, int N, int M,
+                      const double* kpts0, const double* sigma0, const double* fpfh0,
+                      const double* kpts1, const double* sigma1, const double* fpfh1,
+                      int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,
+                      float* Z, const mdgat_taps* taps,
+                      void* workspace, size_t workspace_bytes, void* stream);
+
 /* The same forward fed with the loader's raw frame records instead of separate arrays: frames [B][N][37] fp32,
  * one record per keypoint = xyz(3) | saliency(1) | FPFH(33), the layout of the KITTI keypoint files that
  * SparseDataset.__getitem__ reads (load_data.py:146-165).  normalize_fpfh != 0 applies the loader's L2
@@ -162,11 +194,21 @@ int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* fram
  * call; the results are valid.  The reference has no counterpart (ATen raises nothing either: it returns inf / NaN). */
 int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation);
 
-/* After the caller's synchronisation: *matched = 1 when the LAST forward enqueued on this handle matched at least one frame-0
- * keypoint anywhere in its batch (matches0 >= 0), else 0.  This is the reference's host-side test `valid0.sum() == 0`
+/* mdgat_config.exact_topk only, after the caller's synchronisation: *given_up = near-threshold rows the exact re-decision left
+ * as the attention kernel wrote them since the last call with clear != 0 - rows with more than 16 logits inside the window
+ * around their threshold (masses of equal logits, e.g. duplicated keypoints: such a row keeps EVERY logit >= its threshold,
+ * possibly more than k, where torch.topk keeps exactly k) and rows that did not fit the list.  Informational. */
+int mdgat_topk_repair_status(mdgat_handle* h, int clear, unsigned* given_up);
+
+/* After the caller's synchronisation: *matched = 1 when the forward that carried `token` matched at least one frame-0 keypoint
+ * anywhere in its batch (matches0 >= 0), else 0.  This is the reference's host-side test `valid0.sum() == 0`
  * (models/mdgat.py:464-467: integer zero scores when nothing matched) without a reduction kernel and a device-to-host copy: the
- * extraction kernels write the call's token into a host-mapped word.  Per handle, like the status words above. */
-int mdgat_matched_any(mdgat_handle* h, unsigned* matched);
+ * extraction kernels write the call's token into a host-mapped slot (256 slots, indexed by the token: calls of several threads
+ * and streams on one handle do not disturb each other).  mdgat_last_token returns the token of the most recent
+ * mdgat_forward / mdgat_forward_f64 / mdgat_forward_frames enqueued on the handle - read it before another thread can enqueue
+ * (the Python wrapper does so under its per-handle lock); token 0 stands for that most recent call. */
+unsigned mdgat_last_token(mdgat_handle* h);
+int mdgat_matched_any(mdgat_handle* h, unsigned token, unsigned* matched);
 
 /* Per-kernel-class timing of mdgat_forward, measured with HIP events on the launch stream (bench.py's
  * roofline leg).  mdgat_profile(h, enable, ms, launches) returns the time (ms) and launch count
@@ -185,7 +227,11 @@ enum {
     MDGAT_PROF_EXTRACT = 6,
     MDGAT_PROF_LAYER_FIRST = 7,    /* the launch before layer 0: q/k/v projection only (a third of a layer launch's work) */
     MDGAT_PROF_LAYER_LAST = 8,     /* the launch after the last layer: mlp + residual + final_proj */
-    MDGAT_PROF_CLASSES = 9
+    MDGAT_PROF_F64_GEMM = 9,       /* MDGAT_ARITH_FP64: the Conv1d(k=1) products of the fp64 stages (csrc/f64.hip) */
+    MDGAT_PROF_F64_ATTENTION_FULL = 10,
+    MDGAT_PROF_F64_ATTENTION_TOPK = 11,
+    MDGAT_PROF_F64_OTHER = 12,     /* input assembly, hand-over conversion to fp32 */
+    MDGAT_PROF_CLASSES = 13
 };
 int mdgat_profile(mdgat_handle* h, int enable, double* ms, long long* launches);
 
@@ -253,6 +299,20 @@ int mdgat_attention_qk_probe_sets(int B, int N, int M, int cross, int nq_sets, c
  * matching path; replaces nothing in the reference. */
 int mdgat_mfma_probe(int reps, void* workspace, size_t workspace_bytes, float* ms_out, double* flops_out,
                      long long* ticks_out, void* stream);
+
+/* Measurement only (bench.py, exact_mode.roofline): the rate this device sustains on v_mfma_f64_16x16x4_f64 (two waves per
+ * SIMD, operands in registers, `reps` x 16 instructions per wave).  workspace: >= 72 KB, 256-byte aligned.  Outputs as
+ * mdgat_mfma_probe.  Not part of the matching path. */
+int mdgat_mfma_f64_probe(int reps, void* workspace, size_t workspace_bytes, float* ms_out, double* flops_out,
+                         long long* ticks_out, void* stream);
+
+/* Unit parity of the fp64 kernels (csrc/f64.hip; the fp64 forward uses the same launches):
+ * mdgat_pointwise_f64: as mdgat_pointwise on doubles, no alignment or K granularity required.
+ * mdgat_attention_f64: attention / dynamic_attention (mdgat.py:190-210) on fp64 q | k | v rows [B][P][384] ([which][head][dim]),
+ * msg [B][P][128]; sel (optional): the kept keys of a dynamic layer, layout of mdgat_taps.topk_sel. */
+int mdgat_pointwise_f64(int M, int N, int K, const double* A, int lda, const double* W, int ldw, const double* bias,
+                        int relu, const double* R, int ldr, double* C, int ldc, void* stream);
+int mdgat_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, void* stream);
 
 /* Conv1d(k=1)(+folded BN)(+ReLU) over points: C[m][n] = act(sum_k A[m][k] W[n][k] + bias[n]) (+R).
  * (MLP of mdgat.py:34-46 after folding.)  K must be a multiple of 32; lda/ldw/ldc multiples of 4. */

@@ -17,7 +17,11 @@ EXTRACT_DUSTBIN_MUTUAL = 1
 EXTRACT_THRESHOLD = 2
 EXTRACT_THRESHOLD_MUTUAL = 3
 
-PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores', 'sinkhorn', 'extract', 'layer_first', 'layer_last')
+PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores', 'sinkhorn', 'extract', 'layer_first', 'layer_last',
+                'f64_gemm', 'f64_attention_full', 'f64_attention_topk', 'f64_other')
+
+ARITH_FP32 = 0
+ARITH_FP64 = 1
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -35,6 +39,8 @@ class MdgatConfig(C.Structure):
         ('match_threshold', C.c_float),
         ('attention_mode', C.c_int32),
         ('exact_topk', C.c_int32),
+        ('arithmetic', C.c_int32),
+        ('f64_layers', C.c_int32),
     ]
 
 
@@ -50,6 +56,8 @@ TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel', 'repair_stats')
 SIGNATURES = {
     'mdgat_create': (C.c_int, [C.POINTER(MdgatConfig), C.c_int, C.POINTER(C.c_void_p)]),
     'mdgat_load_weights': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    'mdgat_load_weights_f64': (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]),
+    'mdgat_weights_f64_device_ptr': (C.c_void_p, [C.c_void_p]),
     'mdgat_blob_floats': (C.c_size_t, [C.c_int]),
     'mdgat_weights_device_ptr': (C.c_void_p, [C.c_void_p]),
     'mdgat_destroy': (None, [C.c_void_p]),
@@ -57,10 +65,14 @@ SIGNATURES = {
     'mdgat_workspace_bytes': (C.c_size_t, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     'mdgat_forward': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p] * 4 +
                       [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
+    'mdgat_forward_f64': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int] + [C.c_void_p] * 6 + [C.c_void_p] * 4 +
+                          [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_forward_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
                              [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_async_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
-    'mdgat_matched_any': (C.c_int, [C.c_void_p, C.POINTER(C.c_uint)]),
+    'mdgat_topk_repair_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
+    'mdgat_last_token': (C.c_uint, [C.c_void_p]),
+    'mdgat_matched_any': (C.c_int, [C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]),
     'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     'mdgat_set_lanes': (C.c_int, [C.c_void_p, C.c_int]),
     'mdgat_set_layer_split_tiles': (C.c_int, [C.c_int]),
@@ -72,6 +84,10 @@ SIGNATURES = {
                                   C.c_size_t, C.c_void_p]),
     'mdgat_attention_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_mfma_probe': (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_void_p]),
+    'mdgat_mfma_f64_probe': (C.c_int, [C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_float), C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.c_void_p]),
+    'mdgat_pointwise_f64': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                      C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    'mdgat_attention_f64': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mdgat_attention_qk_probe': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_attention_qk_probe_sets': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_attention_sel': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "f64.hpp"
 
 // ---------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -61,7 +62,8 @@ struct mdgat_handle {
     BlobLayout bl;
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
-    bool loaded;
+    double* weights64;   // device, the blob in fp64 (MDGAT_ARITH_FP64: f64.hip), else nullptr
+    bool loaded, loaded64;
     bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk (or MDGAT_TOPK_REPAIR in the environment), fp32 attention mode
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard,
                           // token of the last forward that matched a frame-0 keypoint
@@ -99,6 +101,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
     if (cfg->L < 0 || 2 * cfg->L > MDGAT_MAX_LAYERS) { mdgat_set_error("mdgat_create: L=%d out of range", cfg->L); return MDGAT_ERR_BAD_ARG; }
     if (cfg->attention_mode != MDGAT_ATTENTION_FP32 && cfg->attention_mode != MDGAT_ATTENTION_F16) { mdgat_set_error("mdgat_create: bad attention_mode %d", cfg->attention_mode); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->arithmetic != MDGAT_ARITH_FP32 && cfg->arithmetic != MDGAT_ARITH_FP64) { mdgat_set_error("mdgat_create: bad arithmetic %d", cfg->arithmetic); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->arithmetic == MDGAT_ARITH_FP64 && cfg->f64_layers > 2 * cfg->L) { mdgat_set_error("mdgat_create: f64_layers=%d > 2L", cfg->f64_layers); return MDGAT_ERR_BAD_ARG; }
     if (cfg->extract_mode < 0 || cfg->extract_mode > 3) { mdgat_set_error("mdgat_create: bad extract_mode %d", cfg->extract_mode); return MDGAT_ERR_BAD_ARG; }
     for (int i = 0; i < 2 * cfg->L; ++i)
         if (cfg->topk[i] < 0) { mdgat_set_error("mdgat_create: topk[%d] < 0", i); return MDGAT_ERR_BAD_ARG; }
@@ -115,7 +119,9 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->bl = mdgat_blob_layout(cfg->L);
     h->weights = nullptr;
     h->wsplit = nullptr;
+    h->weights64 = nullptr;
     h->loaded = false;
+    h->loaded64 = false;
     {
         const char* e = getenv("MDGAT_TOPK_REPAIR");      // (measurements: 0 / 1 override the configuration)
         h->repair = (e ? atoi(e) != 0 : cfg->exact_topk != 0) && cfg->attention_mode == MDGAT_ATTENTION_FP32;
@@ -134,6 +140,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     (void)hipGetDevice(&prev);
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
+    if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64) rc = mdgat_check_hip(hipMalloc(&h->weights64, h->bl.total * sizeof(double)), "hipMalloc(fp64 weights)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMalloc(split weights)");
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMemset(split weights)");
     if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
@@ -226,11 +233,29 @@ extern "C" int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_f
 }
 
 extern "C" float* mdgat_weights_device_ptr(mdgat_handle* h) { return h ? h->weights : nullptr; }
+extern "C" double* mdgat_weights_f64_device_ptr(mdgat_handle* h) { return h ? h->weights64 : nullptr; }
+
+extern "C" int mdgat_load_weights_f64(mdgat_handle* h, const double* blob, size_t n_doubles, int on_device) {
+    if (!h || !blob) { mdgat_set_error("mdgat_load_weights_f64: null argument"); return MDGAT_ERR_BAD_ARG; }
+    if (!h->weights64) { mdgat_set_error("mdgat_load_weights_f64: the handle was not created with MDGAT_ARITH_FP64"); return MDGAT_ERR_BAD_ARG; }
+    if (n_doubles != h->bl.total) {
+        mdgat_set_error("mdgat_load_weights_f64: blob has %zu doubles, expected %zu for L=%d", n_doubles, h->bl.total, h->cfg.L);
+        return MDGAT_ERR_BAD_ARG;
+    }
+    h->loaded64 = false;
+    if (blob != h->weights64)
+        if (int rc = mdgat_check_hip(hipMemcpy(h->weights64, blob, n_doubles * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice),
+                                     "hipMemcpy(fp64 weights)"))
+            return rc;
+    h->loaded64 = true;
+    return MDGAT_OK;
+}
 
 extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (!h) return;
     if (h->weights) (void)hipFree(h->weights);
     if (h->wsplit) (void)hipFree(h->wsplit);
+    if (h->weights64) (void)hipFree(h->weights64);
     if (h->host_error) (void)hipHostFree(h->host_error);
     if (h->lane_stream) { (void)hipStreamSynchronize(h->lane_stream); (void)hipStreamDestroy(h->lane_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -244,6 +269,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
 namespace {
 struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
+    double *x64, *qkv64, *hid64, *msg64;   // MDGAT_ARITH_FP64 only: the residual stream, q|k|v, hidden layer and message of the fp64 layers
     _Float16* qkv16;
     int* near_count;        // [MDGAT_MAX_LAYERS] near-threshold rows listed by each dynamic layer (zeroed at the start of a forward)
     RepairRec* near_recs;   // [near_cap] the list itself, reused layer after layer (a layer's repair runs before the next layer lists)
@@ -253,7 +279,7 @@ struct Workspace {
 };
 // capacity of the near-threshold list: ~1-2 rows in 10^3 are listed; 1/16 of all (pair, head, query) rows is never reached
 int near_capacity(size_t R) { const size_t c = R * 4 / 16; return (int)(c < 1024 ? 1024 : c > (1u << 20) ? (1u << 20) : c); }
-Workspace carve(float* base, int B, int N, int M) {
+Workspace carve(float* base, int B, int N, int M, bool f64) {
     const size_t R = (size_t)B * (N + M);
     Workspace w{};
     size_t o = 0;
@@ -270,6 +296,12 @@ Workspace carve(float* base, int B, int N, int M) {
     w.near_count = reinterpret_cast<int*>(take(MDGAT_MAX_LAYERS));
     w.near_cap = near_capacity(R);
     w.near_recs = reinterpret_cast<RepairRec*>(take((size_t)w.near_cap * (sizeof(RepairRec) / sizeof(float))));
+    if (f64) {
+        w.x64 = reinterpret_cast<double*>(take(R * 128 * 2));
+        w.qkv64 = reinterpret_cast<double*>(take(R * 384 * 2));     // qkv64 and hid64 are contiguous: the encoder stages live there
+        w.hid64 = reinterpret_cast<double*>(take(R * 256 * 2));
+        w.msg64 = reinterpret_cast<double*>(take(R * 128 * 2));
+    }
     w.total = o;
     return w;
 }
@@ -287,13 +319,47 @@ static GemmArgs pointwise(const float* A, int lda, int K, const float* W, const 
     return g;
 }
 
-static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
-                        const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
-                        const float* rec0, const float* rec1, int normalize_fpfh,
+// inputs of a forward: six fp32 arrays, or raw 37-float frame records, or (MDGAT_ARITH_FP64) six fp64 arrays
+struct FwdIn {
+    const float *kpts0, *sigma0, *fpfh0, *kpts1, *sigma1, *fpfh1;
+    const float *rec0, *rec1;
+    int normalize_fpfh;
+    const double *dk0, *ds0, *df0, *dk1, *ds1, *df1;
+    // the same inputs from pair c on (slices of a batch)
+    FwdIn from(size_t c, int N, int M) const {
+        auto o = [](auto* q, size_t n) { return q ? q + n : q; };
+        return FwdIn{o(kpts0, c * N * 3), o(sigma0, c * N), o(fpfh0, c * N * 33), o(kpts1, c * M * 3), o(sigma1, c * M), o(fpfh1, c * M * 33),
+                     o(rec0, c * N * 37), o(rec1, c * M * 37), normalize_fpfh,
+                     o(dk0, c * N * 3), o(ds0, c * N), o(df0, c * N * 33), o(dk1, c * M * 3), o(ds1, c * M), o(df1, c * M * 33)};
+    }
+};
+
+// MDGAT_ARITH_FP64: the number of leading propagation layers that run in fp64 (mdgat_config.f64_layers)
+static int f64_layer_count(const mdgat_config& cfg) {
+    if (cfg.f64_layers >= 0) return cfg.f64_layers;
+    int n = 0;
+    for (int i = 0; i < 2 * cfg.L; ++i)
+        if (cfg.topk[i] > 0) n = i + 1;
+    return n;
+}
+
+static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
                         int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                         const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0, int lane = 0) {
+    const float *kpts0 = in.kpts0, *sigma0 = in.sigma0, *fpfh0 = in.fpfh0, *kpts1 = in.kpts1, *sigma1 = in.sigma1, *fpfh1 = in.fpfh1;
+    const float *rec0 = in.rec0, *rec1 = in.rec1;
+    const int normalize_fpfh = in.normalize_fpfh;
+    const bool f64 = in.dk0 != nullptr;
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
+    if (f64 && (h->cfg.arithmetic != MDGAT_ARITH_FP64 || !h->loaded64)) {
+        mdgat_set_error("mdgat_forward_f64: the handle needs MDGAT_ARITH_FP64 and mdgat_load_weights_f64");
+        return h->cfg.arithmetic != MDGAT_ARITH_FP64 ? MDGAT_ERR_BAD_ARG : MDGAT_ERR_NO_WEIGHTS;
+    }
+    if (!f64 && h->cfg.arithmetic == MDGAT_ARITH_FP64) {
+        mdgat_set_error("mdgat_forward: this handle computes in fp64 (MDGAT_ARITH_FP64): call mdgat_forward_f64 with fp64 inputs");
+        return MDGAT_ERR_BAD_ARG;
+    }
     if (static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_RANGE]) {
         // the forward is asynchronous: what an earlier launch found surfaces here unless the caller asked first
         // (mdgat_async_status after its own synchronisation - MDGAT.forward does)
@@ -304,11 +370,12 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     }
     if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
     const bool arrays = kpts0 && sigma0 && fpfh0 && kpts1 && sigma1 && fpfh1;
-    if ((!arrays && !(rec0 && rec1)) || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
+    const bool arrays64 = in.dk0 && in.ds0 && in.df0 && in.dk1 && in.ds1 && in.df1;
+    if ((!arrays && !(rec0 && rec1) && !arrays64) || !matches0 || !matches1 || !mscores0 || !mscores1 || !workspace) {
         mdgat_set_error("mdgat_forward: null pointer argument");
         return MDGAT_ERR_BAD_ARG;
     }
-    const size_t need = carve(nullptr, B, N, M).total * sizeof(float);
+    const size_t need = carve(nullptr, B, N, M, h->cfg.arithmetic == MDGAT_ARITH_FP64).total * sizeof(float);
     if (workspace_bytes < need) { mdgat_set_error("mdgat_forward: workspace %zu < %zu bytes", workspace_bytes, need); return MDGAT_ERR_BAD_ARG; }
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) { mdgat_set_error("mdgat_forward: workspace must be 256-byte aligned"); return MDGAT_ERR_BAD_ARG; }
     const int L2 = 2 * h->cfg.L;
@@ -322,7 +389,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     hipStream_t s = static_cast<hipStream_t>(stream);
     const BlobLayout& bl = h->bl;
     const float* w = h->weights;
-    Workspace ws = carve(static_cast<float*>(workspace), B, N, M);
+    Workspace ws = carve(static_cast<float*>(workspace), B, N, M, h->cfg.arithmetic == MDGAT_ARITH_FP64);
     const int P = N + M;
     const int R = B * P;
     int rc;
@@ -350,24 +417,73 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     if (repair)
         if ((rc = mdgat_check_hip(hipMemsetAsync(ws.near_count, 0, MDGAT_MAX_LAYERS * sizeof(int), s), "memset(near-threshold counters)"))) return rc;
 
-    // ---- encoders (mdgat.py:392-393), one fused launch ----
-    {
+    const Qkv16 q16 = mdgat_qkv16_carve(ws.qkv16, B, N, M);
+    if ((N & 31) || (M & 31))   // the attention kernel reads V^T in whole 32-key blocks: pad columns must be zero
+        if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
+    int first = 0;              // the first propagation layer the fp32-class kernels run
+    if (!f64) {
+        // ---- encoders (mdgat.py:392-393), one fused launch ----
         EncoderLaunch e{};
         e.kpts0 = kpts0; e.sigma0 = sigma0; e.fpfh0 = fpfh0; e.kpts1 = kpts1; e.sigma1 = sigma1; e.fpfh1 = fpfh1;
         e.rec0 = rec0; e.rec1 = rec1; e.normalize = normalize_fpfh;
         e.w = w; e.bl = &bl; e.es = h->wsplit + WS_LAYER * (size_t)L2 + WS_FINAL;
         e.x = ws.x; e.B = B; e.N = N; e.M = M;
         if ((rc = launch_encoder(e, s))) return rc;
+        mark(MDGAT_PROF_ENCODER);
+        if (taps && taps->x_enc)
+            if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
+    } else {
+        // ---- MDGAT_ARITH_FP64 (f64.hip): encoders and the layers up to the last dynamic one in the reference's arithmetic ----
+        const double* w64 = h->weights64;
+        const size_t Rz = (size_t)R;
+        auto gemm = [&](const double* A0, int lda0, int K0, const double* A1, int lda1, size_t wofs, size_t bofs, int relu, const double* Rs, double* C, int ldc,
+                        int cout, int K) {
+            GemmF64Args g{A0, lda0, K0, A1, lda1, w64 + wofs, K, w64 + bofs, Rs, ldc, C, ldc, R, cout, K, relu};
+            return launch_gemm_f64(g, s);
+        };
+        // encoder stages in the (contiguous) q|k|v + hidden area: 4 + 33 + 32 + 64 + 128 + 64 + 128 = 453 of 640 doubles per point
+        double* in4 = ws.qkv64;
+        double* in33 = in4 + Rz * 4;
+        double* hk1 = in33 + Rz * 33;
+        double* hk2 = hk1 + Rz * 32;
+        double* hk3 = hk2 + Rz * 64;
+        double* hd1 = hk3 + Rz * 128;
+        double* hd2 = hd1 + Rz * 64;
+        if ((rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, s))) return rc;
+        mark(MDGAT_PROF_F64_OTHER);
+        // KeypointEncoder (mdgat.py:184-188), DescriptorEncoder (152-155), their sum (392-393) as one product over [hd ; hk]
+        if ((rc = gemm(in4, 4, 4, nullptr, 0, bl.kenc0_w, bl.kenc0_b, 1, nullptr, hk1, 32, 32, 4))) return rc;
+        if ((rc = gemm(hk1, 32, 32, nullptr, 0, bl.kenc1_w, bl.kenc1_b, 1, nullptr, hk2, 64, 64, 32))) return rc;
+        if ((rc = gemm(hk2, 64, 64, nullptr, 0, bl.kenc2_w, bl.kenc2_b, 1, nullptr, hk3, 128, 128, 64))) return rc;
+        if ((rc = gemm(in33, 33, 33, nullptr, 0, bl.denc0_w, bl.denc0_b, 1, nullptr, hd1, 64, 64, 33))) return rc;
+        if ((rc = gemm(hd1, 64, 64, nullptr, 0, bl.denc1_w, bl.denc1_b, 1, nullptr, hd2, 128, 128, 64))) return rc;
+        if ((rc = gemm(hd2, 128, 128, hk3, 128, bl.encl_w, bl.encl_b, 0, nullptr, ws.x64, 128, 128, 256))) return rc;
+        mark(MDGAT_PROF_F64_GEMM);
+        if (taps && taps->x_enc)
+            if ((rc = launch_f64_to_f32(ws.x64, taps->x_enc, Rz * 128, s))) return rc;
+        first = f64_layer_count(h->cfg);
+        for (int i = 0; i < first; ++i) {
+            const size_t lo = bl.layer0 + (size_t)i * bl.layer_stride;
+            // MultiHeadedAttention (mdgat.py:223-237; merge is folded into mlp.0 by pack.py), attention / dynamic_attention (190-210)
+            if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, lo + bl.qkv_w, lo + bl.qkv_b, 0, nullptr, ws.qkv64, 384, 384, 128))) return rc;
+            mark(MDGAT_PROF_F64_GEMM);
+            uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
+            if ((rc = launch_attention_f64(B, N, M, i & 1, h->cfg.topk[i], ws.qkv64, ws.msg64, sel, s))) return rc;
+            mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_F64_ATTENTION_TOPK : MDGAT_PROF_F64_ATTENTION_FULL);
+            // AttentionalPropagation + residual (mdgat.py:246-248, 274)
+            if ((rc = gemm(ws.x64, 128, 128, ws.msg64, 128, lo + bl.mlp1_w, lo + bl.mlp1_b, 1, nullptr, ws.hid64, 256, 256, 256))) return rc;
+            if ((rc = gemm(ws.hid64, 256, 256, nullptr, 0, lo + bl.mlp2_w, lo + bl.mlp2_b, 0, ws.x64, ws.x64, 128, 128, 256))) return rc;
+            mark(MDGAT_PROF_F64_GEMM);
+            if (taps && taps->x_layers)
+                if ((rc = launch_f64_to_f32(ws.x64, taps->x_layers + (size_t)i * Rz * 128, Rz * 128, s))) return rc;
+        }
+        // hand-over: nothing behind the last dynamic layer is discontinuous
+        if ((rc = launch_f64_to_f32(ws.x64, ws.x, Rz * 128, s))) return rc;
+        mark(MDGAT_PROF_F64_OTHER);
     }
-    mark(MDGAT_PROF_ENCODER);
-    if (taps && taps->x_enc)
-        if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_enc, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_enc"))) return rc;
 
     // ---- 2L attentional propagation layers (mdgat.py:259-276) ----
     // launch i: [attention of layer i] -> [mlp + residual of layer i | q/k/v of layer i + 1 (or final_proj)]
-    const Qkv16 q16 = mdgat_qkv16_carve(ws.qkv16, B, N, M);
-    if ((N & 31) || (M & 31))   // the attention kernel reads V^T in whole 32-key blocks: pad columns must be zero
-        if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
     float* mdesc = ws.hid;
     const _Float16* wfinal = h->wsplit + WS_LAYER * (size_t)L2;
     const _Float16* wfrag = h->wsplit + wsplit_halves(h->cfg.L);      // fragment-order copies (layer_split.hip)
@@ -375,12 +491,12 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     {
         LayerLaunch p{};
         p.x = ws.x; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 0; p.guard = status_dev + MDGAT_STATUS_RANGE;
-        if (L2 > 0) { p.mode3 = 1; p.w3s = h->wsplit + WS_QKV; p.w3f = wfrag + WF_QKV; p.b3 = w + bl.layer0 + bl.qkv_b; }
+        if (first < L2) { p.mode3 = 1; p.w3s = h->wsplit + WS_LAYER * (size_t)first + WS_QKV; p.w3f = wfrag + WF_LAYER * (size_t)first + WF_QKV; p.b3 = w + bl.layer0 + (size_t)first * bl.layer_stride + bl.qkv_b; }
         else { p.mode3 = 2; p.w3s = wfinal; p.w3f = ffinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
         mark(MDGAT_PROF_LAYER_FIRST);
     }
-    for (int i = 0; i < L2; ++i) {
+    for (int i = first; i < L2; ++i) {
         const float* lw = w + bl.layer0 + (size_t)i * bl.layer_stride;
         const _Float16* ls = h->wsplit + WS_LAYER * (size_t)i;
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
@@ -392,7 +508,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
         if (fix) {
             // ws.x still holds this layer's input (the descriptors q / k / v were projected from)
             RepairLaunch rp{q16, ws.msg, ws.x, lw + bl.qkv_w, lw + bl.qk_lo_w, lw + bl.qkv_b, lw + bl.qk_lo_b, B, N, M, cross, kk, nl, sel,
-                            (taps && taps->repair_stats) ? taps->repair_stats + 4 * i : nullptr};
+                            (taps && taps->repair_stats) ? taps->repair_stats + 4 * i : nullptr, status_dev + MDGAT_STATUS_REPAIR_GIVEUP};
             if ((rc = launch_topk_repair(rp, s))) return rc;
         }
         mark(kk > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
@@ -425,7 +541,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const float* kpts0
     const bool fused = ws.sk_bytes != 0;   // N, M <= 2048: the cluster kernel, arg-maxes fused
     float* Zout = Z ? Z : (fused ? nullptr : ws.Z);
     const SkExtract ex{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust,
-                       status_dev + MDGAT_STATUS_MATCHED, h->match_token};
+                       status_dev + MDGAT_STATUS_MATCHED + (h->match_token % MDGAT_MATCH_SLOTS), h->match_token};
     if ((rc = launch_sinkhorn(B, N, M, ws.scores, w + bl.bin_score, 0.f, h->cfg.sinkhorn_iters, Zout, ws.sk, ws.sk_bytes, &ex, s, status_dev,
                               Z ? Z : ws.Z, sk_clear != 0))) return rc;
     mark(MDGAT_PROF_SINKHORN);
@@ -468,7 +584,7 @@ static int prof_collect(mdgat_handle* h) {
 // Taps (whole-batch layouts) run unsliced; mdgat_set_lanes(h, 1) / MDGAT_FORWARD_LANES=1 keeps everything on the caller's stream
 // (slices of 65 536 keypoints beyond 1.5 x that).
 struct LanePlan { int nslices, per, lanes; size_t lane_bytes; };
-static LanePlan lane_plan(int lanes, int B, int N, int M) {
+static LanePlan lane_plan(int lanes, int B, int N, int M, bool f64) {
     static const long env_points = [] { const char* e = getenv("MDGAT_FORWARD_SLICE_POINTS"); return e ? atol(e) : -1L; }();   // unset: defaults; 0: never slice
     LanePlan p{1, B, 1, 0};
     const long per_pair = (long)N + M;
@@ -492,15 +608,16 @@ static LanePlan lane_plan(int lanes, int B, int N, int M) {
         p.per = (int)((B + n - 1) / n);
         p.nslices = (B + p.per - 1) / p.per;
     }
-    p.lane_bytes = (carve(nullptr, p.per, N, M).total * sizeof(float) + 255) & ~size_t(255);
+    p.lane_bytes = (carve(nullptr, p.per, N, M, f64).total * sizeof(float) + 255) & ~size_t(255);
     return p;
 }
 
 extern "C" size_t mdgat_workspace_bytes(const mdgat_handle* h, int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     // (taps run unsliced: the whole batch's workspace is the lower bound in every case)
-    const size_t whole = carve(nullptr, B, N, M).total * sizeof(float);
-    const LanePlan p = lane_plan(h ? h->lanes : 2, B, N, M);
+    const bool f64 = h && h->cfg.arithmetic == MDGAT_ARITH_FP64;
+    const size_t whole = carve(nullptr, B, N, M, f64).total * sizeof(float);
+    const LanePlan p = lane_plan(h ? h->lanes : 2, B, N, M, f64);
     const size_t laned = p.lane_bytes * (size_t)p.lanes;
     return whole > laned ? whole : laned;
 }
@@ -511,19 +628,16 @@ extern "C" int mdgat_set_lanes(mdgat_handle* h, int lanes) {
     return MDGAT_OK;
 }
 
-static int forward_batched(mdgat_handle* h, int B, int N, int M, const float* kpts0, const float* sigma0,
-                           const float* fpfh0, const float* kpts1, const float* sigma1, const float* fpfh1,
-                           const float* rec0, const float* rec1, int normalize_fpfh,
+static int forward_batched(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
                            int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                            const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     LanePlan p{1, B, 1, 0};
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
     std::lock_guard<std::mutex> serialise(h->enqueue);
     if (++h->match_token == 0) h->match_token = 1;      // this call's token (mdgat_matched_any): every slice / lane of the call writes the same one
-    if (!taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M);
+    if (!taps && B > 0 && N > 0 && M > 0 && matches0 && matches1 && mscores0 && mscores1) p = lane_plan(h->lanes, B, N, M, h->cfg.arithmetic == MDGAT_ARITH_FP64);
     if (p.nslices <= 1) {
-        const int rc = forward_impl(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, rec0, rec1, normalize_fpfh, matches0, matches1,
-                                    mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+        const int rc = forward_impl(h, B, N, M, in, matches0, matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
         return rc ? rc : prof_collect(h);
     }
     if (!workspace || workspace_bytes < p.lane_bytes * (size_t)p.lanes) {
@@ -538,14 +652,12 @@ static int forward_batched(mdgat_handle* h, int B, int N, int M, const float* kp
         if ((rc = mdgat_check_hip(hipEventRecord(h->ev_fork, s0), "fork record"))) return rc;
         if ((rc = mdgat_check_hip(hipStreamWaitEvent(h->lane_stream, h->ev_fork, 0), "fork wait"))) return rc;
     }
-    auto off = [](const float* q, size_t n) { return q ? q + n : nullptr; };
     int slice = 0;
     for (int c = 0; c < B && !rc; c += p.per, ++slice) {
         const int b = B - c < p.per ? B - c : p.per;
         const size_t c_ = (size_t)c;
         const int lane = p.lanes == 2 ? (slice & 1) : 0;
-        rc = forward_impl(h, b, N, M, off(kpts0, c_ * N * 3), off(sigma0, c_ * N), off(fpfh0, c_ * N * 33), off(kpts1, c_ * M * 3),
-                          off(sigma1, c_ * M), off(fpfh1, c_ * M * 33), off(rec0, c_ * N * 37), off(rec1, c_ * M * 37), normalize_fpfh,
+        rc = forward_impl(h, b, N, M, in.from(c_, N, M),
                           matches0 + c_ * N, matches1 + c_ * M, mscores0 + c_ * N, mscores1 + c_ * M,
                           Z ? Z + c_ * (N + 1) * (M + 1) : nullptr, nullptr, static_cast<char*>(workspace) + (size_t)lane * p.lane_bytes,
                           p.lane_bytes, lane ? static_cast<void*>(h->lane_stream) : stream, 1, lane);
@@ -566,8 +678,17 @@ extern "C" int mdgat_forward(mdgat_handle* h, int B, int N, int M, const float* 
                              int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
                              const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
     if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1) { mdgat_set_error("mdgat_forward: null input pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_batched(h, B, N, M, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, matches0, matches1, mscores0,
-                          mscores1, Z, taps, workspace, workspace_bytes, stream);
+    const FwdIn in{kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return forward_batched(h, B, N, M, in, matches0, matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+}
+
+extern "C" int mdgat_forward_f64(mdgat_handle* h, int B, int N, int M, const double* kpts0, const double* sigma0,
+                                 const double* fpfh0, const double* kpts1, const double* sigma1, const double* fpfh1,
+                                 int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
+                                 const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!kpts0 || !sigma0 || !fpfh0 || !kpts1 || !sigma1 || !fpfh1) { mdgat_set_error("mdgat_forward_f64: null input pointer"); return MDGAT_ERR_BAD_ARG; }
+    const FwdIn in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1};
+    return forward_batched(h, B, N, M, in, matches0, matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* frames0, const float* frames1,
@@ -575,8 +696,8 @@ extern "C" int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const 
                                     float* mscores1, float* Z, const mdgat_taps* taps, void* workspace,
                                     size_t workspace_bytes, void* stream) {
     if (!frames0 || !frames1) { mdgat_set_error("mdgat_forward_frames: null frame pointer"); return MDGAT_ERR_BAD_ARG; }
-    return forward_batched(h, B, N, M, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, matches0,
-                          matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
+    const FwdIn in{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, frames0, frames1, normalize_fpfh, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    return forward_batched(h, B, N, M, in, matches0, matches1, mscores0, mscores1, Z, taps, workspace, workspace_bytes, stream);
 }
 
 extern "C" int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation) {
@@ -594,11 +715,22 @@ extern "C" int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn
     return MDGAT_OK;
 }
 
-extern "C" int mdgat_matched_any(mdgat_handle* h, unsigned* matched) {
+extern "C" int mdgat_topk_repair_status(mdgat_handle* h, int clear, unsigned* given_up) {
+    if (!h || !given_up) { mdgat_set_error("mdgat_topk_repair_status: null argument"); return MDGAT_ERR_BAD_ARG; }
+    volatile unsigned* st = h->host_error;
+    *given_up = st[MDGAT_STATUS_REPAIR_GIVEUP];
+    if (clear) st[MDGAT_STATUS_REPAIR_GIVEUP] = 0;
+    return MDGAT_OK;
+}
+
+extern "C" unsigned mdgat_last_token(mdgat_handle* h) { return h ? h->match_token : 0u; }
+
+extern "C" int mdgat_matched_any(mdgat_handle* h, unsigned token, unsigned* matched) {
     if (!h || !matched) { mdgat_set_error("mdgat_matched_any: null argument"); return MDGAT_ERR_BAD_ARG; }
-    // the extraction kernels of the LAST forward enqueued on this handle write that call's token when a frame-0 keypoint is
-    // matched (host-mapped word; stream order makes the last call's write the last one)
-    *matched = static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_MATCHED] == h->match_token ? 1u : 0u;
+    // the extraction kernels of the forward that carried `token` write it into the token's slot when a frame-0 keypoint is matched
+    // (host-mapped words; a slot per call, so calls of other threads / streams on this handle in between do not disturb the answer)
+    if (!token) token = h->match_token;
+    *matched = static_cast<volatile unsigned*>(h->host_error)[MDGAT_STATUS_MATCHED + (token % MDGAT_MATCH_SLOTS)] == token ? 1u : 0u;
     return MDGAT_OK;
 }
 
@@ -711,4 +843,17 @@ extern "C" int mdgat_gt_matches(int B, int N, int M, const float* kpts0, const f
     if (!kpts0 || !kpts1 || !gt0 || !gt1 || !rep) { mdgat_set_error("mdgat_gt_matches: null pointer"); return MDGAT_ERR_BAD_ARG; }
     if (N <= 0 || M <= 0) { mdgat_set_error("mdgat_gt_matches: empty frame"); return MDGAT_ERR_BAD_ARG; }
     return launch_gt_match(B, N, M, kpts0, kpts1, T0, T1, threshold, mutual, gt0, gt1, rep, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_pointwise_f64(int M, int N, int K, const double* A, int lda, const double* W, int ldw, const double* bias,
+                                   int relu, const double* R, int ldr, double* C, int ldc, void* stream) {
+    if (!A || !W || !C) { mdgat_set_error("mdgat_pointwise_f64: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    const GemmF64Args g{A, lda, K, nullptr, 0, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu};
+    return launch_gemm_f64(g, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, void* stream) {
+    if (!qkv || !msg) { mdgat_set_error("mdgat_attention_f64: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (topk < 0) { mdgat_set_error("mdgat_attention_f64: topk < 0"); return MDGAT_ERR_BAD_ARG; }
+    return launch_attention_f64(B, N, M, cross, topk, qkv, msg, sel, static_cast<hipStream_t>(stream));
 }

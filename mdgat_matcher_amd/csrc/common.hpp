@@ -47,7 +47,9 @@ struct KeyLayout16 { static __device__ constexpr int koff(int jb, int r) { retur
 #ifdef __HIPCC__
 // base-2 logit units.  Error of a logit against exact arithmetic on the same layer input: rms 1.9e-6, max 1.4e-5 for
 // logits of standard deviation 2.8 (profiles/NOTES_r3.md), proportional to the logits' scale - (|m| + |thr|) / 10 is ~1 there.
-__device__ __forceinline__ float mdgat_near_eps(float thr, float m) { return 2.0e-5f * fmaxf(1.0f, (fabsf(m) + fabsf(thr)) * 0.1f); }
+// What decides a flip is the DIFFERENCE of two logits, whose error can reach twice the per-logit maximum (2.8e-5): the window is
+// 4e-5 (round 5; it was 2e-5 - inside the measured worst case of a difference).  A few more rows are listed for it.
+__device__ __forceinline__ float mdgat_near_eps(float thr, float m) { return 4.0e-5f * fmaxf(1.0f, (fabsf(m) + fabsf(thr)) * 0.1f); }
 #endif
 
 // row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
@@ -151,6 +153,7 @@ struct RepairLaunch {
     int B, N, M, cross, topk;
     NearList near;
     uint32_t* sel; int* stats;
+    unsigned* giveup = nullptr;     // optional host-mapped word (MDGAT_STATUS_REPAIR_GIVEUP): rows left undecided are counted there
 };
 int launch_topk_repair(const RepairLaunch& p, hipStream_t s);
 // full attention as a stream of 64-key chunks (attention_stream.hip); frames with key counts that are multiples of 64
@@ -193,9 +196,13 @@ int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float
 // Asynchronous status words of a handle (host-mapped memory the kernels write; read by the host after a synchronisation).
 constexpr int MDGAT_STATUS_SK_FALLBACK = 0;   // the Sinkhorn cluster kernel lost a partner workgroup: the launch was redone by the streaming kernel
 constexpr int MDGAT_STATUS_RANGE = 1;         // an activation left the f16 operand range or is not finite: the outputs are invalid
-constexpr int MDGAT_STATUS_MATCHED = 2;       // token of the last forward whose extraction matched at least one frame-0 keypoint (mdgat.py:465: the
-                                              // reference tests valid0.sum() on the host; mdgat_matched_any reads this word instead of a reduction + copy)
-constexpr int MDGAT_STATUS_WORDS = 4;
+constexpr int MDGAT_STATUS_REPAIR_GIVEUP = 2; // exact_topk (repair.hip): near-threshold rows NOT re-decided - more than 16 candidates inside the window (masses of
+                                              // equal logits: such a row keeps every logit >= its threshold, possibly more than k) or dropped from a full list
+constexpr int MDGAT_STATUS_MATCHED = 4;       // first of MDGAT_MATCH_SLOTS words: slot (token % slots) receives the token of a forward whose extraction matched
+                                              // at least one frame-0 keypoint (mdgat.py:465: the reference tests valid0.sum() on the host; mdgat_matched_any
+                                              // reads the call's slot instead of a reduction + copy; a slot per call: concurrent callers of one handle)
+constexpr int MDGAT_MATCH_SLOTS = 256;
+constexpr int MDGAT_STATUS_WORDS = MDGAT_STATUS_MATCHED + MDGAT_MATCH_SLOTS;
 constexpr float MDGAT_F16_GUARD = 6.0e4f;     // f16 max is 65504; the split's hi plane must stay finite
 // status (optional, device pointer to MDGAT_STATUS_WORDS host-mapped words).  Zfb: where the streaming fallback puts Z when
 // the cluster kernel lost a partner and the caller wanted no Z (NULL: the cluster launch is cooperative instead).

@@ -1,0 +1,691 @@
+// Reference-exact arithmetic (mdgat_config.arithmetic == MDGAT_ARITH_FP64): the encoders and the propagation layers up to and
+// including the last DYNAMIC layer in fp64 on v_mfma_f64_16x16x4_f64.
+//
+// Why: dynamic_attention (mdgat.py:196-210) keeps the k largest logits of a row - a discontinuous function of the logits.  The
+// reference computes them in fp64; the fp32-class (split-f16) kernels of the default path resolve ~1e-5, so about 1.5 rows per
+// pair at N = 512 keep another key than the reference does and Z moves by 1e-4 ... 8e-4 around that keypoint.  Re-deciding near
+// ties inside a layer does not help (repair.hip): the flips arrive with the layer's INPUT, the accumulated error of the layers
+// before.  So this mode carries the residual stream x, q / k / v, the logits and the softmax in fp64 through the last layer
+// that selects; nothing behind that layer is discontinuous, and the forward hands over to the split-f16 kernels there (api.hip).
+//
+// gfx950 mapping.  v_mfma_f64_16x16x4_f64: A 16x4, B 4x16 one double per lane (row / col = lane & 15, k = lane >> 4); C/D
+// col = lane & 15, row = (lane >> 4) + 4 reg - NOT the f32 layout (cdna_hip_programming.md section 3).  64 cycles per
+// instruction and SIMD: 32 FLOP/clk/SIMD, 78.6 TFLOP/s at 2.4 GHz - the vector fp64 rate; what the matrix instruction buys
+// is operand economy (1024 FMAs from two register pairs), not rate.  At that rate everything else hides behind the matrix
+// pipe as long as there is a second wave per SIMD: the kernels below are plain - LDS tiles for the GEMM, fragments straight
+// from L2 for the attention - and sized for two to three workgroups per CU.
+//
+//   gemm_f64_kernel       C = act(A W^T + b) (+ R): every Conv1d(k=1) of the path (mdgat.py:34-46 after BN folding; 152-155,
+//                         184-188, 227-232, 246-248, 274), 64 x 64 / 64 x 128 tiles, 32-deep K chunks through LDS.
+//   attention_f64_kernel  attention / dynamic_attention (mdgat.py:190-210) for 16 (or 32) queries of a (pair, frame, head) per
+//                         workgroup, the KEYS split over the four waves: S^T = K Q^T puts a query's logits into the four lanes
+//                         (q, q + 16, q + 32, q + 48), the D fragment of a 16-key block is the B operand of the P.V product as
+//                         it stands.  Full attention: online softmax per wave, the waves combined at the end.  Dynamic attention:
+//                         pass A writes the fp32 roundings of the logits (as monotone integers) to LDS, one wave per row finds the
+//                         exact k-th largest of them, pass B recomputes the fp64 logits and keeps what lies above; logits whose
+//                         fp32 roundings TIE at the k-th place are ranked by their fp64 values (a short list per row, resolved
+//                         after the pass).  Rounding is monotone, so the selection is the fp64 top-k exactly.
+#include "common.hpp"
+#include "f64.hpp"
+
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+
+// ================================================================================================ GEMM
+constexpr int G_BM = 64, G_KC = 32, G_LD = G_KC + 2;      // row pitch 34 doubles = 68 dwords: the 64 lanes of a fragment read (row l15, k g) hit 64 banks
+
+template <int WN>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
+__global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
+    constexpr int BN = 32 * WN;
+    extern __shared__ __attribute__((aligned(16))) double gsm[];
+    double* As = gsm;                       // [64][G_LD]
+    double* Ws = gsm + G_BM * G_LD;         // [BN][G_LD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g = lane >> 4;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int row0 = blockIdx.x * G_BM, col0 = blockIdx.y * BN;
+    constexpr int NA = G_BM * G_KC / 256, NW = BN * G_KC / 256;
+    double ra[NA], rw[NW];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) {
+            const int idx = tid + 256 * u, r = idx >> 5, c = idx & 31;
+            const int row = row0 + r, kk = k0 + c;
+            double v = 0.0;
+            if (row < a.M && kk < a.K) v = kk < a.K0 ? a.A0[(size_t)row * a.lda0 + kk] : a.A1[(size_t)row * a.lda1 + (kk - a.K0)];
+            ra[u] = v;
+        }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) {
+            const int idx = tid + 256 * u, r = idx >> 5, c = idx & 31;
+            const int n = col0 + r, kk = k0 + c;
+            rw[u] = (n < a.N && kk < a.K) ? a.W[(size_t)n * a.ldw + kk] : 0.0;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * u; As[(idx >> 5) * G_LD + (idx & 31)] = ra[u]; }
+#pragma unroll
+        for (int u = 0; u < NW; ++u) { const int idx = tid + 256 * u; Ws[(idx >> 5) * G_LD + (idx & 31)] = rw[u]; }
+    };
+    f64x4 acc[2][WN];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < WN; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    fetch(0);
+    stash();
+    __syncthreads();
+    const double* ap = As + (wm * 32 + l15) * G_LD + g;
+    const double* wp = Ws + (wn * 16 * WN + l15) * G_LD + g;
+    for (int k0 = 0; k0 < a.K; k0 += G_KC) {
+        const bool more = k0 + G_KC < a.K;
+        if (more) fetch(k0 + G_KC);                     // the next chunk travels while this one is multiplied
+        const int rem = a.K - k0;
+        const int steps = rem >= G_KC ? G_KC / 4 : (rem + 3) >> 2;
+        for (int j = 0; j < steps; ++j) {
+            double fa[2], fw[WN];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = ap[i * 16 * G_LD + 4 * j];
+#pragma unroll
+            for (int i = 0; i < WN; ++i) fw[i] = wp[i * 16 * G_LD + 4 * j];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int n = 0; n < WN; ++n) acc[i][n] = mfma64(fa[i], fw[n], acc[i][n]);
+        }
+        if (more) {
+            __syncthreads();
+            stash();
+            __syncthreads();
+        }
+    }
+    // D: lane (column l15, g), register i -> row g + 4 i of the 16 x 16 block
+#pragma unroll
+    for (int nb = 0; nb < WN; ++nb) {
+        const int n = col0 + wn * 16 * WN + nb * 16 + l15;
+        if (n >= a.N) continue;
+        const double bias = a.bias ? a.bias[n] : 0.0;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + wm * 32 + mb * 16 + g + 4 * i;
+                if (row >= a.M) continue;
+                double v = acc[mb][nb][i] + bias;
+                if (a.relu) v = v > 0.0 ? v : 0.0;
+                if (a.R) v += a.R[(size_t)row * a.ldr + n];
+                a.C[(size_t)row * a.ldc + n] = v;
+            }
+    }
+}
+
+// ================================================================================================ attention
+// monotone image of a float in the unsigned integers (larger float <-> larger integer; -inf below every finite value)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned b = __builtin_bit_cast(unsigned, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ double shfl_xor_f64(double v, int m) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+// a value of the four lanes (q, q + 16, q + 32, q + 48) of a row combined
+__device__ __forceinline__ double quad_max(double v) { v = fmax(v, shfl_xor_f64(v, 16)); return fmax(v, shfl_xor_f64(v, 32)); }
+__device__ __forceinline__ double quad_sum(double v) { v += shfl_xor_f64(v, 16); return v + shfl_xor_f64(v, 32); }
+
+constexpr int A_LIST = 32;        // logits tied (as fp32 roundings) at the k-th place that are ranked by their fp64 values; more: key order
+struct RowSel { unsigned thr; int mode; int aux; int pad; };
+// mode 0: keep ord >= thr.  mode 1: keep ord > thr, and of the tied (ord == thr) those with key <= aux.  mode 2: keep ord > thr; the
+// tied ones go to the row's list and the `aux` largest of them (fp64 value, then lower key) are added after the pass.
+
+// Exact k-th largest of the nk integers row[0 .. nk) (LDS), one wave per row (the row in registers: NV values per lane), every
+// lane returns the same answer.  Invariant: count(>= L) = cL >= k > cH = count(>= H), L < H.  Probes: the normal quantile of the
+// row first, then Newton steps on the count with the normal density at the probe, then interpolation on the counts and bisection
+// of the integer bracket in turns - the bisection alone closes any bracket in 32 probes, so any distribution terminates.
+template <int NV>
+__device__ RowSel topk_row_search(const unsigned* row, int nk, int k, float zq, int lane) {
+    if (k >= nk) return RowSel{0u, 0, 0, 0};
+    unsigned v[NV];                      // pads: 0, below the image of every float (-inf is 0x007fffff)
+#pragma unroll
+    for (int i = 0; i < NV; ++i) { const int idx = lane + 64 * i; v[i] = idx < nk ? row[idx] : 0u; }
+    float s = 0.f, ss = 0.f;
+    unsigned mn = ~0u, mx = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const bool ok = lane + 64 * i < nk;
+        const float f = ok ? ord2f(v[i]) : 0.f;
+        s += f; ss = fmaf(f, f, ss);
+        mn = min(mn, ok ? v[i] : ~0u); mx = max(mx, v[i]);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+        s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64);
+        mn = min(mn, (unsigned)__shfl_xor((int)mn, m, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64));
+    }
+    const float inv_n = 1.0f / (float)nk;
+    const float mu = s * inv_n;
+    const float sd = sqrtf(fmaxf(ss * inv_n - mu * mu, 1e-12f));
+    const float inv_sd = 1.0f / sd;
+    auto count_ge = [&](unsigned T) {        // T > L >= 0x007fffff: the pads never count
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) c += __popcll(__ballot(v[i] >= T));
+        return c;
+    };
+    unsigned L = mn, H = mx == ~0u ? mx : mx + 1u;
+    int cL = nk, cH = 0;
+    float t = mu + zq * sd;
+    for (int p = 0; p < 200; ++p) {
+        if (cL == k || H - L <= 1u) break;
+        unsigned T;
+        if (p < 4) T = f2ord(t);                                    // quantile, then Newton steps (below)
+        else if (p & 1) {
+            const float fl = ord2f(L), fh = ord2f(H - 1u);
+            T = f2ord(fl + (fh - fl) * (((float)(cL - k) + 0.5f) / (float)(cL - cH)));
+        } else T = L + ((H - L) >> 1);
+        if (!(T > L && T < H)) {                                    // a step that left the bracket: interpolate, else bisect
+            const float fl = ord2f(L), fh = ord2f(H - 1u);
+            T = f2ord(fl + (fh - fl) * (((float)(cL - k) + 0.5f) / (float)(cL - cH)));
+            if (!(T > L && T < H)) T = L + ((H - L) >> 1);
+        }
+        const int c = count_ge(T);
+        if (c >= k) { L = T; cL = c; } else { H = T; cH = c; }
+        const float tp = ord2f(T);
+        const float z = (tp - mu) * inv_sd;
+        const float dens = (float)nk * 0.3989422804f * inv_sd * __expf(-0.5f * z * z);
+        t = tp + ((float)(c - k) + 0.5f) / fmaxf(dens, 1e-3f * (float)nk * inv_sd);
+    }
+    if (cL == k) return RowSel{L, 0, 0, 0};
+    // H == L + 1: L is the k-th largest value and cL - cH >= 2 logits share it
+    const int need = k - cH, ntied = cL - cH;
+    if (ntied <= A_LIST) return RowSel{L, 2, need, 0};
+    int seen = 0, keylim = nk;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        unsigned long long mask = __ballot(v[i] == L);
+        const int c = __popcll(mask);
+        if (keylim == nk && seen + c >= need) {
+            for (int n = need - seen; n > 1; --n) mask &= mask - 1;
+            keylim = 64 * i + __builtin_ctzll(mask);
+        }
+        seen += c;
+    }
+    return RowSel{L, 1, keylim, 0};
+}
+
+// LDS carve of the attention kernel.  The rounding images (dynamic layers) are dead once the rows have been searched - pass B
+// recomputes the logits - so the output partials of the final combine share their space.
+struct AttnLds {
+    double* obuf;        // [4 waves][QT][32]
+    double* mw;          // [4][QT] row maxima per wave
+    double* lw;          // [4][QT] row sums per wave
+    double* lS;          // [QT][A_LIST]   fp64 logits of the tied candidates
+    int* lkey;           // [QT][A_LIST]   their keys (bit 31: kept, set by the resolution)
+    int* lcount;         // [QT]
+    RowSel* sel;         // [QT]
+    unsigned* img;       // [QT][imgld]  (aliases obuf)
+};
+__device__ __forceinline__ AttnLds attn_lds(double* base, int QT) {
+    AttnLds s;
+    s.mw = base; base += 4 * QT;
+    s.lw = base; base += 4 * QT;
+    s.lS = base; base += QT * A_LIST;
+    s.lkey = reinterpret_cast<int*>(base);
+    s.lcount = s.lkey + QT * A_LIST;
+    s.sel = reinterpret_cast<RowSel*>(s.lcount + QT);
+    s.obuf = reinterpret_cast<double*>(s.sel + QT);
+    s.img = reinterpret_cast<unsigned*>(s.obuf);
+    return s;
+}
+size_t attn_lds_bytes(int QT, int nk_max, bool topk) {
+    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel);
+    const size_t ob = (size_t)4 * QT * 32 * 8;
+    const size_t im = topk ? (size_t)QT * (((nk_max + 63) & ~63) + 4) * 4 : 0;
+    return fixed + (ob > im ? ob : im);
+}
+
+template <bool TOPK, int QB, bool TAP>
+__global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
+    constexpr int QT = 16 * QB;
+    extern __shared__ __attribute__((aligned(16))) double asmem[];
+    const AttnLds sm = attn_lds(asmem, QT);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    // 1-D grid, XCD aware: workgroups i, i + 8, i + 16, ... (one XCD under round-robin dispatch) walk the query tiles of ONE unit
+    // (pair, frame, head), whose keys and values they read straight from that XCD's L2
+    const int slot = blockIdx.x >> 3;
+    const int unit = (slot / a.tiles) * 8 + (blockIdx.x & 7), tile = slot % a.tiles;
+    if (unit >= a.units) return;
+    const int head = unit & 3, side = (unit >> 2) & 1, b = unit >> 3;
+    const int P = a.N + a.M;
+    const int nq = side ? a.M : a.N, q_off = side ? a.N : 0;
+    const int src = a.cross ? 1 - side : side;
+    const int nk = src ? a.M : a.N, k_off = src ? a.N : 0;
+    const int q0 = tile * QT;
+    if (q0 >= nq) return;
+    const int imgld = ((nk + 63) & ~63) + 4;
+    const double* kbase = a.qkv + ((size_t)b * P + k_off) * 384 + 128 + head * 32;
+    const double* vbase = kbase + 128;
+
+    // this lane's query fragments: dims 8 g + j of query l15 (B operand of k-step j), pre-scaled by 1 / sqrt(32) (mdgat.py:192, 201)
+    double qf[QB][8];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const int qrow = min(q0 + qb * 16 + l15, nq - 1);
+        const f64x2* p = reinterpret_cast<const f64x2*>(a.qkv + ((size_t)b * P + q_off + qrow) * 384 + head * 32 + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f64x2 v = p[j];
+            qf[qb][2 * j] = v[0] * 0.17677669529663687;
+            qf[qb][2 * j + 1] = v[1] * 0.17677669529663687;
+        }
+    }
+    const int nblk = (nk + 15) >> 4;                    // 16-key blocks; this wave: blocks wave, wave + 4, ...
+    // K fragment of a block: dims 8 g .. 8 g + 7 of key 16 jb + l15 (A operand; dim 8 g + j at k-step j, as in qf)
+    auto kload = [&](int jb, double (&kf)[8]) {
+        const int key = min(jb * 16 + l15, nk - 1);
+        const f64x2* p = reinterpret_cast<const f64x2*>(kbase + (size_t)key * 384 + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const f64x2 v = p[j]; kf[2 * j] = v[0]; kf[2 * j + 1] = v[1]; }
+    };
+    // V fragments of a block: k-step s covers keys 16 jb + 4 s + g; this lane's A operand = dims 2 l15, 2 l15 + 1 of that key
+    // (output dim blocks t = 0, 1: D register r of block t is dim 2 (g + 4 r) + t)
+    auto vload = [&](int jb, f64x2 (&vf)[4]) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int key = min(jb * 16 + 4 * s + g, nk - 1);
+            vf[s] = *reinterpret_cast<const f64x2*>(vbase + (size_t)key * 384 + 2 * l15);
+        }
+    };
+    // logits of one block for query block qb: S[r] = logit of key 16 jb + g + 4 r (pads: -inf)
+    auto logits = [&](int jb, const double (&kf)[8], int qb) {
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc = mfma64(kf[j], qf[qb][j], acc);
+        if (jb * 16 + 16 > nk) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (jb * 16 + g + 4 * r >= nk) acc[r] = -__builtin_inf();
+        }
+        return acc;
+    };
+    f64x4 O[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { O[qb][0] = f64x4{0.0, 0.0, 0.0, 0.0}; O[qb][1] = O[qb][0]; }
+    double lsum[QB], mrun[QB];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) { lsum[qb] = 0.0; mrun[qb] = -__builtin_inf(); }
+
+    if (!TOPK) {
+        // ---- full attention: online softmax over this wave's blocks ----
+        double kf[8], kn[8];
+        f64x2 vf[4];
+        if (wave < nblk) kload(wave, kn);
+        for (int jb = wave; jb < nblk; jb += 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[j] = kn[j];
+            vload(jb, vf);
+            if (jb + 4 < nblk) kload(jb + 4, kn);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const f64x4 S = logits(jb, kf, qb);
+                const double mb = quad_max(fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
+                const double mnew = fmax(mrun[qb], mb);
+                const double sc = exp(mrun[qb] - mnew);           // (first block: exp(-inf) = 0)
+                mrun[qb] = mnew;
+                f64x4 p;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) p[r] = exp(S[r] - mnew);
+                lsum[qb] = lsum[qb] * sc + ((p[0] + p[1]) + (p[2] + p[3]));
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) O[qb][t][r] *= sc;
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    O[qb][0] = mfma64(vf[s][0], p[s], O[qb][0]);
+                    O[qb][1] = mfma64(vf[s][1], p[s], O[qb][1]);
+                }
+            }
+        }
+    } else {
+        // ---- dynamic attention, pass A: fp32 roundings of the logits -> LDS, row maxima ----
+        {
+            double kf[8], kn[8];
+            if (wave < nblk) kload(wave, kn);
+            for (int jb = wave; jb < nblk; jb += 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kf[j] = kn[j];
+                if (jb + 4 < nblk) kload(jb + 4, kn);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) {
+                    const f64x4 S = logits(jb, kf, qb);
+                    mrun[qb] = fmax(mrun[qb], fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
+                    unsigned* row = sm.img + (qb * 16 + l15) * imgld + jb * 16 + g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) row[4 * r] = f2ord((float)S[r]);
+                }
+            }
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                mrun[qb] = quad_max(mrun[qb]);
+                if (g == 0) sm.mw[wave * QT + qb * 16 + l15] = mrun[qb];
+            }
+            if (tid < QT) sm.lcount[tid] = 0;
+        }
+        __syncthreads();
+        // ---- the exact k-th largest rounding of every row: one wave per row ----
+        for (int q = wave; q < QT; q += 4) {
+            const unsigned* row = sm.img + q * imgld;
+            const RowSel rs = nk <= 512 ? topk_row_search<8>(row, nk, a.topk, a.zq, lane)
+                            : nk <= 1024 ? topk_row_search<16>(row, nk, a.topk, a.zq, lane) : topk_row_search<32>(row, nk, a.topk, a.zq, lane);
+            if (lane == 0) sm.sel[q] = rs;
+        }
+        __syncthreads();
+        // ---- pass B: the fp64 logits again, masked softmax against the row maximum, P.V ----
+        RowSel rs[QB];
+        uint32_t* tap[QB];
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const int q = qb * 16 + l15;
+            rs[qb] = sm.sel[q];
+            mrun[qb] = fmax(fmax(sm.mw[q], sm.mw[QT + q]), fmax(sm.mw[2 * QT + q], sm.mw[3 * QT + q]));
+            tap[qb] = TAP ? a.sel + (((size_t)b * 4 + head) * P + q_off + min(q0 + q, nq - 1)) * a.selW : nullptr;
+        }
+        double kf[8], kn[8];
+        f64x2 vf[4];
+        if (wave < nblk) kload(wave, kn);
+        for (int jb = wave; jb < nblk; jb += 4) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) kf[j] = kn[j];
+            vload(jb, vf);
+            if (jb + 4 < nblk) kload(jb + 4, kn);
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) {
+                const f64x4 S = logits(jb, kf, qb);
+                f64x4 p;
+                unsigned bits = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = jb * 16 + g + 4 * r;
+                    const unsigned o = f2ord((float)S[r]);
+                    bool keep = o > rs[qb].thr;
+                    if (o == rs[qb].thr) {
+                        if (rs[qb].mode == 0) keep = true;
+                        else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
+                        else if (key < nk) {
+                            const int q = qb * 16 + l15;
+                            const int slot = atomicAdd(&sm.lcount[q], 1);
+                            if (slot < A_LIST) { sm.lS[q * A_LIST + slot] = S[r]; sm.lkey[q * A_LIST + slot] = key; }
+                        }
+                    }
+                    keep = keep && key < nk;
+                    p[r] = keep ? exp(S[r] - mrun[qb]) : 0.0;
+                    bits |= (unsigned)keep << (4 * r);        // keys 16 jb + g + 4 r
+                }
+                if (TAP && bits && q0 + qb * 16 + l15 < nq) atomicOr(tap[qb] + (jb >> 1), bits << (16 * (jb & 1) + g));
+                lsum[qb] += (p[0] + p[1]) + (p[2] + p[3]);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    O[qb][0] = mfma64(vf[s][0], p[s], O[qb][0]);
+                    O[qb][1] = mfma64(vf[s][1], p[s], O[qb][1]);
+                }
+            }
+        }
+    }
+
+    // ---- combine the four waves: row statistics and output partials through LDS ----
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+        const double l = quad_sum(lsum[qb]);
+        const int q = qb * 16 + l15;
+        if (g == 0) { sm.lw[wave * QT + q] = l; if (!TOPK) sm.mw[wave * QT + q] = mrun[qb]; }
+        double* ob = sm.obuf + ((size_t)wave * QT + q) * 32;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ob[2 * (g + 4 * r) + t] = O[qb][t][r];
+    }
+    __syncthreads();
+    if (TOPK) {
+        // rows with tied roundings at the k-th place: rank the listed candidates by fp64 value (then lower key), keep `aux`
+        for (int q = wave; q < QT; q += 4) {
+            const RowSel r = sm.sel[q];
+            if (r.mode != 2) continue;
+            const int n = min(sm.lcount[q], A_LIST);
+            if (lane < n) {
+                const double si = sm.lS[q * A_LIST + lane];
+                const int ki = sm.lkey[q * A_LIST + lane];
+                int rank = 0;
+                for (int j = 0; j < n; ++j) {
+                    const double sj = sm.lS[q * A_LIST + j];
+                    const int kj = sm.lkey[q * A_LIST + j];
+                    rank += (sj > si) || (sj == si && kj < ki);
+                }
+                if (rank < r.aux) {
+                    sm.lkey[q * A_LIST + lane] = ki | (int)0x80000000;
+                    if (TAP && q0 + q < nq) atomicOr(a.sel + (((size_t)b * 4 + head) * P + q_off + q0 + q) * a.selW + (ki >> 5), 1u << (ki & 31));
+                }
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < QT * 16; e += 256) {
+        const int q = e >> 4, d = (e & 15) * 2;
+        if (q0 + q >= nq) continue;
+        double m = -__builtin_inf();
+#pragma unroll
+        for (int w = 0; w < 4; ++w) m = fmax(m, sm.mw[w * QT + q]);
+        double l = 0.0, o0 = 0.0, o1 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const double mwv = sm.mw[w * QT + q];
+            const double f = TOPK ? 1.0 : (mwv == -__builtin_inf() ? 0.0 : exp(mwv - m));
+            l += f * sm.lw[w * QT + q];
+            o0 += f * sm.obuf[((size_t)w * QT + q) * 32 + d];
+            o1 += f * sm.obuf[((size_t)w * QT + q) * 32 + d + 1];
+        }
+        if (TOPK && sm.sel[q].mode == 2) {
+            const int n = min(sm.lcount[q], A_LIST);
+            for (int j = 0; j < n; ++j) {
+                const int kj = sm.lkey[q * A_LIST + j];
+                if (kj >= 0) continue;
+                const double p = exp(sm.lS[q * A_LIST + j] - m);
+                const f64x2 v = *reinterpret_cast<const f64x2*>(vbase + (size_t)(kj & 0x7fffffff) * 384 + d);
+                l += p; o0 += p * v[0]; o1 += p * v[1];
+            }
+        }
+        const double inv = 1.0 / l;
+        *reinterpret_cast<f64x2*>(a.msg + ((size_t)b * P + q_off + q0 + q) * 128 + head * 32 + d) = f64x2{o0 * inv, o1 * inv};
+    }
+}
+
+// ================================================================================================ small kernels
+// encoder inputs (mdgat.py:186-187, 154): in4 [R][4] = x y z saliency, in33 [R][33] = FPFH, rows pair-major (frame 0 then frame 1)
+__global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
+                                                            const double* sigma1, const double* fpfh1, double* in4, double* in33, int B, int N, int M) {
+    const int P = N + M;
+    const size_t total = (size_t)B * P * 37;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t row = idx / 37;
+        const int c = (int)(idx - row * 37);
+        const int b = (int)(row / P), p = (int)(row - (size_t)b * P);
+        const bool f1 = p >= N;
+        const int n = f1 ? p - N : p, cnt = f1 ? M : N;
+        const double* kp = f1 ? kpts1 : kpts0;
+        const double* sg = f1 ? sigma1 : sigma0;
+        const double* fp = f1 ? fpfh1 : fpfh0;
+        const size_t r = (size_t)b * cnt + n;
+        if (c < 3) in4[row * 4 + c] = kp[r * 3 + c];
+        else if (c == 3) in4[row * 4 + 3] = sg[r];
+        else in33[row * 33 + (c - 4)] = fp[r * 33 + (c - 4)];
+    }
+}
+
+__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+
+// measurement only: what v_mfma_f64_16x16x4_f64 sustains (two waves per SIMD, operands in registers, four accumulator chains)
+__global__ __launch_bounds__(512, 2) void mfma64_probe_kernel(const double* src, double* sink, long long* ticks, int reps) {
+    const int tid = threadIdx.x;
+    double x[8], y[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { x[i] = src[tid * 16 + i]; y[i] = src[tid * 16 + 8 + i]; }
+    f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0, c2 = c0, c3 = c0;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+#pragma unroll 1
+    for (int r = 0; r < reps; ++r) {
+#pragma unroll
+        for (int i = 0; i < 8; i += 2) {
+            asm volatile("" : "+v"(x[i]));
+            c0 = mfma64(x[i], y[i], c0);
+            c1 = mfma64(x[i + 1], y[i], c1);
+            c2 = mfma64(x[i], y[i + 1], c2);
+            c3 = mfma64(x[i + 1], y[i + 1], c3);
+        }
+    }
+    const long long t1 = __builtin_amdgcn_s_memtime();
+    const f64x4 c = (c0 + c1) + (c2 + c3);
+    const double s = (c[0] + c[1]) + (c[2] + c[3]);
+    if (s == 123.456) sink[tid] = s;
+    if (tid == 0 && blockIdx.x == 0) ticks[0] = t1 - t0;
+}
+__global__ void mfma64_probe_fill(double* p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        unsigned s = (unsigned)i * 1664525u + 1013904223u;
+        s = s * 1664525u + 1013904223u;
+        p[i] = ((int)(s >> 12) % 2000001 - 1000000) * 1e-6;
+    }
+}
+
+}  // namespace
+
+// ================================================================================================ launchers
+int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MDGAT_OK;
+    static std::atomic<unsigned long long> done2{0}, done4{0};
+    if (a.N > 64) {
+        const size_t lds = (size_t)(G_BM + 128) * G_LD * sizeof(double);
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(gemm_f64_kernel<4>), lds, done4, "gemm_f64 LDS")) return rc;
+        hipLaunchKernelGGL(gemm_f64_kernel<4>, dim3((a.M + G_BM - 1) / G_BM, (a.N + 127) / 128), dim3(256), lds, s, a);
+    } else {
+        const size_t lds = (size_t)(G_BM + 64) * G_LD * sizeof(double);
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(gemm_f64_kernel<2>), lds, done2, "gemm_f64 LDS")) return rc;
+        hipLaunchKernelGGL(gemm_f64_kernel<2>, dim3((a.M + G_BM - 1) / G_BM, (a.N + 63) / 64), dim3(256), lds, s, a);
+    }
+    return mdgat_check_hip(hipGetLastError(), "gemm_f64 launch");
+}
+
+// upper-tail standard normal quantile (only seeds the threshold search)
+static float f64_normal_quantile_upper(double p) {
+    if (p <= 0.0) return 8.f;
+    if (p >= 1.0) return -8.f;
+    // Abramowitz-Stegun 26.2.23 (|error| < 4.5e-4)
+    const bool upper = p < 0.5;
+    const double pp = upper ? p : 1.0 - p;
+    const double t = sqrt(-2.0 * log(pp));
+    const double x = t - (2.515517 + 0.802853 * t + 0.010328 * t * t) / (1.0 + 1.432788 * t + 0.189269 * t * t + 0.001308 * t * t * t);
+    return (float)(upper ? x : -x);
+}
+
+int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s) {
+    if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
+    const int nk_max = N > M ? N : M, nk_min = N < M ? N : M;
+    if (topk > nk_min) {   // torch.topk raises (mdgat.py:202)
+        mdgat_set_error("dynamic attention: k=%d exceeds the number of keys (%d)", topk, nk_min);
+        return MDGAT_ERR_BAD_ARG;
+    }
+    if (nk_max > 2048 && topk > 0) {
+        mdgat_set_error("dynamic attention (fp64): %d keys per frame > 2048 supported", nk_max);
+        return MDGAT_ERR_UNSUPPORTED;
+    }
+    const bool dyn = topk > 0 && !(topk == N && topk == M);
+    AttnF64Args a{};
+    a.qkv = qkv; a.msg = msg; a.N = N; a.M = M; a.cross = cross; a.topk = dyn ? topk : 0;
+    a.zq = dyn ? f64_normal_quantile_upper(((double)topk - 0.5) / (double)nk_max) : 0.f;
+    a.selW = (nk_max + 31) / 32;
+    a.sel = nullptr;
+    a.units = B * 2 * MDGAT_HEADS;
+    if (sel && topk > 0) {
+        if (int rc = mdgat_check_hip(hipMemsetAsync(sel, dyn ? 0 : 0xff, mdgat_topk_sel_words(B, N, M) * sizeof(uint32_t), s), "memset(top-k tap)")) return rc;
+        if (dyn) a.sel = sel;
+    }
+    const int ugroups = (a.units + 7) / 8;
+    auto go = [&](auto kern, int QT, bool tk) -> int {
+        const size_t lds = attn_lds_bytes(QT, nk_max, tk);
+        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention_f64 LDS")) return rc;
+        a.tiles = (nk_max + QT - 1) / QT;
+        hipLaunchKernelGGL(kern, dim3(8 * a.tiles * ugroups), dim3(256), lds, s, a);
+        return mdgat_check_hip(hipGetLastError(), "attention_f64 launch");
+    };
+    // 32 queries per workgroup halve the key traffic per query; 16 where the rounding images of 32 rows would keep a second
+    // workgroup off the CU (66 KB at 512 keys)
+    if (!dyn) return go(attention_f64_kernel<false, 2, false>, 32, false);
+    if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 2, true>, 32, true) : go(attention_f64_kernel<true, 2, false>, 32, true);
+    return a.sel ? go(attention_f64_kernel<true, 1, true>, 16, true) : go(attention_f64_kernel<true, 1, false>, 16, true);
+}
+
+int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
+                        const double* sigma1, const double* fpfh1, double* in4, double* in33, hipStream_t s) {
+    const size_t total = (size_t)B * (N + M) * 37;
+    const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(assemble_f64_kernel, dim3(blocks), dim3(256), 0, s, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, in4, in33, B, N, M);
+    return mdgat_check_hip(hipGetLastError(), "assemble_f64 launch");
+}
+
+int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s) {
+    if (!n) return MDGAT_OK;
+    const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+    return mdgat_check_hip(hipGetLastError(), "f64_to_f32 launch");
+}
+
+extern "C" int mdgat_mfma_f64_probe(int reps, void* workspace, size_t workspace_bytes, float* ms_out, double* flops_out,
+                                    long long* ticks_out, void* stream) {
+    const size_t need = (size_t)512 * 16 * 8 + 512 * 8 + 256;
+    if (reps <= 0 || !workspace || workspace_bytes < need || !ms_out || !flops_out || !ticks_out) {
+        mdgat_set_error("mdgat_mfma_f64_probe: bad argument (workspace >= %zu bytes)", need);
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int dev = 0, num_cu = 0;
+    if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
+    if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "hipDeviceGetAttribute")) return rc;
+    double* src = static_cast<double*>(workspace);
+    double* sink = src + 512 * 16;
+    long long* ticks = reinterpret_cast<long long*>(sink + 512);
+    hipLaunchKernelGGL(mfma64_probe_fill, dim3(32), dim3(256), 0, s, src, 512 * 16);
+    const int grid = num_cu * 2;
+    hipLaunchKernelGGL(mfma64_probe_kernel, dim3(grid), dim3(512), 0, s, src, sink, ticks, 8);      // warm-up
+    hipEvent_t e0, e1;
+    if (int rc = mdgat_check_hip(hipEventCreate(&e0), "hipEventCreate")) return rc;
+    if (int rc = mdgat_check_hip(hipEventCreate(&e1), "hipEventCreate")) { (void)hipEventDestroy(e0); return rc; }
+    (void)hipEventRecord(e0, s);
+    hipLaunchKernelGGL(mfma64_probe_kernel, dim3(grid), dim3(512), 0, s, src, sink, ticks, reps);
+    (void)hipEventRecord(e1, s);
+    int rc = mdgat_check_hip(hipEventSynchronize(e1), "mfma64 probe");
+    float ms = 0.f;
+    if (!rc) rc = mdgat_check_hip(hipEventElapsedTime(&ms, e0, e1), "hipEventElapsedTime");
+    long long t = 0;
+    if (!rc) rc = mdgat_check_hip(hipMemcpy(&t, ticks, sizeof(t), hipMemcpyDeviceToHost), "hipMemcpy(ticks)");
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    *ms_out = ms;
+    *flops_out = (double)grid * 8.0 /* waves */ * (double)reps * 16.0 /* MFMAs per rep */ * 2048.0;
+    *ticks_out = t;
+    return MDGAT_OK;
+}

@@ -1,0 +1,35 @@
+// fp64 kernels of the reference-exact mode (f64.hip): declarations shared with api.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+// C[M][N] = act(A W^T + bias) (+ R); the K input columns come from A0 (columns [0, K0)) and A1 (columns [K0, K)).  No alignment
+// beyond 8 bytes is assumed of any operand (the FPFH rows are 33 doubles).
+struct GemmF64Args {
+    const double* A0; int lda0; int K0;
+    const double* A1; int lda1;
+    const double* W; int ldw;          // [N][K]
+    const double* bias;                // [N] or nullptr
+    const double* R; int ldr;          // residual [M][N] or nullptr (may alias C)
+    double* C; int ldc;
+    int M, N, K;
+    int relu;
+};
+int launch_gemm_f64(const GemmF64Args& a, hipStream_t s);
+
+struct AttnF64Args {
+    const double* qkv;     // [B][P][384]: q | k | v, each [4 heads][32 dims] (the rows of pack.py's qkv_w)
+    double* msg;           // [B][P][128]: channel = head * 32 + dim
+    int N, M, cross, topk;
+    float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
+    uint32_t* sel;         // parity tap (mdgat_taps.topk_sel layout) or nullptr
+    int selW;
+    int units, tiles;      // B * 2 * 4 (pair, frame, head) units; query tiles per unit
+};
+// attention (topk == 0) / dynamic_attention (mdgat.py:190-210) on fp64 q / k / v; sel: optional tap of the kept keys
+int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s);
+// in4 [R][4] = x y z saliency, in33 [R][33] = FPFH; rows pair-major, frame 0 then frame 1
+int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
+                        const double* sigma1, const double* fpfh1, double* in4, double* in33, hipStream_t s);
+int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);

@@ -52,6 +52,7 @@ struct RepairArgs {
     const int* count; const RepairRec* recs; int cap;
     uint32_t* sel; int selW;
     int* stats;
+    unsigned* giveup;    // optional (host-mapped status word): rows left as the attention kernel wrote them (> NEAR_MAXC candidates, or a full list)
 };
 
 __device__ __forceinline__ double wave_sum_d(double v) {
@@ -207,7 +208,10 @@ __global__ __launch_bounds__(64 * RP_WAVES, 2) void topk_repair_kernel(RepairArg
     const int first = blockIdx.x * RP_WAVES + wave;
     RepairRec r = a.recs[first < a.cap ? first : 0];
     int n = *a.count;
-    if (n > a.cap) n = a.cap;
+    if (n > a.cap) {
+        if (a.giveup && blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.giveup, (unsigned)(n - a.cap));      // rows that did not fit the list
+        n = a.cap;
+    }
     const int P = a.N + a.M;
     for (int rec = first; rec < n; rec += gridDim.x * RP_WAVES) {
         if (rec != first) r = a.recs[rec];
@@ -236,7 +240,10 @@ __global__ __launch_bounds__(64 * RP_WAVES, 2) void topk_repair_kernel(RepairArg
             atomicAdd(a.stats + 0, 1);
             if (nc > NEAR_MAXC) atomicAdd(a.stats + 3, 1);
         }
-        if (nc > NEAR_MAXC) continue;
+        if (nc > NEAR_MAXC) {
+            if (a.giveup && lane == 0) atomicAdd(a.giveup, 1u);
+            continue;
+        }
         const int need = a.topk - R.above;          // candidates to keep
         // the candidates arrived in the order of the LDS atomics: sort them by key, so that the sums below have one order
         if (lane == 0) {
@@ -316,7 +323,7 @@ int launch_topk_repair(const RepairLaunch& p, hipStream_t s) {
     const int nk_max = p.N > p.M ? p.N : p.M;
     if (nk_max > 2048) return MDGAT_OK;                 // (the dynamic kernels reject such frames before this point)
     RepairArgs a{p.qkv.q16, p.qkv.k16, p.qkv.vt16, p.msg, p.x, p.w, p.wlo, p.b, p.blo, p.N, p.M, p.qkv.Npad, p.qkv.PP, p.cross, p.topk,
-                 p.near.count, p.near.recs, p.near.cap, p.sel, (nk_max + 31) / 32, p.stats};
+                 p.near.count, p.near.recs, p.near.cap, p.sel, (nk_max + 31) / 32, p.stats, p.giveup};
     // one wave per listed row (~1 row in 10^3 is listed); a launch that finds the list empty leaves at once
     const long rows = (long)p.B * (p.N + p.M) * 4;
     int blocks = (int)((rows / 256 + RP_WAVES - 1) / RP_WAVES);

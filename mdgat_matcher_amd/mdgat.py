@@ -10,7 +10,10 @@ Host-side mirror of ``/root/reference/models/mdgat.py:315-603`` (class ``MDGAT``
   ``matches0/1`` (int64, -1 = unmatched), ``matching_scores0/1`` (module dtype) and ``loss`` out, the
   empty-keypoint early-out of ``mdgat.py:374-382`` included;
 * tolerant of ``net.double().eval()`` (``test.py:193``): the kernels compute in fp32, results are cast
-  back to the module's dtype.
+  back to the module's dtype;
+* ``MDGAT(config with arithmetic='fp64')`` (not a reference key) selects the library's reference-exact mode: fp64 inputs,
+  fp64 weights and fp64 matrix-core arithmetic through the last dynamic layer, so that every ``logits.topk(k)``
+  (``mdgat.py:202``) selects what the reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``).
 
 All arithmetic happens in ``libmdgat_hip.so``; PyTorch only owns device memory and streams.  There is no
 CPU path: tensors that are not on a gfx950 device raise.  Training (loss / backward) is out of scope:
@@ -106,6 +109,11 @@ class _DeviceState:
             self.handle = None
 
 
+def _sync_raw_stream(handle: int, dev):
+    """Synchronise a stream known by its raw handle (the keys of _DeviceState.workspaces)."""
+    torch.cuda.ExternalStream(handle, device=dev).synchronize()
+
+
 def _close_states(states):
     for st in list(states.values()):
         st.close()
@@ -151,6 +159,16 @@ class MDGAT(nn.Module):
         # BASELINE configs[1]) but not the ones that arrive with the layer's input, which dominate - the number of rows
         # selected differently from the fp64 reference stays the same (profiles/parity_r4.txt) - and costs 3-6 %.
         self.exact_topk = bool(self.config.get('exact_topk', False))
+        # not a reference key: 'fp32' (default: fp32-class arithmetic everywhere) or 'fp64' - the reference's own arithmetic
+        # (test.py:193 runs net.double()) for the encoders and the layers up to the last dynamic one, where the top-k selection
+        # of mdgat.py:202 is decided (include/mdgat_hip.h: mdgat_arithmetic; csrc/f64.hip).  'f64_layers' (optional) overrides
+        # how many leading layers run in fp64 (default -1: through the last layer with a k).
+        self.arithmetic = str(self.config.get('arithmetic', 'fp32'))
+        if self.arithmetic not in ('fp32', 'fp64'):
+            raise ValueError(f"arithmetic={self.arithmetic!r}: expected 'fp32' or 'fp64'")
+        self.f64_layers = int(self.config.get('f64_layers', -1))
+        if self.arithmetic == 'fp64' and self.attention_dtype != 'fp32':
+            raise ValueError("arithmetic='fp64' and attention_dtype='f16' exclude each other")
         if self.descriptor != 'FPFH':
             raise NotImplementedError(
                 f"descriptor={self.descriptor!r}: only the 'FPFH' hot path is implemented on MI355X "
@@ -175,12 +193,13 @@ class MDGAT(nn.Module):
         # [1] True while a blob installed by load_packed() (e.g. received by an RCCL broadcast) stands in for this
         #     module's own parameters: casts / moves of the module must not throw it away.
         self._blob_holder = [None, False]
+        self._blob64_holder = [None]        # arithmetic='fp64': the same blob before its rounding to fp32 (shared like [0] above)
         self._sig_holder = [self._signature()]
         # replicas never run __init__, so only the original module owns (and finally frees) the handles
         weakref.finalize(self, _close_states, self._states)
 
     # ------------------------------------------------------------------ copy / pickle
-    _RUNTIME_ATTRS = ('_states', '_states_lock', '_blob_holder', '_sig_holder')
+    _RUNTIME_ATTRS = ('_states', '_states_lock', '_blob_holder', '_blob64_holder', '_sig_holder')
 
     def __getstate__(self):
         """copy.deepcopy(net) / torch.save(net) (the reference's nn.Module supports both): library handles, locks and packed
@@ -195,6 +214,7 @@ class MDGAT(nn.Module):
         self._states = {}
         self._states_lock = threading.RLock()
         self._blob_holder = [None, False]
+        self._blob64_holder = [None]
         self._sig_holder = [self._signature()]
         weakref.finalize(self, _close_states, self._states)
 
@@ -206,6 +226,7 @@ class MDGAT(nn.Module):
             self._states.clear()
             self._blob_holder[0] = None
             self._blob_holder[1] = False
+            self._blob64_holder[0] = None
 
     def _signature(self):
         ts = list(self.parameters()) + list(self.buffers())
@@ -256,9 +277,11 @@ class MDGAT(nn.Module):
     def _topk_schedule(self):
         return pack.resolve_topk_schedule(self.config['L'], list(self.k))
 
-    def packed_weights(self):
-        """fp32 blob (numpy) of the current parameters in the library's layout."""
-        return pack.pack_state_dict(self.state_dict(), self.config['L'])
+    def packed_weights(self, dtype=None):
+        """fp32 blob (numpy) of the current parameters in the library's layout (``dtype=numpy.float64``: before the
+        rounding to fp32 - what arithmetic='fp64' loads in addition)."""
+        import numpy as np
+        return pack.pack_state_dict(self.state_dict(), self.config['L'], dtype=dtype or np.float32)
 
     def _host_blob(self):
         """The packed blob, made once per set of parameters and shared with DataParallel replicas."""
@@ -268,6 +291,9 @@ class MDGAT(nn.Module):
                     raise RuntimeError('this MDGAT is a DataParallel replica without packed weights: the owner module '
                                        'packs them in _replicate_for_data_parallel() - was replicate() bypassed?')
                 self._blob_holder[0] = self.packed_weights()
+                if getattr(self, 'arithmetic', 'fp32') == 'fp64':
+                    import numpy as np
+                    self._blob64_holder[0] = self.packed_weights(np.float64)
             return self._blob_holder[0]
 
     def _state_for(self, device: torch.device, blob_device_tensor: Optional[torch.Tensor] = None) -> _DeviceState:
@@ -288,6 +314,9 @@ class MDGAT(nn.Module):
             cfg.match_threshold = float(self.config['match_threshold'])
             cfg.attention_mode = 0 if self.attention_dtype == 'fp32' else 1
             cfg.exact_topk = int(getattr(self, 'exact_topk', False))
+            f64 = getattr(self, 'arithmetic', 'fp32') == 'fp64'
+            cfg.arithmetic = _lib.ARITH_FP64 if f64 else _lib.ARITH_FP32
+            cfg.f64_layers = int(getattr(self, 'f64_layers', -1))
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx)
@@ -303,6 +332,13 @@ class MDGAT(nn.Module):
                     assert blob.size == lib.mdgat_blob_floats(L), (blob.size, lib.mdgat_blob_floats(L))
                     _lib.check(lib.mdgat_load_weights(handle, blob.ctypes.data_as(C.c_void_p), blob.size, 0),
                                'mdgat_load_weights')
+                if f64:
+                    blob64 = self._blob64_holder[0]
+                    if blob64 is None:
+                        raise RuntimeError("arithmetic='fp64' needs the fp64 blob: load_packed(blob, blob64) on ranks that "
+                                           'received their weights by broadcast')
+                    _lib.check(lib.mdgat_load_weights_f64(handle, blob64.ctypes.data_as(C.c_void_p), blob64.size, 0),
+                               'mdgat_load_weights_f64')
             except Exception:
                 st.close()
                 raise
@@ -320,10 +356,14 @@ class MDGAT(nn.Module):
                 with st.lock:
                     _lib.check(_lib.load().mdgat_set_lanes(st.handle, lanes), 'mdgat_set_lanes')
 
-    def load_packed(self, blob: torch.Tensor):
+    def load_packed(self, blob: torch.Tensor, blob64: Optional[torch.Tensor] = None):
         """Install an already packed fp32 blob that lives on a GPU (e.g. received by an RCCL broadcast,
-        see shard.broadcast_weights) instead of packing this module's own parameters."""
+        see shard.broadcast_weights) instead of packing this module's own parameters.  arithmetic='fp64' needs
+        ``blob64`` as well: the same blob in float64 (``packed_weights(numpy.float64)``)."""
         assert blob.is_cuda and blob.dtype == torch.float32 and blob.is_contiguous()
+        if getattr(self, 'arithmetic', 'fp32') == 'fp64':
+            if blob64 is None or blob64.dtype != torch.float64 or blob64.numel() != blob.numel():
+                raise ValueError("arithmetic='fp64': load_packed needs blob64, the float64 blob of the same layout")
         idx = blob.device.index
         with self._states_lock:
             old = self._states.pop(idx, None)
@@ -332,6 +372,7 @@ class MDGAT(nn.Module):
             # a host copy as well: any other device of this process (DataParallel replicas, a later .to()) loads the SAME
             # weights from it - never this module's own parameters, which are random init on a rank that received a blob
             self._blob_holder[0] = blob.detach().cpu().numpy().copy()
+            self._blob64_holder[0] = blob64.detach().cpu().numpy().copy() if blob64 is not None else None
             self._blob_holder[1] = True     # stands until load_state_dict() / repack(): see _invalidate_if_changed
             self._sig_holder[0] = self._signature()
             for other in [i for i in self._states if i != idx]:
@@ -354,7 +395,8 @@ class MDGAT(nn.Module):
         if self.training:
             raise NotImplementedError('mdgat_matcher_amd implements inference only: call .eval() (training, the '
                                       'losses of mdgat.py:486-594 and backward are out of scope)')
-        res = self._run(kpts0, data['scores0'], data['descriptors0'], kpts1, data['scores1'], data['descriptors1'])
+        token = [0]
+        res = self._run(kpts0, data['scores0'], data['descriptors0'], kpts1, data['scores1'], data['descriptors1'], token_out=token)
         m0, m1, s0, s1 = res[:4]
         s0, s1 = s0.to(out_dtype), s1.to(out_dtype)
         if self.loss_method != 'superglue':
@@ -364,7 +406,7 @@ class MDGAT(nn.Module):
             # (the library answers from a host-mapped word its extraction kernels write - mdgat_matched_any - so the test costs a
             # stream synchronisation, as in the reference, but no reduction kernel and no copy)
             torch.cuda.current_stream(m0.device).synchronize()
-            nothing_matched = not self._matched_any(m0.device)
+            nothing_matched = not self._matched_any(m0.device, token[0])
             self.check(m0.device, synchronize=False)        # (synchronised above: report this call's status now)
             if nothing_matched:
                 s0, s1 = torch.zeros_like(m0), torch.zeros_like(m1)
@@ -378,13 +420,15 @@ class MDGAT(nn.Module):
             'loss': m0.new_zeros((), dtype=out_dtype),     # losses are training-only: not computed
         }
 
-    def _matched_any(self, device) -> bool:
-        """Did the last forward on ``device`` (already synchronised by the caller) match any frame-0 keypoint?  (mdgat.py:465)"""
+    def _matched_any(self, device, token=0) -> bool:
+        """Did the forward that carried ``token`` on ``device`` (already synchronised by the caller) match any frame-0 keypoint?
+        (mdgat.py:465.)  The token is per call - read under the handle's lock right after the enqueue (``_run``) - so forwards
+        other threads or streams put on the same handle in the meantime do not change the answer; 0 = the handle's last call."""
         idx = device.index if device.index is not None else torch.cuda.current_device()
         with self._states_lock:
             st = self._states.get(idx)
         flag = C.c_uint(0)
-        _lib.check(_lib.load().mdgat_matched_any(st.handle, C.byref(flag)), 'mdgat_matched_any')
+        _lib.check(_lib.load().mdgat_matched_any(st.handle, int(token), C.byref(flag)), 'mdgat_matched_any')
         return bool(flag.value)
 
     def check(self, device=None, synchronize=True):
@@ -401,19 +445,30 @@ class MDGAT(nn.Module):
         if st is None:
             return {'sinkhorn_fallback': False}
         if synchronize:
-            # (the CURRENT stream only - where this thread's forwards were enqueued; a device-wide synchronisation would stall
-            # every other stream of the process.  The status words are per handle: a caller that runs forwards of one module on
-            # several streams synchronises those itself before asking.)
+            # Every stream this module's forwards were enqueued on (the per-stream workspaces remember them) - not just the
+            # current one: the status words are per handle, and a caller that ran _run / match_frames on stream A and asks from
+            # stream B would otherwise read (and clear) them before A's kernels have written.  Other streams of the process
+            # are left alone (no device-wide synchronisation).
             torch.cuda.current_stream(dev).synchronize()
+            with st.lock:
+                handles = list(st.workspaces)
+            for hnd in handles:
+                if hnd and hnd != torch.cuda.current_stream(dev).cuda_stream:
+                    _sync_raw_stream(hnd, dev)
         fb, rg = C.c_uint(0), C.c_uint(0)
         _lib.check(_lib.load().mdgat_async_status(st.handle, 1, C.byref(fb), C.byref(rg)), 'mdgat_matcher_amd')
-        return {'sinkhorn_fallback': bool(fb.value)}
+        out = {'sinkhorn_fallback': bool(fb.value)}
+        if getattr(self, 'exact_topk', False):
+            gu = C.c_uint(0)
+            _lib.check(_lib.load().mdgat_topk_repair_status(st.handle, 1, C.byref(gu)), 'mdgat_topk_repair_status')
+            out['topk_rows_not_redecided'] = int(gu.value)
+        return out
 
     @staticmethod
     def _f32(t, device):
         return t.to(device=device, dtype=torch.float32).contiguous()
 
-    def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True):
+    def _run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True, token_out=None):
         """One forward through the library on the current stream.  Either six arrays (keypoints / saliency / FPFH per
         frame) or ``frames=(records0, records1)`` raw [B, N, 37] loader records.  Asynchronous; returns device tensors
         ``(matches0, matches1, mscores0, mscores1, Z or None)``."""
@@ -422,6 +477,21 @@ class MDGAT(nn.Module):
             raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
                                'device; there is no CPU fallback')
         dev = probe.device
+        f64 = getattr(self, 'arithmetic', 'fp32') == 'fp64'
+        if f64 and frames is not None:
+            # the loader's record handling (load_data.py:152-165, 290-292: split, FPFH normalised in float32, cast to double)
+            # on the device; the library's fp64 entry point takes the arrays
+            r0, r1 = (f.to(device=dev, dtype=torch.float32) for f in frames)
+            if r0.shape[-1] != 37 or r1.shape[-1] != 37 or r0.dim() != 3:
+                raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
+
+            def _split(r):
+                d = r[..., 4:]
+                if normalize:
+                    d = d * (1 / d.norm(dim=-1, keepdim=True))
+                return r[..., :3], r[..., 3], d
+            (kpts0, sigma0, fpfh0), (kpts1, sigma1, fpfh1) = _split(r0), _split(r1)
+            frames = None
         if frames is not None:
             if frames[0].shape[-1] != 37 or frames[1].shape[-1] != 37 or frames[0].dim() != 3:
                 raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
@@ -430,7 +500,8 @@ class MDGAT(nn.Module):
         else:
             if fpfh0.shape[-1] != 33 or fpfh1.shape[-1] != 33 or kpts0.shape[-1] != 3 or kpts1.shape[-1] != 3:
                 raise ValueError('expected keypoints [B, N, 3] and 33-D FPFH descriptors [B, N, 33]')
-            ins = [self._f32(t, dev) for t in (kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1)]
+            in_dtype = torch.float64 if f64 else torch.float32
+            ins = [t.to(device=dev, dtype=in_dtype).contiguous() for t in (kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1)]
             B, N, M = kpts0.shape[0], kpts0.shape[1], kpts1.shape[1]
         st = self._state_for(dev)
         lib = _lib.load()
@@ -452,9 +523,13 @@ class MDGAT(nn.Module):
                     C.byref(tap_struct) if tap_struct is not None else None, ws.data_ptr(), ws.numel(), stream)
             if frames is not None:
                 rc = lib.mdgat_forward_frames(st.handle, B, N, M, ins[0].data_ptr(), ins[1].data_ptr(), int(bool(normalize)), *outs)
+            elif f64:
+                rc = lib.mdgat_forward_f64(st.handle, B, N, M, *[t.data_ptr() for t in ins], *outs)
             else:
                 rc = lib.mdgat_forward(st.handle, B, N, M, *[t.data_ptr() for t in ins], *outs)
-            _lib.check(rc, 'mdgat_forward_frames' if frames is not None else 'mdgat_forward')
+            if token_out is not None:
+                token_out[0] = int(lib.mdgat_last_token(st.handle))     # (still under st.lock: this call's token)
+            _lib.check(rc, 'mdgat_forward_frames' if frames is not None else 'mdgat_forward_f64' if f64 else 'mdgat_forward')
         return m0, m1, s0, s1, Z
 
     def profile(self, device, enable: bool):

@@ -216,3 +216,50 @@ def gt_matches(kpts0: torch.Tensor, kpts1: torch.Tensor, T0=None, T1=None, thres
                                                 t1.data_ptr() if t1 is not None else None, float(threshold), int(bool(mutual)),
                                                 g0.data_ptr(), g1.data_ptr(), rep.data_ptr(), _stream(k0)), 'mdgat_gt_matches')
     return g0, g1, rep
+
+
+# ---- fp64 kernels of the reference-exact mode (csrc/f64.hip; MDGAT(arithmetic='fp64') launches the same ones) ----
+def pointwise_f64(a: torch.Tensor, w: torch.Tensor, bias=None, relu: bool = False, residual=None) -> torch.Tensor:
+    """Conv1d(k=1) over points in fp64 (mdgat.py:34-46 after BN folding): a [M, K] x w [N, K]^T (+ bias)(ReLU)(+ residual)."""
+    _need_cuda(a, w)
+    a = a.to(torch.float64).contiguous()
+    w = w.to(torch.float64).contiguous()
+    M, K = a.shape
+    N = w.shape[0]
+    assert w.shape[1] == K
+    bias = bias.to(torch.float64).contiguous() if bias is not None else None
+    residual = residual.to(torch.float64).contiguous() if residual is not None else None
+    out = torch.empty((M, N), dtype=torch.float64, device=a.device)
+    with torch.cuda.device(a.device):
+        _lib.check(_lib.load().mdgat_pointwise_f64(M, N, K, a.data_ptr(), K, w.data_ptr(), K, bias.data_ptr() if bias is not None else None,
+                                                   int(bool(relu)), residual.data_ptr() if residual is not None else None, N,
+                                                   out.data_ptr(), N, _stream(a)), 'mdgat_pointwise_f64')
+    return out
+
+
+def attention_f64(qkv: torch.Tensor, N: int, M: int, cross: bool, topk: int = 0, return_selection: bool = False):
+    """attention / dynamic_attention (mdgat.py:190-210) in fp64.  qkv [B, N+M, 3, 4, 32] float64 -> message [B, N+M, 128] float64
+    (with ``return_selection``: also the masks of the keys a dynamic layer kept, see topk_sel_to_masks)."""
+    _need_cuda(qkv)
+    x = qkv.to(torch.float64).contiguous()
+    B, P = x.shape[0], x.shape[1]
+    assert P == N + M and tuple(x.shape[2:]) == (3, 4, 32)
+    msg = torch.empty((B, P, 128), dtype=torch.float64, device=x.device)
+    with torch.cuda.device(x.device):
+        sel = torch.empty(topk_sel_words(B, N, M), dtype=torch.int32, device=x.device) if return_selection else None
+        _lib.check(_lib.load().mdgat_attention_f64(B, N, M, int(bool(cross)), int(topk), x.data_ptr(), msg.data_ptr(),
+                                                   sel.data_ptr() if sel is not None else None, _stream(x)), 'mdgat_attention_f64')
+    if return_selection:
+        return msg, topk_sel_to_masks(sel, B, N, M, cross)
+    return msg
+
+
+def mfma_f64_probe(device, reps: int = 2000):
+    """Measurement only: (ms, flops, shader ticks) of the v_mfma_f64_16x16x4_f64 probe loop on ``device``."""
+    dev = torch.device(device)
+    ws = torch.empty(1 << 17, dtype=torch.uint8, device=dev)
+    ms, fl, tk = C.c_float(0), C.c_double(0), C.c_longlong(0)
+    with torch.cuda.device(dev):
+        _lib.check(_lib.load().mdgat_mfma_f64_probe(int(reps), ws.data_ptr(), ws.numel(), C.byref(ms), C.byref(fl), C.byref(tk),
+                                                    torch.cuda.current_stream(dev).cuda_stream), 'mdgat_mfma_f64_probe')
+    return ms.value, fl.value, tk.value

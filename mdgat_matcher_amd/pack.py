@@ -141,7 +141,9 @@ def check_supported(sd, L):
         raise ValueError(f'state dict does not hold exactly 2L={2 * L} GNN layers')
 
 
-def pack_state_dict(sd, L: int) -> np.ndarray:
+def pack_state_dict(sd, L: int, dtype=np.float32) -> np.ndarray:
+    """The packed blob.  ``dtype=np.float64`` returns the folded weights BEFORE their rounding to fp32 - what the library's
+    reference-exact mode loads next to the fp32 blob (``mdgat_load_weights_f64``; same layout)."""
     sd = strip_module_prefix(sd)
     check_supported(sd, L)
     lay = blob_layout(L)
@@ -204,7 +206,7 @@ def pack_state_dict(sd, L: int) -> np.ndarray:
         put(base + lay['mlp2_w'], w2); put(base + lay['mlp2_b'], b2)
     w, b = _plain(sd, 'final_proj'); put(lay['final_w'], w); put(lay['final_b'], b)
     blob[lay['bin_score']] = float(_np(sd['bin_score']))
-    return blob.astype(np.float32)
+    return blob.astype(dtype)
 
 
 def resolve_topk_schedule(L: int, k_list: List[Optional[int]]) -> List[int]:

@@ -100,8 +100,17 @@ def broadcast_weights(net, device, rank: int, world: int):
     else:
         blob = torch.empty(n, dtype=torch.float32, device=device)
     broadcast_blob(blob, 0)
+    blob64 = None
+    if getattr(net, 'arithmetic', 'fp32') == 'fp64':
+        # the reference-exact mode loads the folded weights before their rounding to fp32 as well (29 MB at L = 9)
+        import numpy as np
+        if rank == 0:
+            blob64 = torch.from_numpy(net.packed_weights(np.float64)).to(device)
+        else:
+            blob64 = torch.empty(n, dtype=torch.float64, device=device)
+        broadcast_blob(blob64, 0)
     if blob.is_cuda:
-        net.load_packed(blob)
+        net.load_packed(blob, blob64)
     return blob
 
 

@@ -15,7 +15,7 @@ import torch  # noqa: E402
 from mdgat_matcher_amd import MDGAT  # noqa: E402
 
 
-def _fake_run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True):
+def _fake_run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, taps=None, frames=None, normalize=True, token_out=None):
     B, N, M = kpts0.shape[0], kpts0.shape[1], kpts1.shape[1]
     rank = int(os.environ.get('RANK', '0'))
     time.sleep(0.02 if rank == 3 else 0.001)        # rank 3 is the straggler the line must show (by a margin no scheduler noise of a busy box covers)

@@ -1,0 +1,250 @@
+"""GPU parity of the reference-exact mode (MDGAT(arithmetic='fp64'), csrc/f64.hip) through the C ABI.
+
+The point of the mode is the LITERAL north-star bar: Z within 1e-4 of the reference's fp64 output on every pair, with no
+attribution of top-k flips - because no selection flips: the encoders and the layers through the last dynamic one compute in
+fp64 from fp64 inputs and weights, so ``logits.topk(k)`` (mdgat.py:202) selects what the reference selects.  The tests compare
+with the REFERENCE's own outputs (tests/golden/cfg_*.npz, made by tools/make_goldens.py from the imported reference) at the
+literal tolerance, and with the oracle (pinned to the reference by tests/test_oracle_golden.py) op by op."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from mdgat_matcher_amd import MDGAT, ops, synth  # noqa: E402
+from oracle import mdgat_oracle as O  # noqa: E402
+
+DEV = 'cuda:0'
+Z_TOL = 1e-4            # north star, literal
+F64_TOL = 1e-11         # the fp64 kernels against torch fp64 on the same operands (summation order only)
+
+
+def _g(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + '.npz'))
+
+
+@pytest.mark.parametrize('rows,cout,K,relu,res', [(100, 32, 4, True, False), (130, 64, 33, True, False), (257, 128, 64, True, False),
+                                                  (1024, 384, 128, False, False), (300, 256, 256, True, False),
+                                                  (777, 128, 256, False, True), (64, 128, 128, False, False), (1, 5, 3, False, True)])
+def test_pointwise_f64(rows, cout, K, relu, res):
+    rs = np.random.RandomState(rows + cout + K)
+    a = torch.from_numpy(rs.standard_normal((rows, K)))
+    w = torch.from_numpy(rs.standard_normal((cout, K)) / np.sqrt(K))
+    b = torch.from_numpy(rs.standard_normal(cout))
+    r = torch.from_numpy(rs.standard_normal((rows, cout))) if res else None
+    out = ops.pointwise_f64(a.to(DEV), w.to(DEV), b.to(DEV), relu, r.to(DEV) if res else None).cpu()
+    ref = a @ w.T + b
+    if relu:
+        ref = torch.relu(ref)
+    if res:
+        ref = ref + r
+    assert (out - ref).abs().max() < F64_TOL
+
+
+def _ref_msg_to_lib(msg):
+    b, dh, h, n = msg.shape
+    return msg.permute(0, 3, 2, 1).reshape(b, n, h * dh)
+
+
+def _sides(qkv, N, M, cross):
+    """(query rows, source rows) per frame, in the oracle's [B, dh, H, n] layout"""
+    fr = ((0, N), (N, N + M))
+    for side in range(2):
+        lo, hi = fr[side]
+        slo, shi = fr[1 - side] if cross else fr[side]
+        yield (lo, hi), qkv[:, lo:hi, 0].permute(0, 3, 2, 1), qkv[:, slo:shi, 1].permute(0, 3, 2, 1), qkv[:, slo:shi, 2].permute(0, 3, 2, 1)
+
+
+@pytest.mark.parametrize('N,M', [(64, 64), (40, 56), (512, 512), (257, 130), (33, 31), (2048, 1300), (16, 16), (5, 3)])
+@pytest.mark.parametrize('cross', [False, True])
+def test_attention_f64_full(N, M, cross):
+    rs = np.random.RandomState(N + 7 * M + cross)
+    B = 2 if N <= 512 else 1
+    qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
+    out = ops.attention_f64(qkv.to(DEV), N, M, cross).cpu()
+    for (lo, hi), q, k, v in _sides(qkv, N, M, cross):
+        ref, _ = O.attention(q, k, v)
+        assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < F64_TOL
+
+
+@pytest.mark.parametrize('N,M,k,cross', [(64, 64, 16, False), (64, 64, 1, False), (64, 64, 63, True), (40, 56, 8, True), (512, 512, 128, False),
+                                         (512, 512, 64, True), (256, 256, 128, False), (100, 70, 70, False), (48, 64, 16, True),
+                                         (300, 500, 64, True), (1024, 1024, 128, False), (2048, 2048, 64, False), (700, 600, 100, False),
+                                         (1500, 520, 64, True), (513, 513, 512, False), (17, 17, 16, False)])
+def test_attention_f64_topk_selects_like_fp64(N, M, k, cross):
+    """No near-tie rows excluded (tests/test_gpu_ops.py::test_attention_topk has to): the kept keys are torch.topk's on fp64
+    logits, row by row, and the message agrees to fp64 rounding."""
+    rs = np.random.RandomState(N + 13 * M + k)
+    B = 2 if N <= 512 else 1
+    qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
+    out, masks = ops.attention_f64(qkv.to(DEV), N, M, cross, topk=k, return_selection=True)
+    out = out.cpu()
+    for side, ((lo, hi), q, kk, v) in enumerate(_sides(qkv, N, M, cross)):
+        rep = []
+        ref, _ = O.dynamic_attention(q, kk, v, k, report=rep)
+        own = rep[0]['own']                                              # [B, H, n, m]
+        assert torch.equal(masks[side].cpu(), own), int((masks[side].cpu() ^ own).any(-1).sum())
+        assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < F64_TOL
+
+
+def test_attention_f64_topk_fp32_ties_are_ranked_in_fp64():
+    """Logits whose fp32 roundings coincide at the k-th place: the kernel's search runs on the roundings, the tied candidates are
+    then ranked by their fp64 values (f64.hip: the list path) - or, when more than 32 tie, by key order (exact duplicates)."""
+    rs = np.random.RandomState(5)
+    N = M = 128
+    k = 16
+    qkv = torch.from_numpy(rs.standard_normal((1, N + M, 3, 4, 32)) * 1.3)
+    # per frame and head: make the (k+1)-th key of query row r a copy of the k-th key, moved by ~1e-10 relative - below the
+    # fp32 resolution of the logit (6e-8 relative), far above fp64's
+    planted = 0
+    for lo in (0, N):
+        for h in range(4):
+            q = qkv[0, lo:lo + N, 0, h]
+            kk = qkv[0, lo:lo + N, 1, h]
+            logits = q @ kk.T / 32 ** 0.5
+            used = set()                # a key is copied / overwritten at most once: two copies of one key would tie in fp64 too
+            for r in range(0, N, 9):
+                order = logits[r].argsort(descending=True)
+                a, b = int(order[k - 1]), int(order[k])
+                if a in used or b in used:
+                    continue
+                used.update((a, b))
+                sign = 1.0 if (planted & 1) else -1.0
+                kk[b] = kk[a] * (1.0 + sign * 1e-10)
+                qkv[0, lo + b, 2, h] = torch.from_numpy(rs.standard_normal(32))          # a different value row: a wrong pick moves the message
+                logits = q @ kk.T / 32 ** 0.5
+                planted += 1
+    assert planted > 12
+    out, masks = ops.attention_f64(qkv.to(DEV), N, M, False, topk=k, return_selection=True)
+    out = out.cpu()
+    tied_rows = 0
+    for side, ((lo, hi), q, kk, v) in enumerate(_sides(qkv, N, M, False)):
+        rep = []
+        ref, _ = O.dynamic_attention(q, kk, v, k, report=rep)
+        logits = torch.einsum('bdhn,bdhm->bhnm', q, kk) / 32 ** 0.5
+        top = logits.topk(k + 1, dim=3).values
+        tied_rows += int((top[..., k - 1].float() == top[..., k].float()).sum())
+        assert torch.equal(masks[side].cpu(), rep[0]['own'])
+        assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < F64_TOL
+    assert tied_rows >= 8, tied_rows          # the construction did produce fp32 ties at the k-th place
+    # masses of EXACT duplicates (40 copies of one key straddling the k-th place): exactly k keys, lowest indices among the ties
+    qkv2 = torch.from_numpy(rs.standard_normal((1, 2 * 96, 3, 4, 32)))
+    qkv2[0, 10:50, 1] = qkv2[0, 10, 1]
+    qkv2[0, 10:50, 2] = qkv2[0, 10, 2]
+    out2, masks2 = ops.attention_f64(qkv2.to(DEV), 96, 96, False, topk=24, return_selection=True)
+    assert bool((masks2[0].sum(-1) == 24).all()) and bool((masks2[1].sum(-1) == 24).all())
+    q, kk, v = (qkv2[:, :96, i].permute(0, 3, 2, 1) for i in range(3))
+    ref, _ = O.dynamic_attention(q, kk, v, 24)
+    assert (out2.cpu()[:, :96] - _ref_msg_to_lib(ref)).abs().max() < 1e-9       # (equal logits, equal values: any choice among them)
+    m = masks2[0].cpu()[0]                                                      # [H, n, keys]
+    dup = m[:, :, 10:50]
+    first_gap = (~dup).float().argmax(-1)                                       # kept duplicates are a prefix of the group
+    assert bool(((dup.sum(-1) == first_gap) | dup.all(-1)).all())
+
+
+def _build(g, **cfg_over):
+    B, n, m, L, S, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    bin_score = float(g['bin_score']) if 'bin_score' in g else 1.0
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, **cfg_over)
+    sd = synth.make_state_dict(L=L, seed=seed, bin_score=bin_score)
+    net = MDGAT(cfg).double()
+    net.load_state_dict(sd)
+    net = net.double().eval().to(DEV)
+    data = synth.make_batch(B, n, m, first_pair=first_pair)
+    return net, cfg, sd, data, (B, n, m, L)
+
+
+@pytest.mark.parametrize('name', ['fwd_n64_L1_S1', 'fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20'])
+def test_f64_stages_vs_reference(golden_dir, name):
+    """Every stage tensor of the fp64 layers against the reference's (forward hooks, tools/make_goldens.py): fp32 taps of fp64
+    values, so 1e-6 here; Z, matches and scores at the bar."""
+    g = _g(golden_dir, name)
+    net, cfg, sd, data, (B, n, m, L) = _build(g, arithmetic='fp64', f64_layers=2 * int(g['meta'][3]))
+    P = n + m
+    dev = {k: v.to(DEV) for k, v in data.items()}
+    taps = {'x_enc': torch.empty(B, P, 128, device=DEV), 'x_layers': torch.empty(2 * L, B, P, 128, device=DEV),
+            'mdesc': torch.empty(B, P, 128, device=DEV), 'scores': torch.empty(B, n, m, device=DEV)}
+    m0, m1, s0, s1, Z = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'],
+                                 dev['descriptors1'], want_Z=True, taps=taps)
+    torch.cuda.synchronize()
+    net.check(DEV)
+    t = lambda x: np.transpose(x, (0, 2, 1))
+    enc = taps['x_enc'].cpu().double().numpy()
+    assert max(np.abs(enc[:, :n] - t(g['enc0'])).max(), np.abs(enc[:, n:] - t(g['enc1'])).max()) < 2e-6
+    xl = taps['x_layers'].cpu().double().numpy()
+    for i in range(2 * L):
+        e = max(np.abs(xl[i][:, :n] - t(g[f'layer{i}_desc0'])).max(), np.abs(xl[i][:, n:] - t(g[f'layer{i}_desc1'])).max())
+        assert e < 5e-6, (i, e)
+    assert np.abs(Z.cpu().double().numpy() - g['Z']).max() < 2e-5
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+    assert np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max() < 2e-5
+
+
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n512_L9_S100_seed7', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b'])
+def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
+    """THE bar, literally: against the reference's own fp64 outputs, every pair - matches bit-identical, |dZ| < 1e-4 on every held
+    entry, matching scores < 1e-4 - and not one top-k row selected differently from the fp64 oracle on the same trajectory."""
+    from parity_util import hip_forward_with_selection
+    g = _g(golden_dir, name)
+    net, cfg, sd, data, (B, n, m, L) = _build(g, arithmetic='fp64')
+    dev = {k: v.to(DEV) for k, v in data.items()}
+    (m0, m1, s0, s1, Z), forced = hip_forward_with_selection(net, dev)
+    net.check(DEV)
+    Zc = Z.cpu().double().numpy()
+    sub = int(g['sub']) if 'sub' in g else 8
+    mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    err = np.abs(mine - ref_Z).reshape(B, -1).max(1)
+    es = max(np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max(), np.abs(s1.cpu().double().numpy() - g['default_mscores1']).max())
+    print(f'[parity-f64] {name}: per-pair max|dZ| vs the reference {np.array2string(err, precision=2)}; mscores {es:.2e}; '
+          f'pairs within the literal 1e-4: {int((err < Z_TOL).sum())}/{B}')
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+    assert (err < Z_TOL).all(), err
+    assert es < Z_TOL
+    assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
+    # the selections are the fp64 oracle's own on the same trajectory: zero rows differ
+    if n <= 512:
+        cap = {}
+        ref = O.mdgat_forward(sd, cfg, data, cap, forced_topk=forced)
+        rows = sum(r['rows'] for reps in cap.get('topk_report', {}).values() for r in reps)
+        bad = sum(r['bad_count'] for reps in cap.get('topk_report', {}).values() for r in reps)
+        print(f'[parity-f64] {name}: top-k rows differing from the fp64 selection: {rows}; full Z max|d| {np.abs(Zc - cap["Z"].numpy()).max():.2e}')
+        assert rows == 0 and bad == 0
+        assert np.abs(Zc - cap['Z'].numpy()).max() < Z_TOL
+        assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
+    # the untapped kernels (what ships) give the same bits
+    plain = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=True)
+    assert torch.equal(plain[0], m0) and torch.equal(plain[1], m1) and torch.equal(plain[4], Z)
+
+
+def test_f64_dict_api_slices_and_errors():
+    """forward(dict) in the exact mode: a batch large enough to run in slices on two lanes equals the pairs run alone; fp32
+    entry points refuse an fp64 handle."""
+    L = 2
+    cfg = synth.default_config(L=L, k=[16, None, 8, None], sinkhorn_iterations=10, arithmetic='fp64')
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=3))
+    net = net.eval().to(DEV)
+    os.environ.pop('MDGAT_FORWARD_SLICE_POINTS', None)
+    data = synth.make_batch(6, 96, 80, device=DEV)
+    out = net(data)
+    assert out['matches0'].dtype == torch.int64 and out['matching_scores0'].dtype == torch.float64
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
+    assert torch.equal(m0, out['matches0'])
+    one = net.match(*[a[4:5] for a in args], return_scores=True)
+    assert torch.equal(one[0][0], m0[4]) and torch.equal(one[4][0], Z[4])
+    sd = synth.make_state_dict(L=L, seed=3)
+    cap = {}
+    ref = O.mdgat_forward(sd, cfg, {k: v.cpu() for k, v in data.items()}, cap)
+    assert torch.equal(m0.cpu(), ref['matches0']) and (Z.cpu().double() - cap['Z']).abs().max() < 2e-5
+    # records in: the loader's split and normalisation on the device, then the same path
+    rec0 = torch.cat([data['keypoints0'], data['scores0'][..., None], data['descriptors0']], -1).float()
+    rec1 = torch.cat([data['keypoints1'], data['scores1'][..., None], data['descriptors1']], -1).float()
+    mf = net.match_frames(rec0, rec1, normalize=False)
+    assert (mf[0] == m0).float().mean() > 0.95

@@ -29,7 +29,7 @@ def test_blob_layout_matches_library():
     lib = _lib.load()
     for L in (0, 1, 4, 9, 32):
         assert lib.mdgat_blob_floats(L) == pack.blob_layout(L)['total']
-    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 4)     # L, iters, topk[64], extract_mode, threshold, attention_mode, exact_topk
+    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 6)     # L, iters, topk[64], extract_mode, threshold, attention_mode, exact_topk, arithmetic, f64_layers
 
 
 def test_state_dict_names_match_reference_fixture():
@@ -269,6 +269,7 @@ class _FakeLib:
 
     def __init__(self):
         self.calls, self.loaded, self.status, self.matched = [], [], (0, 0), 0
+        self.token, self.matched_by_token, self.loaded64 = 0, {}, []
 
     def mdgat_create(self, cfg, idx, handle):
         self.calls.append(('create', idx))
@@ -287,9 +288,24 @@ class _FakeLib:
     def mdgat_workspace_bytes(self, handle, B, N, M):
         return 256 * B
 
+    def mdgat_load_weights_f64(self, handle, ptr, n, on_device):
+        addr = ptr.value if hasattr(ptr, 'value') else C.cast(ptr, C.c_void_p).value
+        self.loaded64.append(np.ctypeslib.as_array(C.cast(addr, C.POINTER(C.c_double)), shape=(n,)).copy())
+        self.calls.append(('load64', int(on_device)))
+        return 0
+
     def mdgat_forward(self, *a):
+        self.token += 1
         self.calls.append(('forward', a[1], a[-2], a[-1]))          # B, workspace bytes, stream
         return 0
+
+    def mdgat_forward_f64(self, *a):
+        self.token += 1
+        self.calls.append(('forward_f64', a[1], a[-2], a[-1]))
+        return 0
+
+    def mdgat_last_token(self, handle):
+        return self.token
 
     def mdgat_async_status(self, handle, clear, fb, rg):
         fb._obj.value, rg._obj.value = self.status
@@ -297,8 +313,9 @@ class _FakeLib:
             self.status = (0, 0)
         return _lib.ERR_UNSUPPORTED if rg._obj.value else 0
 
-    def mdgat_matched_any(self, handle, matched):
-        matched._obj.value = self.matched
+    def mdgat_matched_any(self, handle, token, matched):
+        self.calls.append(('matched_any', token))
+        matched._obj.value = self.matched_by_token.get(token, self.matched)
         return 0
 
     def mdgat_destroy(self, handle):
@@ -319,6 +336,9 @@ def _stubbed(fake, stream_holder):
     cm.enter_context(mock.patch.object(torch.cuda, 'device', lambda d: contextlib.nullcontext()))
     cm.enter_context(mock.patch.object(torch.cuda, 'synchronize', lambda d=None: None))
     cm.enter_context(mock.patch.object(torch.cuda, 'current_stream', lambda d=None: mock.Mock(cuda_stream=stream_holder[0])))
+    from mdgat_matcher_amd import mdgat as _m
+    synced = stream_holder[1] if len(stream_holder) > 1 else []
+    cm.enter_context(mock.patch.object(_m, '_sync_raw_stream', lambda h, d: synced.append(h)))
     return cm
 
 
@@ -339,7 +359,10 @@ def test_workspace_per_stream_and_status_check():
         st = net._states[0]
         assert set(st.workspaces) == {11, 22} and st.workspaces[11].data_ptr() != st.workspaces[22].data_ptr()
         assert [c[3] for c in fake.calls if c[0] == 'forward'] == [11, 22, 11]
-        assert net.check('cuda:0') == {'sinkhorn_fallback': False}
+        stream.append([])                                                       # (records the raw streams check() synchronises)
+        with _stubbed(fake, stream):
+            assert net.check('cuda:0') == {'sinkhorn_fallback': False}
+            assert stream[1] == [22]      # every stream the module's forwards ran on is synchronised, not only the current one (11)
         fake.status = (1, 0)
         assert net.check('cuda:0') == {'sinkhorn_fallback': True}
         fake.status = (0, 1)
@@ -492,3 +515,73 @@ def test_two_device_dataparallel_with_stubbed_library():
         gathered = torch.cat([o[0] for o in outs], dim=0)                           # DataParallel.gather of matches0
         assert gathered.shape == (4, 8)
         net._invalidate()
+
+
+def test_forward_asks_about_its_own_token():
+    """the "nothing matched" test of mdgat.py:465 must be about THIS call - forward() reads its call's token under the
+    handle lock and asks mdgat_matched_any about that token, so a forward another thread enqueues on the same handle between this
+    call's synchronisation and its question does not change the answer."""
+    import threading
+    fake, stream = _FakeLib(), [11]
+    net = MDGAT(synth.default_config(L=1, k=[])).eval()
+    d = synth.make_batch(2, 8, 8)
+    with _stubbed(fake, stream):
+        net(d)
+        assert fake.calls[-2][0] == 'matched_any' or fake.calls[-1][0] == 'matched_any'
+        asked = [c for c in fake.calls if c[0] == 'matched_any']
+        assert asked[-1][1] == 1                                    # the first forward's token
+        # an interleaved caller: a second thread's forward lands between the enqueue and the question of the first
+        real_sync = torch.cuda.current_stream
+
+        def interloper():
+            args = (d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'])
+            net._run(*args)
+        orig = MDGAT._matched_any
+
+        def racing(self, device, token=0):
+            t = threading.Thread(target=interloper)
+            t.start(); t.join()                                     # token 3 is now the handle's last token
+            return orig(self, device, token)
+        fake.matched_by_token = {2: 0, 3: 1}
+        from unittest import mock
+        with mock.patch.object(MDGAT, '_matched_any', racing):
+            out = net(d)                                            # token 2: nothing matched, whatever token 3 did
+        assert out['matching_scores0'].dtype == torch.int64
+        assert [c for c in fake.calls if c[0] == 'matched_any'][-1][1] == 2
+        net._invalidate()
+
+
+def test_fp64_arithmetic_host_logic():
+    """arithmetic='fp64': the handle is created with MDGAT_ARITH_FP64, BOTH blobs are loaded (the fp64 one is the folded weights
+    before their rounding), the inputs reach mdgat_forward_f64 as float64, and load_packed insists on the fp64 blob."""
+    fake, stream = _FakeLib(), [11]
+    cfgs = []
+    orig_create = fake.mdgat_create
+
+    def create(cfg, idx, handle):
+        cfgs.append((cfg._obj.arithmetic, cfg._obj.f64_layers))
+        return orig_create(cfg, idx, handle)
+    fake.mdgat_create = create
+    net = MDGAT(synth.default_config(L=2, arithmetic='fp64')).double()
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    net = net.eval()
+    d = synth.make_batch(2, 8, 8)
+    with _stubbed(fake, stream):
+        out = net(d)
+        assert cfgs == [(_lib.ARITH_FP64, -1)]
+        assert [c[0] for c in fake.calls if c[0].startswith('load')] == ['load', 'load64']
+        assert any(c[0] == 'forward_f64' for c in fake.calls) and not any(c[0] == 'forward' for c in fake.calls)
+        b32, b64 = fake.loaded[0], fake.loaded64[0]
+        assert b64.dtype == np.float64 and b32.shape == b64.shape
+        np.testing.assert_array_equal(b32, b64.astype(np.float32))          # the fp32 blob is the rounding of the fp64 one
+        assert np.abs(b64 - b32).max() > 0                                   # ... and the fp64 one carries more
+        assert out['matches0'].dtype == torch.int64
+        with pytest.raises(ValueError, match='blob64'):
+            net.load_packed(torch.from_numpy(b32))
+        net.load_packed(torch.from_numpy(b32), torch.from_numpy(b64))
+        assert fake.calls[-1] == ('load64', 0) and fake.calls[-2] == ('load', 1)
+        net._invalidate()
+    with pytest.raises(ValueError):
+        MDGAT(synth.default_config(L=1, arithmetic='fp16'))
+    with pytest.raises(ValueError):
+        MDGAT(synth.default_config(L=1, arithmetic='fp64', attention_dtype='f16'))

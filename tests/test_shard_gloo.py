@@ -236,6 +236,36 @@ def test_bench_eight_ranks_gloo_stub(tmp_path):
         assert calls and set(calls) == {'512 512 512'} and len(calls) == 8 + 1 + 2 * 3, (r, len(calls))
 
 
+def test_bench_plain_form_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 8 --config 3` WITHOUT a launcher must produce eight ranks (it used to run one and
+    print n_gpus 1): bench.py re-executes itself under torch.distributed.run.  And a launcher whose world differs from --gpus is
+    refused instead of mislabelled.  (Stub runner, gloo, CPU.)"""
+    import json
+    import subprocess
+    log = str(tmp_path / 'calls')
+    env = dict(os.environ, MDGAT_BENCH_STUB_LOG=log, OMP_NUM_THREADS='1')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'HSA_ENABLE_IPC_MODE_LEGACY'):
+        env.pop(k, None)
+    runner = os.path.join(ROOT, 'tests', 'bench_stub_runner.py')
+    p = subprocess.run([sys.executable, runner, '--gpus', '8', '--config', '3', '--steps', '2', '--warmup', '1', '--windows', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 8 and d['config']['rccl_world_size'] == 8 and d['config']['pairs_per_rank'] == [512] * 8
+    assert 'starting 8 ranks' in p.stderr
+    for r in range(8):
+        assert set(open(f'{log}.{r}').read().split()) == {'512'}
+    # a launcher that started 2 ranks for a --gpus 4 request: every rank refuses, nothing is printed
+    port = 29911 + (os.getpid() % 80)
+    p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',
+                        '--master-port', str(port), runner, '--gpus', '4', '--steps', '1', '--warmup', '0', '--windows', '1'],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0 and not [ln for ln in p.stdout.splitlines() if ln.startswith('{')]
+    assert 'WORLD_SIZE=2' in p.stderr
+
+
 def test_env_defaults_for_rccl_on_this_pool(monkeypatch):
     """bench.py and shard.init_distributed put HSA_ENABLE_IPC_MODE_LEGACY=0 into the environment when nobody chose (RCCL on
     this pool's hosts needs it: INTEGRATION.md) and never override a choice."""
