@@ -86,8 +86,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
         const bool more = k0 + G_KC < a.K;
         if (more) fetch(k0 + G_KC);                     // the next chunk travels while this one is multiplied
         const int rem = a.K - k0;
-        const int steps = rem >= G_KC ? G_KC / 4 : (rem + 3) >> 2;
-        for (int j = 0; j < steps; ++j) {
+        auto kstep = [&](int j) {
             double fa[2], fw[WN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = ap[i * 16 * G_LD + 4 * j];
@@ -97,7 +96,11 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int n = 0; n < WN; ++n) acc[i][n] = mfma64(fa[i], fw[n], acc[i][n]);
-        }
+        };
+        // (unrolling the eight steps of a whole chunk lets the compiler hoist every fragment read: 296 registers, one wave per
+        // SIMD, 40.8 -> 29.6 TFLOP/s at 32768 x 256 x 256 - the second wave is what hides the read latency here)
+        const int steps = rem >= G_KC ? G_KC / 4 : (rem + 3) >> 2;
+        for (int j = 0; j < steps; ++j) kstep(j);
         if (more) {
             __syncthreads();
             stash();
@@ -142,6 +145,30 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 // a value of the four lanes (q, q + 16, q + 32, q + 48) of a row combined
 __device__ __forceinline__ double quad_max(double v) { v = fmax(v, shfl_xor_f64(v, 16)); return fmax(v, shfl_xor_f64(v, 32)); }
 __device__ __forceinline__ double quad_sum(double v) { v += shfl_xor_f64(v, 16); return v + shfl_xor_f64(v, 32); }
+
+// exp(x) for x <= 0 (or -inf): the softmax numerators.  n = rint(x / ln 2), exp(x - n ln 2) by its Taylor polynomial of degree 12
+// on |r| <= 0.347 (truncation 1.7e-16 relative), scaled by v_ldexp_f64 - 19 fp64-rate instructions, a third of the library
+// routine's, which also serves arguments these kernels never have.  -inf (masked keys) and everything below -745 give 0.
+__device__ __forceinline__ double exp_neg(double x) {
+    x = fmax(x, -745.5);
+    const double n = __builtin_rint(x * 1.4426950408889634);
+    double r = __builtin_fma(n, -0.6931471805599453, x);
+    r = __builtin_fma(n, -2.3190468138462996e-17, r);
+    double p = 2.08767569878681e-09;                    // 1 / 12!
+    p = __builtin_fma(p, r, 2.505210838544172e-08);     // 1 / 11!
+    p = __builtin_fma(p, r, 2.755731922398589e-07);     // 1 / 10!
+    p = __builtin_fma(p, r, 2.7557319223985893e-06);    // 1 / 9!
+    p = __builtin_fma(p, r, 2.48015873015873e-05);      // 1 / 8!
+    p = __builtin_fma(p, r, 0.0001984126984126984);     // 1 / 7!
+    p = __builtin_fma(p, r, 0.001388888888888889);      // 1 / 6!
+    p = __builtin_fma(p, r, 0.008333333333333333);      // 1 / 5!
+    p = __builtin_fma(p, r, 0.041666666666666664);      // 1 / 4!
+    p = __builtin_fma(p, r, 0.16666666666666666);       // 1 / 3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return ldexp(p, (int)n);
+}
 
 constexpr int A_LIST = 32;        // logits tied (as fp32 roundings) at the k-th place that are ranked by their fp64 values; more: key order
 struct RowSel { unsigned thr; int mode; int aux; int pad; };
@@ -254,8 +281,11 @@ size_t attn_lds_bytes(int QT, int nk_max, bool topk) {
     return fixed + (ob > im ? ob : im);
 }
 
-template <bool TOPK, int QB, bool TAP>
+// KEEP (dynamic attention, at most 512 keys = 8 blocks per wave, QB = 1): the fp64 logits of pass A stay in registers (64 of them)
+// and pass B neither reads K nor multiplies again - a third of the matrix work of the recomputing form.
+template <bool TOPK, int QB, bool TAP, bool KEEP = false>
 __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
+    static_assert(!KEEP || (TOPK && QB == 1), "KEEP: dynamic attention, one query block");
     constexpr int QT = 16 * QB;
     extern __shared__ __attribute__((aligned(16))) double asmem[];
     const AttnLds sm = attn_lds(asmem, QT);
@@ -342,16 +372,19 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 const f64x4 S = logits(jb, kf, qb);
                 const double mb = quad_max(fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
                 const double mnew = fmax(mrun[qb], mb);
-                const double sc = exp(mrun[qb] - mnew);           // (first block: exp(-inf) = 0)
+                if (__any(mnew != mrun[qb])) {                    // (after the first blocks the running maximum rarely moves)
+                    const double sc = exp_neg(mrun[qb] - mnew);   // (first block: exp(-inf) = 0)
+                    lsum[qb] *= sc;
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) O[qb][t][r] *= sc;
+                }
                 mrun[qb] = mnew;
                 f64x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = exp(S[r] - mnew);
-                lsum[qb] = lsum[qb] * sc + ((p[0] + p[1]) + (p[2] + p[3]));
-#pragma unroll
-                for (int t = 0; t < 2; ++t)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) O[qb][t][r] *= sc;
+                for (int r = 0; r < 4; ++r) p[r] = exp_neg(S[r] - mnew);
+                lsum[qb] += (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     O[qb][0] = mfma64(vf[s][0], p[s], O[qb][0]);
@@ -361,7 +394,23 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         }
     } else {
         // ---- dynamic attention, pass A: fp32 roundings of the logits -> LDS, row maxima ----
-        {
+        f64x4 Sk[KEEP ? 8 : 1];
+        if (KEEP) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int jb = wave + 4 * i;
+                if (jb < nblk) {
+                    double kf[8];
+                    kload(jb, kf);
+                    const f64x4 S = logits(jb, kf, 0);
+                    Sk[i] = S;
+                    mrun[0] = fmax(mrun[0], fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
+                    unsigned* row = sm.img + l15 * imgld + jb * 16 + g;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) row[4 * r] = f2ord((float)S[r]);
+                }
+            }
+        } else {
             double kf[8], kn[8];
             if (wave < nblk) kload(wave, kn);
             for (int jb = wave; jb < nblk; jb += 4) {
@@ -377,6 +426,8 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                     for (int r = 0; r < 4; ++r) row[4 * r] = f2ord((float)S[r]);
                 }
             }
+        }
+        {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 mrun[qb] = quad_max(mrun[qb]);
@@ -403,44 +454,57 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             mrun[qb] = fmax(fmax(sm.mw[q], sm.mw[QT + q]), fmax(sm.mw[2 * QT + q], sm.mw[3 * QT + q]));
             tap[qb] = TAP ? a.sel + (((size_t)b * 4 + head) * P + q_off + min(q0 + q, nq - 1)) * a.selW : nullptr;
         }
-        double kf[8], kn[8];
-        f64x2 vf[4];
-        if (wave < nblk) kload(wave, kn);
-        for (int jb = wave; jb < nblk; jb += 4) {
+        // one block of pass B for query block qb: classify, masked exponentials, P.V
+        auto pass_b = [&](int jb, const f64x4& S, const f64x2 (&vf)[4], int qb) {
+            f64x4 p;
+            unsigned bits = 0;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = kn[j];
-            vload(jb, vf);
-            if (jb + 4 < nblk) kload(jb + 4, kn);
-#pragma unroll
-            for (int qb = 0; qb < QB; ++qb) {
-                const f64x4 S = logits(jb, kf, qb);
-                f64x4 p;
-                unsigned bits = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int key = jb * 16 + g + 4 * r;
-                    const unsigned o = f2ord((float)S[r]);
-                    bool keep = o > rs[qb].thr;
-                    if (o == rs[qb].thr) {
-                        if (rs[qb].mode == 0) keep = true;
-                        else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
-                        else if (key < nk) {
-                            const int q = qb * 16 + l15;
-                            const int slot = atomicAdd(&sm.lcount[q], 1);
-                            if (slot < A_LIST) { sm.lS[q * A_LIST + slot] = S[r]; sm.lkey[q * A_LIST + slot] = key; }
-                        }
+            for (int r = 0; r < 4; ++r) {
+                const int key = jb * 16 + g + 4 * r;
+                const unsigned o = f2ord((float)S[r]);
+                bool keep = o > rs[qb].thr;
+                if (o == rs[qb].thr) {
+                    if (rs[qb].mode == 0) keep = true;
+                    else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
+                    else if (key < nk) {
+                        const int q = qb * 16 + l15;
+                        const int slot = atomicAdd(&sm.lcount[q], 1);
+                        if (slot < A_LIST) { sm.lS[q * A_LIST + slot] = S[r]; sm.lkey[q * A_LIST + slot] = key; }
                     }
-                    keep = keep && key < nk;
-                    p[r] = keep ? exp(S[r] - mrun[qb]) : 0.0;
-                    bits |= (unsigned)keep << (4 * r);        // keys 16 jb + g + 4 r
                 }
-                if (TAP && bits && q0 + qb * 16 + l15 < nq) atomicOr(tap[qb] + (jb >> 1), bits << (16 * (jb & 1) + g));
-                lsum[qb] += (p[0] + p[1]) + (p[2] + p[3]);
+                keep = keep && key < nk;
+                p[r] = keep ? exp_neg(S[r] - mrun[qb]) : 0.0;
+                bits |= (unsigned)keep << (4 * r);        // keys 16 jb + g + 4 r
+            }
+            if (TAP && bits && q0 + qb * 16 + l15 < nq) atomicOr(tap[qb] + (jb >> 1), bits << (16 * (jb & 1) + g));
+            lsum[qb] += (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    O[qb][0] = mfma64(vf[s][0], p[s], O[qb][0]);
-                    O[qb][1] = mfma64(vf[s][1], p[s], O[qb][1]);
+            for (int s = 0; s < 4; ++s) {
+                O[qb][0] = mfma64(vf[s][0], p[s], O[qb][0]);
+                O[qb][1] = mfma64(vf[s][1], p[s], O[qb][1]);
+            }
+        };
+        if (KEEP) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int jb = wave + 4 * i;
+                if (jb < nblk) {
+                    f64x2 vf[4];
+                    vload(jb, vf);
+                    pass_b(jb, Sk[i], vf, 0);
                 }
+            }
+        } else {
+            double kf[8], kn[8];
+            f64x2 vf[4];
+            if (wave < nblk) kload(wave, kn);
+            for (int jb = wave; jb < nblk; jb += 4) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) kf[j] = kn[j];
+                vload(jb, vf);
+                if (jb + 4 < nblk) kload(jb + 4, kn);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) pass_b(jb, logits(jb, kf, qb), vf, qb);
             }
         }
     }
@@ -491,7 +555,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const double mwv = sm.mw[w * QT + q];
-            const double f = TOPK ? 1.0 : (mwv == -__builtin_inf() ? 0.0 : exp(mwv - m));
+            const double f = TOPK ? 1.0 : (mwv == -__builtin_inf() ? 0.0 : exp_neg(mwv - m));
             l += f * sm.lw[w * QT + q];
             o0 += f * sm.obuf[((size_t)w * QT + q) * 32 + d];
             o1 += f * sm.obuf[((size_t)w * QT + q) * 32 + d + 1];
@@ -501,7 +565,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             for (int j = 0; j < n; ++j) {
                 const int kj = sm.lkey[q * A_LIST + j];
                 if (kj >= 0) continue;
-                const double p = exp(sm.lS[q * A_LIST + j] - m);
+                const double p = exp_neg(sm.lS[q * A_LIST + j] - m);
                 const f64x2 v = *reinterpret_cast<const f64x2*>(vbase + (size_t)(kj & 0x7fffffff) * 384 + d);
                 l += p; o0 += p * v[0]; o1 += p * v[1];
             }
@@ -631,10 +695,10 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         hipLaunchKernelGGL(kern, dim3(8 * a.tiles * ugroups), dim3(256), lds, s, a);
         return mdgat_check_hip(hipGetLastError(), "attention_f64 launch");
     };
-    // 32 queries per workgroup halve the key traffic per query; 16 where the rounding images of 32 rows would keep a second
-    // workgroup off the CU (66 KB at 512 keys)
+    // full attention: 32 queries per workgroup (half the key traffic per query).  Dynamic attention: 16 - at most 512 keys the
+    // fp64 logits stay in registers between the passes (KEEP), beyond that the rounding images of 32 rows would not fit the LDS
     if (!dyn) return go(attention_f64_kernel<false, 2, false>, 32, false);
-    if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 2, true>, 32, true) : go(attention_f64_kernel<true, 2, false>, 32, true);
+    if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 1, true, true>, 16, true) : go(attention_f64_kernel<true, 1, false, true>, 16, true);
     return a.sel ? go(attention_f64_kernel<true, 1, true>, 16, true) : go(attention_f64_kernel<true, 1, false>, 16, true);
 }
 

@@ -218,3 +218,17 @@ def test_loader_vs_reference(golden_dir, mutual):
         np.testing.assert_array_equal(m0, g[tag + 'gt_matches0'].astype(np.int64))         # load_data.py:257-285
         np.testing.assert_array_equal(m1, g[tag + 'gt_matches1'].astype(np.int64))
         assert rep == int(g[tag + 'rep']) and rep > 10
+
+
+def test_committed_fixtures_are_what_the_generator_writes():
+    """Fixture guard: tools/make_goldens.py --check regenerates the small fixtures from the imported reference
+    into a scratch directory and compares keys and values with the committed files.  Only where /root/reference exists (the
+    build container); the GPU box has no reference."""
+    import subprocess
+    import sys
+    if not os.path.exists(os.path.join(os.environ.get('MDGAT_REFERENCE', '/root/reference'), 'models', 'mdgat.py')):
+        pytest.skip('the reference is not present on this box')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'make_goldens.py'), '--check'], capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-2000:]
+    assert 'OK' in p.stdout.splitlines()[-1]

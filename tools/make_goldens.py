@@ -278,8 +278,42 @@ def gen_edges(M):
     print('wrote edge_cases', 'int-quirk:', arrays['alldust_mscores_is_int'])
 
 
+CHECK_DEFAULT = ('fwd_n64_L1_S1', 'fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20', 'op_vectors', 'edge_cases', 'cfg_n256_L4_S20')
+
+
+def compare_dirs(fresh, committed, names):
+    """Fixture guard: the files this script writes today against the committed ones - same keys, integers identical, floats to
+    1e-12 (the reference's fp64 sums may reassociate with the thread count).  Returns the list of disagreements."""
+    bad = []
+    for nm in names:
+        a, b = np.load(os.path.join(fresh, nm + '.npz')), np.load(os.path.join(committed, nm + '.npz'))
+        if set(a.files) != set(b.files):
+            bad.append(f'{nm}: keys differ: only regenerated {sorted(set(a.files) - set(b.files))}, only committed {sorted(set(b.files) - set(a.files))}')
+        for key in sorted(set(a.files) & set(b.files)):
+            x, y = a[key], b[key]
+            if x.shape != y.shape or x.dtype != y.dtype:
+                bad.append(f'{nm}[{key}]: {x.dtype}{x.shape} regenerated vs {y.dtype}{y.shape} committed')
+            elif np.issubdtype(x.dtype, np.floating):
+                fin = np.isfinite(x) & np.isfinite(y)
+                if not np.array_equal(np.isfinite(x), np.isfinite(y)) or (fin.any() and np.abs(x[fin] - y[fin]).max() > 1e-12 * max(1.0, np.abs(y[fin]).max())):
+                    bad.append(f'{nm}[{key}]: values differ by {np.abs(x[fin] - y[fin]).max():.3e}')
+            elif not np.array_equal(x, y):
+                bad.append(f'{nm}[{key}]: integer values differ')
+    return bad
+
+
 def main():
-    """python tools/make_goldens.py [fixture name ...]  (no names: all of them)"""
+    """python tools/make_goldens.py [--check] [fixture name ...]  (no names: all of them; --check: regenerate into a scratch
+    directory and compare with the committed files instead of overwriting them - default set: the small fixtures)"""
+    global OUT
+    check = '--check' in sys.argv[1:]
+    sys.argv = [a for a in sys.argv if a != '--check']
+    committed = OUT
+    if check:
+        import tempfile
+        OUT = tempfile.mkdtemp(prefix='mdgat_goldens_')
+        if len(sys.argv) == 1:
+            sys.argv += list(CHECK_DEFAULT)
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(os.cpu_count())
     M = import_reference()
@@ -306,9 +340,19 @@ def main():
     ]
     unknown = only - {nm for nm, _ in jobs}
     assert not unknown, f'unknown fixtures {sorted(unknown)}'
+    done = []
     for nm, fn in jobs:
         if not only or nm in only:
             fn(nm)
+            done.append(nm)
+    if check:
+        bad = compare_dirs(OUT, committed, done)
+        import shutil
+        shutil.rmtree(OUT, ignore_errors=True)
+        for line in bad:
+            print('MISMATCH', line)
+        print(f'checked {len(done)} fixtures against {committed}: ' + ('OK' if not bad else f'{len(bad)} disagreements'))
+        sys.exit(1 if bad else 0)
 
 
 if __name__ == '__main__':
