@@ -71,7 +71,7 @@ struct mdgat_handle {
     // Two lanes (forward_batched): the second lane's stream and the events that fork it off the caller's stream and join it again
     int lanes;            // 1 or 2 (mdgat_set_lanes; default 2, MDGAT_FORWARD_LANES)
     hipStream_t lane_stream;
-    hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_fork, ev_join, ev_mid;     // ev_mid: staggered lanes (forward_batched)
     // optional per-kernel-class timing of mdgat_forward (mdgat_profile): HIP events on the launch stream of each lane
     bool prof_on;
     struct ProfLane { std::vector<hipEvent_t> ev; std::vector<int> cls; size_t n = 0; } prof[2];
@@ -130,7 +130,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->match_token = 0;
     h->prof_on = false;
     h->lane_stream = nullptr;
-    h->ev_fork = h->ev_join = nullptr;
+    h->ev_fork = h->ev_join = h->ev_mid = nullptr;
     {
         const char* e = getenv("MDGAT_FORWARD_LANES");
         h->lanes = (e && atoi(e) == 1) ? 1 : 2;
@@ -148,6 +148,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (!rc) rc = mdgat_check_hip(hipStreamCreateWithFlags(&h->lane_stream, hipStreamNonBlocking), "hipStreamCreate(lane)");
     if (!rc) rc = mdgat_check_hip(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming), "hipEventCreate");
     if (!rc) rc = mdgat_check_hip(hipEventCreateWithFlags(&h->ev_join, hipEventDisableTiming), "hipEventCreate");
+    if (!rc) rc = mdgat_check_hip(hipEventCreateWithFlags(&h->ev_mid, hipEventDisableTiming), "hipEventCreate");
     (void)hipSetDevice(prev);
     if (rc) {
         mdgat_destroy(h);
@@ -260,6 +261,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (h->lane_stream) { (void)hipStreamSynchronize(h->lane_stream); (void)hipStreamDestroy(h->lane_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_join) (void)hipEventDestroy(h->ev_join);
+    if (h->ev_mid) (void)hipEventDestroy(h->ev_mid);
     for (auto& pl : h->prof)
         for (hipEvent_t e : pl.ev) (void)hipEventDestroy(e);
     delete h;
@@ -345,7 +347,8 @@ static int f64_layer_count(const mdgat_config& cfg) {
 
 static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
                         int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z,
-                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0, int lane = 0) {
+                        const mdgat_taps* taps, void* workspace, size_t workspace_bytes, void* stream, int defer_alldust = 0, int lane = 0,
+                        int mid_layer = -1) {
     const float *kpts0 = in.kpts0, *sigma0 = in.sigma0, *fpfh0 = in.fpfh0, *kpts1 = in.kpts1, *sigma1 = in.sigma1, *fpfh1 = in.fpfh1;
     const float *rec0 = in.rec0, *rec1 = in.rec1;
     const int normalize_fpfh = in.normalize_fpfh;
@@ -521,6 +524,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         else { p.mode3 = 2; p.w3s = wfinal; p.w3f = ffinal; p.b3 = w + bl.final_b; }
         if ((rc = launch_layer(p, s))) return rc;
         mark(i + 1 < L2 ? MDGAT_PROF_LAYER : MDGAT_PROF_LAYER_LAST);
+        if (i == mid_layer) (void)hipEventRecord(h->ev_mid, s);      // staggered lanes: the other lane starts here
         if (taps && taps->x_layers)
             if ((rc = mdgat_check_hip(hipMemcpyAsync(taps->x_layers + (size_t)i * R * 128, ws.x, (size_t)R * 128 * sizeof(float), hipMemcpyDeviceToDevice, s), "tap x_layers"))) return rc;
     }
@@ -652,15 +656,22 @@ static int forward_batched(mdgat_handle* h, int B, int N, int M, const FwdIn& in
         if ((rc = mdgat_check_hip(hipEventRecord(h->ev_fork, s0), "fork record"))) return rc;
         if ((rc = mdgat_check_hip(hipStreamWaitEvent(h->lane_stream, h->ev_fork, 0), "fork wait"))) return rc;
     }
+    // Experiment (MDGAT_LANE_STAGGER = layer index, unset / negative: off): with four or more slices the second
+    // lane starts when the first lane's first slice has passed that layer, so that the Sinkhorn launch of one lane runs next to
+    // layer / attention launches of the other instead of next to the other lane's Sinkhorn.
+    static const int stagger = [] { const char* e = getenv("MDGAT_LANE_STAGGER"); return e ? atoi(e) : -1; }();
+    const int mid_layer = (p.lanes == 2 && p.nslices >= 4 && stagger >= 0 && stagger < 2 * h->cfg.L) ? stagger : -1;
     int slice = 0;
     for (int c = 0; c < B && !rc; c += p.per, ++slice) {
         const int b = B - c < p.per ? B - c : p.per;
         const size_t c_ = (size_t)c;
         const int lane = p.lanes == 2 ? (slice & 1) : 0;
+        if (slice == 1 && mid_layer >= 0)
+            if ((rc = mdgat_check_hip(hipStreamWaitEvent(h->lane_stream, h->ev_mid, 0), "stagger wait"))) break;
         rc = forward_impl(h, b, N, M, in.from(c_, N, M),
                           matches0 + c_ * N, matches1 + c_ * M, mscores0 + c_ * N, mscores1 + c_ * M,
                           Z ? Z + c_ * (N + 1) * (M + 1) : nullptr, nullptr, static_cast<char*>(workspace) + (size_t)lane * p.lane_bytes,
-                          p.lane_bytes, lane ? static_cast<void*>(h->lane_stream) : stream, 1, lane);
+                          p.lane_bytes, lane ? static_cast<void*>(h->lane_stream) : stream, 1, lane, slice == 0 ? mid_layer : -1);
     }
     if (p.lanes == 2) {
         // (joined even after a failed launch: the caller's stream must not run ahead of what the second lane was given)

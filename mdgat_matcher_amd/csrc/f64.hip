@@ -21,12 +21,13 @@
 //                         workgroup, the KEYS split over the four waves: S^T = K Q^T puts a query's logits into the four lanes
 //                         (q, q + 16, q + 32, q + 48), the D fragment of a 16-key block is the B operand of the P.V product as
 //                         it stands.  Full attention: online softmax per wave, the waves combined at the end.  Dynamic attention:
-//                         pass A writes the fp32 roundings of the logits (as monotone integers) to LDS, one wave per row finds the
+//                         pass A writes the fp32 roundings of the logits to LDS, one wave per row finds the
 //                         exact k-th largest of them, pass B recomputes the fp64 logits and keeps what lies above; logits whose
 //                         fp32 roundings TIE at the k-th place are ranked by their fp64 values (a short list per row, resolved
 //                         after the pass).  Rounding is monotone, so the selection is the fp64 top-k exactly.
 #include "common.hpp"
 #include "f64.hpp"
+#include "row_search.hpp"
 
 typedef double f64x4 __attribute__((ext_vector_type(4)));
 typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -86,7 +87,12 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
         const bool more = k0 + G_KC < a.K;
         if (more) fetch(k0 + G_KC);                     // the next chunk travels while this one is multiplied
         const int rem = a.K - k0;
-        auto kstep = [&](int j) {
+        const int steps = rem >= G_KC ? G_KC / 4 : (rem + 3) >> 2;
+        // (Measured and dropped, profiles/NOTES_r5.md section 1: the eight steps of a whole chunk unrolled - the compiler hoists every
+        // fragment read: 296 registers, one wave per SIMD, 40.8 -> 29.6 TFLOP/s at 32768 x 256 x 256; the reads of step j + 1 issued
+        // before the products of step j by rotating two register sets: 39.8 -> 37.8.  The second wave of the SIMD already covers
+        // the read latency; what the matrix pipe waits for is elsewhere.)
+        for (int j = 0; j < steps; ++j) {
             double fa[2], fw[WN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) fa[i] = ap[i * 16 * G_LD + 4 * j];
@@ -96,11 +102,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int n = 0; n < WN; ++n) acc[i][n] = mfma64(fa[i], fw[n], acc[i][n]);
-        };
-        // (unrolling the eight steps of a whole chunk lets the compiler hoist every fragment read: 296 registers, one wave per
-        // SIMD, 40.8 -> 29.6 TFLOP/s at 32768 x 256 x 256 - the second wave is what hides the read latency here)
-        const int steps = rem >= G_KC ? G_KC / 4 : (rem + 3) >> 2;
-        for (int j = 0; j < steps; ++j) kstep(j);
+        }
         if (more) {
             __syncthreads();
             stash();
@@ -128,15 +130,6 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
 }
 
 // ================================================================================================ attention
-// monotone image of a float in the unsigned integers (larger float <-> larger integer; -inf below every finite value)
-__device__ __forceinline__ unsigned f2ord(float f) {
-    const unsigned b = __builtin_bit_cast(unsigned, f);
-    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-    const unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
-    return __builtin_bit_cast(float, b);
-}
 __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
     const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
@@ -171,83 +164,18 @@ __device__ __forceinline__ double exp_neg(double x) {
 }
 
 constexpr int A_LIST = 32;        // logits tied (as fp32 roundings) at the k-th place that are ranked by their fp64 values; more: key order
-struct RowSel { unsigned thr; int mode; int aux; int pad; };
-// mode 0: keep ord >= thr.  mode 1: keep ord > thr, and of the tied (ord == thr) those with key <= aux.  mode 2: keep ord > thr; the
-// tied ones go to the row's list and the `aux` largest of them (fp64 value, then lower key) are added after the pass.
+struct RowSel { float thr; int mode; int aux; int pad; };
+// (on the fp32 roundings of the logits: the roundings equal to thr are TIED at the k-th place)
+// mode 0: keep every rounding >= thr.  mode 1: keep those above thr, and of the tied those with key <= aux.  mode 2: keep those above
+// thr; the tied ones go to the row's list and the `aux` largest of them (fp64 value, then lower key) are added after the pass.
 
-// Exact k-th largest of the nk integers row[0 .. nk) (LDS), one wave per row (the row in registers: NV values per lane), every
-// lane returns the same answer.  Invariant: count(>= L) = cL >= k > cH = count(>= H), L < H.  Probes: the normal quantile of the
-// row first, then Newton steps on the count with the normal density at the probe, then interpolation on the counts and bisection
-// of the integer bracket in turns - the bisection alone closes any bracket in 32 probes, so any distribution terminates.
+// the row search of row_search.hpp in the terms of this kernel's pass B
 template <int NV>
-__device__ RowSel topk_row_search(const unsigned* row, int nk, int k, float zq, int lane) {
-    if (k >= nk) return RowSel{0u, 0, 0, 0};
-    unsigned v[NV];                      // pads: 0, below the image of every float (-inf is 0x007fffff)
-#pragma unroll
-    for (int i = 0; i < NV; ++i) { const int idx = lane + 64 * i; v[i] = idx < nk ? row[idx] : 0u; }
-    float s = 0.f, ss = 0.f;
-    unsigned mn = ~0u, mx = 0u;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const bool ok = lane + 64 * i < nk;
-        const float f = ok ? ord2f(v[i]) : 0.f;
-        s += f; ss = fmaf(f, f, ss);
-        mn = min(mn, ok ? v[i] : ~0u); mx = max(mx, v[i]);
-    }
-#pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-        s += __shfl_xor(s, m, 64); ss += __shfl_xor(ss, m, 64);
-        mn = min(mn, (unsigned)__shfl_xor((int)mn, m, 64)); mx = max(mx, (unsigned)__shfl_xor((int)mx, m, 64));
-    }
-    const float inv_n = 1.0f / (float)nk;
-    const float mu = s * inv_n;
-    const float sd = sqrtf(fmaxf(ss * inv_n - mu * mu, 1e-12f));
-    const float inv_sd = 1.0f / sd;
-    auto count_ge = [&](unsigned T) {        // T > L >= 0x007fffff: the pads never count
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) c += __popcll(__ballot(v[i] >= T));
-        return c;
-    };
-    unsigned L = mn, H = mx == ~0u ? mx : mx + 1u;
-    int cL = nk, cH = 0;
-    float t = mu + zq * sd;
-    for (int p = 0; p < 200; ++p) {
-        if (cL == k || H - L <= 1u) break;
-        unsigned T;
-        if (p < 4) T = f2ord(t);                                    // quantile, then Newton steps (below)
-        else if (p & 1) {
-            const float fl = ord2f(L), fh = ord2f(H - 1u);
-            T = f2ord(fl + (fh - fl) * (((float)(cL - k) + 0.5f) / (float)(cL - cH)));
-        } else T = L + ((H - L) >> 1);
-        if (!(T > L && T < H)) {                                    // a step that left the bracket: interpolate, else bisect
-            const float fl = ord2f(L), fh = ord2f(H - 1u);
-            T = f2ord(fl + (fh - fl) * (((float)(cL - k) + 0.5f) / (float)(cL - cH)));
-            if (!(T > L && T < H)) T = L + ((H - L) >> 1);
-        }
-        const int c = count_ge(T);
-        if (c >= k) { L = T; cL = c; } else { H = T; cH = c; }
-        const float tp = ord2f(T);
-        const float z = (tp - mu) * inv_sd;
-        const float dens = (float)nk * 0.3989422804f * inv_sd * __expf(-0.5f * z * z);
-        t = tp + ((float)(c - k) + 0.5f) / fmaxf(dens, 1e-3f * (float)nk * inv_sd);
-    }
-    if (cL == k) return RowSel{L, 0, 0, 0};
-    // H == L + 1: L is the k-th largest value and cL - cH >= 2 logits share it
-    const int need = k - cH, ntied = cL - cH;
-    if (ntied <= A_LIST) return RowSel{L, 2, need, 0};
-    int seen = 0, keylim = nk;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        unsigned long long mask = __ballot(v[i] == L);
-        const int c = __popcll(mask);
-        if (keylim == nk && seen + c >= need) {
-            for (int n = need - seen; n > 1; --n) mask &= mask - 1;
-            keylim = 64 * i + __builtin_ctzll(mask);
-        }
-        seen += c;
-    }
-    return RowSel{L, 1, keylim, 0};
+__device__ RowSel f64_row_select(const float* row, int nk, int k, int lane, int* hist) {
+    const RowSearch r = topk_row_search<NV>(row, nk, k, lane, A_LIST, hist);
+    if (k >= nk || r.c_ge == k) return RowSel{r.thr, 0, 0, 0};
+    if (r.c_ge - r.c_gt <= A_LIST) return RowSel{r.thr, 2, k - r.c_gt, 0};
+    return RowSel{r.thr, 1, r.keylim, 0};
 }
 
 // LDS carve of the attention kernel.  The rounding images (dynamic layers) are dead once the rows have been searched - pass B
@@ -260,7 +188,8 @@ struct AttnLds {
     int* lkey;           // [QT][A_LIST]   their keys (bit 31: kept, set by the resolution)
     int* lcount;         // [QT]
     RowSel* sel;         // [QT]
-    unsigned* img;       // [QT][imgld]  (aliases obuf)
+    int* hist;           // [4 waves][RS_HIST_INTS] radix-select histograms (row_search.hpp)
+    float* img;          // [QT][imgld]  (aliases obuf)
 };
 __device__ __forceinline__ AttnLds attn_lds(double* base, int QT) {
     AttnLds s;
@@ -270,12 +199,13 @@ __device__ __forceinline__ AttnLds attn_lds(double* base, int QT) {
     s.lkey = reinterpret_cast<int*>(base);
     s.lcount = s.lkey + QT * A_LIST;
     s.sel = reinterpret_cast<RowSel*>(s.lcount + QT);
-    s.obuf = reinterpret_cast<double*>(s.sel + QT);
-    s.img = reinterpret_cast<unsigned*>(s.obuf);
+    s.hist = reinterpret_cast<int*>(s.sel + QT);
+    s.obuf = reinterpret_cast<double*>(s.hist + 4 * RS_HIST_INTS);
+    s.img = reinterpret_cast<float*>(s.obuf);
     return s;
 }
 size_t attn_lds_bytes(int QT, int nk_max, bool topk) {
-    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel);
+    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel) + 4 * RS_HIST_INTS * 4;
     const size_t ob = (size_t)4 * QT * 32 * 8;
     const size_t im = topk ? (size_t)QT * (((nk_max + 63) & ~63) + 4) * 4 : 0;
     return fixed + (ob > im ? ob : im);
@@ -405,9 +335,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                     const f64x4 S = logits(jb, kf, 0);
                     Sk[i] = S;
                     mrun[0] = fmax(mrun[0], fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
-                    unsigned* row = sm.img + l15 * imgld + jb * 16 + g;
+                    float* row = sm.img + l15 * imgld + jb * 16 + g;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) row[4 * r] = f2ord((float)S[r]);
+                    for (int r = 0; r < 4; ++r) row[4 * r] = (float)S[r];
                 }
             }
         } else {
@@ -421,9 +351,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 for (int qb = 0; qb < QB; ++qb) {
                     const f64x4 S = logits(jb, kf, qb);
                     mrun[qb] = fmax(mrun[qb], fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
-                    unsigned* row = sm.img + (qb * 16 + l15) * imgld + jb * 16 + g;
+                    float* row = sm.img + (qb * 16 + l15) * imgld + jb * 16 + g;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) row[4 * r] = f2ord((float)S[r]);
+                    for (int r = 0; r < 4; ++r) row[4 * r] = (float)S[r];
                 }
             }
         }
@@ -438,9 +368,10 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         __syncthreads();
         // ---- the exact k-th largest rounding of every row: one wave per row ----
         for (int q = wave; q < QT; q += 4) {
-            const unsigned* row = sm.img + q * imgld;
-            const RowSel rs = nk <= 512 ? topk_row_search<8>(row, nk, a.topk, a.zq, lane)
-                            : nk <= 1024 ? topk_row_search<16>(row, nk, a.topk, a.zq, lane) : topk_row_search<32>(row, nk, a.topk, a.zq, lane);
+            const float* row = sm.img + q * imgld;
+            int* hist = sm.hist + wave * RS_HIST_INTS;
+            const RowSel rs = nk <= 512 ? f64_row_select<8>(row, nk, a.topk, lane, hist)
+                            : nk <= 1024 ? f64_row_select<16>(row, nk, a.topk, lane, hist) : f64_row_select<32>(row, nk, a.topk, lane, hist);
             if (lane == 0) sm.sel[q] = rs;
         }
         __syncthreads();
@@ -461,9 +392,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = jb * 16 + g + 4 * r;
-                const unsigned o = f2ord((float)S[r]);
-                bool keep = o > rs[qb].thr;
-                if (o == rs[qb].thr) {
+                const float sf = (float)S[r];
+                bool keep = sf > rs[qb].thr;
+                if (sf == rs[qb].thr) {
                     if (rs[qb].mode == 0) keep = true;
                     else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
                     else if (key < nk) {

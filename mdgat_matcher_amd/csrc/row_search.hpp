@@ -1,0 +1,145 @@
+// Exact k-th largest of one attention row, one wave per row (f64.hip: the reference-exact mode).  dynamic_attention
+// (mdgat.py:196-210) keeps the k largest logits of a row; the fp64 attention kernel parks the fp32 roundings of a tile's logits in LDS
+// and lets ONE wave select on each row from registers - no exchange between waves - instead of searching 16 or 32 rows in lockstep
+// across the lanes and waves that hold them in matrix-fragment layout (attention.hip's fp32-class kernels do that; three variants of
+// this scheme for their 2048-key kernel were measured and lost: profiles/NOTES_r5.md section 3).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "common.hpp"
+
+// monotone image of a float in the unsigned integers (larger float <-> larger integer; -inf below every finite value)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    const unsigned b = __builtin_bit_cast(unsigned, f);
+    return (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    const unsigned b = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __builtin_bit_cast(float, b);
+}
+
+// wave-wide reductions / scans on the vector ALU (DPP row shifts + row broadcasts).  After the six steps lane l holds the inclusive
+// prefix over lanes 0..l, lane 63 the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int rs_dpp(int identity, int v) { return __builtin_amdgcn_update_dpp(identity, v, CTRL, ROW_MASK, 0xf, false); }
+template <typename Op>
+__device__ __forceinline__ int rs_wave_scan(int v, int identity, Op op) {
+    v = op(v, rs_dpp<0x111, 0xf>(identity, v));   // row_shr:1
+    v = op(v, rs_dpp<0x112, 0xf>(identity, v));   // row_shr:2
+    v = op(v, rs_dpp<0x114, 0xf>(identity, v));   // row_shr:4
+    v = op(v, rs_dpp<0x118, 0xf>(identity, v));   // row_shr:8
+    v = op(v, rs_dpp<0x142, 0xa>(identity, v));   // row_bcast:15 -> rows 1, 3
+    v = op(v, rs_dpp<0x143, 0xc>(identity, v));   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+__device__ __forceinline__ unsigned rs_wave_max_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_readlane(rs_wave_scan((int)v, 0, [](int a, int b) { return (int)max((unsigned)a, (unsigned)b); }), 63);
+}
+__device__ __forceinline__ unsigned rs_wave_min_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_readlane(rs_wave_scan((int)v, -1, [](int a, int b) { return (int)min((unsigned)a, (unsigned)b); }), 63);
+}
+__device__ __forceinline__ int rs_wave_sum_i(int v) { return __builtin_amdgcn_readlane(rs_wave_scan(v, 0, [](int a, int b) { return a + b; }), 63); }
+
+struct RowSearch {
+    float thr;         // the k-th largest value of the row (-inf: every key is kept).  count(>= thr) = c_ge >= k > c_gt = count(> thr)
+    int c_ge, c_gt;
+    float mx;          // largest value of the row
+    int keylim;        // c_ge > k and more than list_cap values equal thr: of those the ones with key <= keylim are the first k - c_gt in key
+                       // order (torch.topk keeps exactly k; which of several equal logits is unspecified there - here the lowest keys)
+};
+
+// row: nk floats in LDS, nk <= 64 NV (-0.0 counts as +0.0); hist: RS_HIST_INTS ints of LDS owned by this wave.  Every lane returns the same answer.
+// RADIX SELECT on the monotone integer images of the floats, eight bits a level: a 256-bin histogram of the values still in play
+// (LDS atomics), a DPP suffix scan that finds the bin holding the k-th largest, and down into that bin - until it holds one value or
+// the digits run out (equal values: the tie).  Three levels on logits of order one, ~170 instructions each, and the SAME work for
+// every row: the bracketing searches this replaces (probe a threshold, count, Newton / interpolation / bisection) average 5 probes
+// but have a tail of 20-30, and a tile waits at a barrier for its slowest row (measured at 2048 keys: 36 000 cycles of search and
+// 40 000 of waiting per tile; profiles/NOTES_r5.md section 3).
+// near (optional): receives whether more than k values lie at or above thr - mdgat_near_eps (repair.hip's near-threshold rows).
+typedef __attribute__((address_space(3))) int rs_lds_int;
+typedef __attribute__((address_space(3))) const float rs_lds_cfloat;
+constexpr int RS_HIST_INTS = 320;       // 256 bins + one waste bin per lane
+template <int NV>
+__device__ RowSearch topk_row_search(const float* row_, int nk, int k, int lane, int list_cap, int* hist_, bool* near = nullptr) {
+    // (both pointers are LDS: said here, or the function addresses them as flat memory)
+    rs_lds_cfloat* row = (rs_lds_cfloat*)row_;
+    rs_lds_int* hist = (rs_lds_int*)hist_;
+    // (the arguments are the same in every lane; as a function's parameters they arrive in vector registers)
+    nk = __builtin_amdgcn_readfirstlane(nk);
+    k = __builtin_amdgcn_readfirstlane(k);
+    list_cap = __builtin_amdgcn_readfirstlane(list_cap);
+    unsigned o[NV];                      // pads: 0, below the image of every float (-inf is 0x007fffff)
+    unsigned omn = ~0u, omx = 0u;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = lane + 64 * i;
+        o[i] = idx < nk ? f2ord(row[idx] + 0.f) : 0u;
+        omn = min(omn, idx < nk ? o[i] : ~0u); omx = max(omx, o[i]);
+    }
+    omn = rs_wave_min_u(omn); omx = rs_wave_max_u(omx);
+    RowSearch out{-__builtin_inff(), nk, 0, ord2f(omx), 1 << 30};
+    if (k >= nk) return out;             // keep everything
+    unsigned base = omn;
+    int sh = 24 - __builtin_clz((omx - omn) | 0xffu);        // ((omx - omn) >> sh) < 256
+    int above = 0, ceq = 0;
+    unsigned width = 256u;               // digits in play at this level: the last step of a bin narrower than 256 values has fewer
+    for (;;) {
+        hist[4 * lane] = 0; hist[4 * lane + 1] = 0; hist[4 * lane + 2] = 0; hist[4 * lane + 3] = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            // (values out of play - below base, the pads among them, or beyond the 256 digits - go to this lane's waste bin: an
+            // unconditional atomic instead of a branch per value, and no two lanes on one waste address)
+            const unsigned d = (o[i] - base) >> sh;
+            __atomic_fetch_add(hist + ((o[i] >= base && d < width) ? (int)d : 256 + lane), 1, __ATOMIC_RELAXED);
+        }
+        int4 h;
+        h.x = hist[4 * lane]; h.y = hist[4 * lane + 1]; h.z = hist[4 * lane + 2]; h.w = hist[4 * lane + 3];
+        const int pre = rs_wave_scan(h.x + h.y + h.z + h.w, 0, [](int a, int b) { return a + b; });
+        const int tot = __builtin_amdgcn_readlane(pre, 63);
+        // values in play above this lane's four bins, then bin by bin from the top
+        const int a3 = above + tot - pre, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;
+        int bin = -1, ab = 0, cnt = 0;
+        if (a0 < k && k <= a0 + h.x) { bin = 4 * lane; ab = a0; cnt = h.x; }
+        if (a1 < k && k <= a1 + h.y) { bin = 4 * lane + 1; ab = a1; cnt = h.y; }
+        if (a2 < k && k <= a2 + h.z) { bin = 4 * lane + 2; ab = a2; cnt = h.z; }
+        if (a3 < k && k <= a3 + h.w) { bin = 4 * lane + 3; ab = a3; cnt = h.w; }
+        const int src = __builtin_ctzll(__ballot(bin >= 0));          // exactly one lane holds the bin of the k-th largest
+        bin = __builtin_amdgcn_readlane(bin, src);
+        above = __builtin_amdgcn_readlane(ab, src);
+        ceq = __builtin_amdgcn_readlane(cnt, src);
+        base += (unsigned)bin << sh;
+        if (sh == 0) break;                                           // the bin is one value: `ceq` values equal it
+        if (ceq == 1) {                                               // one value left in play: it is the k-th largest
+            unsigned m = 0u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) m = max(m, (o[i] >= base && ((o[i] - base) >> sh) == 0u) ? o[i] : 0u);
+            base = rs_wave_max_u(m);
+            break;
+        }
+        width = sh >= 8 ? 256u : 1u << sh;      // (the bin just chosen spans 2^sh values: the next level must not look beyond it)
+        sh = sh > 8 ? sh - 8 : 0;
+    }
+    out.thr = ord2f(base); out.c_gt = above; out.c_ge = above + ceq;
+    if (near) {
+        const unsigned on = f2ord(out.thr - mdgat_near_eps(out.thr, out.mx));
+        int c = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) c += o[i] >= on ? 1 : 0;
+        *near = rs_wave_sum_i(c) > k;
+    }
+    if (out.c_ge == k || ceq <= list_cap) return out;
+    // more than list_cap values share the k-th place: the first k - c_gt of them in key order stay (key = lane + 64 i)
+    const int need = k - above;
+    int seen = 0, keylim = nk;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        unsigned long long mask = __ballot(o[i] == base);
+        const int c = __popcll(mask);
+        if (keylim == nk && seen + c >= need) {
+            for (int n = need - seen; n > 1; --n) mask &= mask - 1;
+            keylim = 64 * i + __builtin_ctzll(mask);
+        }
+        seen += c;
+    }
+    out.keylim = keylim;
+    return out;
+}

@@ -89,6 +89,41 @@ def test_unchanged_caller_sequence_of_test_py(models_mdgat, golden_dir, tmp_path
             assert float(pred['loss'].mean()) == 0.0                           # (train.py:245 takes the mean; inference: zero)
 
 
+def test_dropin_exact_mode(models_mdgat, golden_dir):
+    """The same unchanged-caller sequence with ONE more config key, arithmetic='fp64' (INTEGRATION.md section 3b), at BASELINE
+    configs[0]'s shape (8 pairs of 256 keypoints, L = 4, dynamic self layers): the checkpoint goes through DataParallel's
+    load_state_dict in FLOAT32 and `.double()` afterwards exactly like test.py:156-193 - which rounds the weights to fp32 in the
+    reference as well - so the comparison is with the oracle on those rounded weights; matches identical, scores within 1e-4, and
+    the loader's float64 inputs reach the library unrounded."""
+    from torch.autograd import Variable
+    from mdgat_matcher_amd import synth
+    from oracle import mdgat_oracle as O
+    MDGAT = models_mdgat.MDGAT
+    L, S, n, B = 4, 20, 256, 4
+    cfg = {'sinkhorn_iterations': S, 'match_threshold': 0.2, 'lr': 1e-4, 'loss_method': 'triplet_loss', 'k': synth.DEFAULT_K,
+           'descriptor': 'FPFH', 'mutual_check': False, 'triplet_loss_gamma': 0.5, 'train_step': 3, 'L': L, 'arithmetic': 'fp64'}
+    sd32 = {kk: (v.float() if v.is_floating_point() else v) for kk, v in synth.make_state_dict(L=L, seed=11).items()}
+    net = torch.nn.DataParallel(MDGAT(cfg))
+    net.load_state_dict({'module.' + kk: v for kk, v in sd32.items()})
+    net.to(torch.device('cuda:0'))
+    sd_ref = {kk: (v.double() if v.is_floating_point() else v) for kk, v in sd32.items()}     # what .double() makes of the fp32 module
+    with torch.no_grad():
+        pred = _loader_batch(B, n, n, 70)
+        cap = {}
+        ref = O.mdgat_forward(sd_ref, {kk: v for kk, v in cfg.items() if kk != 'arithmetic'}, {kk: v for kk, v in pred.items() if torch.is_tensor(v)}, cap)
+        net.double().eval()
+        for kk in pred:
+            if kk not in ('idx0', 'idx1', 'sequence') and type(pred[kk]) == torch.Tensor:
+                pred[kk] = Variable(pred[kk].cuda().detach())
+        data = net(pred)
+        assert data['matches0'].dtype == torch.int64 and data['matching_scores0'].dtype == torch.float64
+        assert torch.equal(data['matches0'].cpu(), ref['matches0']) and torch.equal(data['matches1'].cpu(), ref['matches1'])
+        assert (data['matching_scores0'].cpu() - ref['matching_scores0']).abs().max() < 1e-4
+        Z = net.module.match(pred['keypoints0'], pred['descriptors0'], pred['keypoints1'], pred['descriptors1'], pred['scores0'],
+                             pred['scores1'], return_scores=True)[4]
+        assert (Z.cpu().double() - cap['Z']).abs().max() < 1e-4
+
+
 def test_all_dustbin_batch_returns_integer_zero_scores(models_mdgat, golden_dir):
     """mdgat.py:465-467: when no frame-0 keypoint of the batch is matched the reference returns torch.zeros_like(indices) -
     INT64 zeros - for both score vectors (tests/golden/edge_cases.npz holds the reference's output)."""

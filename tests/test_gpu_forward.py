@@ -807,9 +807,9 @@ def test_exact_topk_selects_like_fp64_on_the_same_layer_input(n, m, L, S, k, B):
     assert res[False][1] == [0, 0, 0, 0]                  # switched off: nothing is examined
     examined, corrected, _, given_up = res[True][1]
     assert examined > 0 and corrected <= examined and given_up == 0
-    # ~1 row in 10^3 is listed, ~1 in 50 of those corrected: the re-decision must stay a rare path
+    # ~1-2 rows in 10^3 are listed (the window is 4e-5 since round 5), ~1 in 50-100 of those corrected: the re-decision must stay a rare path
     rows = sum(B * 4 * (n + m) for kk in net._topk_schedule() if kk > 0)
-    assert examined < 0.005 * rows and corrected <= max(8, examined // 10), (examined, corrected, rows)
+    assert examined < 0.01 * rows and corrected <= max(8, examined // 10), (examined, corrected, rows)
 
 
 def test_fuzz_checkpoint_short():

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Fuzz of the fp64 dynamic attention kernel's selection (csrc/f64.hip + row_search.hpp) on the GPU box: random shapes, k, logit
+scales, duplicated keys; the kept keys must be torch.topk's on the fp64 logits, row by row, and exactly k of them.  Rows whose k-th
+and (k+1)-th fp64 logit agree to 1e-13 relative (duplicated keys: equal in exact arithmetic, the last bits are the summation order's)
+are only held to the count: any choice among equals is right.    python tools/fuzz_f64_topk.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from mdgat_matcher_amd import ops  # noqa: E402
+
+DEV = 'cuda:0'
+
+
+def run(seconds=30.0, seed=0, verbose=True):
+    rs = np.random.RandomState(seed)
+    t0, cases, rows_checked, bad = time.time(), 0, 0, []
+    while time.time() - t0 < seconds:
+        N = int(rs.choice([16, 48, 64, 100, 256, 300, 512, 513, 700, 1024]))
+        M = N if rs.rand() < 0.6 else int(rs.choice([32, 64, 200, 512, 640]))
+        k = int(rs.randint(1, min(N, M) + 1))
+        cross = bool(rs.rand() < 0.4)
+        scale = float(rs.choice([0.05, 0.5, 1.3, 3.0, 8.0]))
+        B = 1 if max(N, M) > 512 else 2
+        qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * scale)
+        if rs.rand() < 0.3:                     # duplicated keypoints
+            src = rs.randint(0, N + M, 6)
+            dst = rs.randint(0, N + M, 6)
+            qkv[:, dst] = qkv[:, src]
+        if rs.rand() < 0.2:                     # an offset: logits far from zero
+            qkv[:, :, 0] += float(rs.choice([-2, 2]))
+        out, masks = ops.attention_f64(qkv.to(DEV), N, M, cross, topk=k, return_selection=True)
+        fr = ((0, N), (N, N + M))
+        for side in range(2):
+            lo, hi = fr[side]
+            slo, shi = fr[1 - side] if cross else fr[side]
+            q = qkv[:, lo:hi, 0].permute(0, 2, 1, 3)              # [B, H, n, d]
+            kk = qkv[:, slo:shi, 1].permute(0, 2, 1, 3)
+            logits = (q @ kk.transpose(-1, -2)) / 32 ** 0.5
+            nk = logits.shape[-1]
+            mine = masks[side].cpu()
+            if k >= nk:
+                ok = mine.all(-1)
+                amb = torch.zeros_like(ok)
+            else:
+                top = logits.topk(k + 1, dim=-1)
+                own = torch.zeros_like(logits, dtype=torch.bool).scatter_(3, top.indices[..., :k], True)
+                amb = (top.values[..., k - 1] - top.values[..., k]).abs() <= 1e-13 * top.values[..., k].abs().clamp(min=1e-3)   # any choice among equal logits is right
+                ok = (mine == own).all(-1) | amb
+                ok &= (mine.sum(-1) == k)
+            rows_checked += int((~amb).sum())
+            if not bool(ok.all()):
+                idx = (~ok).nonzero()[0].tolist()
+                bad.append((N, M, k, cross, scale, side, idx))
+                if verbose:
+                    b_, h_, r_ = idx
+                    print(f'MISMATCH N={N} M={M} k={k} cross={cross} scale={scale} side={side} row={idx}: kept {int(mine[b_, h_, r_].sum())}, '
+                          f'diff keys {(mine[b_, h_, r_] ^ own[b_, h_, r_]).nonzero().flatten().tolist()}, '
+                          f'k-th / (k+1)-th logit {top.values[b_, h_, r_, k - 1].item():.17g} / {top.values[b_, h_, r_, k].item():.17g}')
+        cases += 1
+    if verbose:
+        print(f'fuzz_f64_topk: {cases} cases, {rows_checked} rows checked, {len(bad)} with a mismatch')
+    return cases, rows_checked, bad
+
+
+if __name__ == '__main__':
+    secs = float(sys.argv[1]) if len(sys.argv) > 1 else 30.0
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    _, _, bad = run(secs, seed)
+    sys.exit(1 if bad else 0)

@@ -79,7 +79,13 @@ def search(S, k, variant='shipped'):
     c_prev, t_prev = np.full(rows, nk, np.int64), lo.copy()
     waves = rows // 16
     passes = np.zeros(waves, np.int64)
+    cap = int(variant[5:]) if variant.startswith('defer') else 80
     for it in range(80):
+        if it >= cap:
+            # straggler deferral: after `cap` probes the wave stops; rows still probing go to a list that a
+            # repair.hip-style launch finishes one row per wave (state 9)
+            state[state == 0] = 9
+            break
         probing = state == 0
         wave_active = probing.reshape(waves, 16).any(1)
         if not wave_active.any():
@@ -151,6 +157,7 @@ def search(S, k, variant='shipped'):
     # finishing passes: state 2 = one pass; 4 = two; 5 = three
     done = state == 1
     assert ((S[done] >= thr[done][:, None]).sum(1) >= k).all()
+    search.deferred = int((state == 9).sum())
     st = state.reshape(waves, 16)
     passes += np.maximum((st == 2).any(1) * 1, (st == 4).any(1) * 2) + (st == 5).any(1) * 3
     search.last_probe_passes = passes - np.maximum((st == 2).any(1) * 1, (st == 4).any(1) * 2) - (st == 5).any(1) * 3
@@ -165,9 +172,14 @@ if __name__ == '__main__':
     for v in variants:
         tot, n = 0.0, 0
         hist = np.zeros(16, np.int64)
+        deferred = rows_all = 0
         for k, S in layers:
             passes, nprobe, _ = search(S, k, v)
+            deferred += getattr(search, 'deferred', 0)
+            rows_all += S.shape[0]
             tot += passes.sum()
             n += len(passes)
             hist += np.bincount(np.minimum(nprobe, 15), minlength=16)
+        if v.startswith('defer'):
+            print(f'   deferred rows: {deferred} of {rows_all} = {deferred / rows_all:.4f}')
         print(f'{v}: (last layer: probes per wave {search.last_probe_passes.mean():.2f}) {tot / n:.2f} counting passes per wave over {n} waves; probes per row: mean {np.dot(hist, np.arange(16)) / hist.sum():.2f}, histogram {hist.tolist()}')
