@@ -39,7 +39,10 @@ __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) { return __
 // ================================================================================================ GEMM
 constexpr int G_BM = 64, G_KC = 32, G_LD = G_KC + 2;      // row pitch 34 doubles = 68 dwords: the 64 lanes of a fragment read (row l15, k g) hit 64 banks
 
-template <int WN>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
+// FAST: whole tiles only (M a multiple of 64, N of 32 WN, K and K0 of 32, 16-byte aligned rows): a chunk comes from ONE source,
+// the tile copies are 16-byte loads without a predicate each (the general form runs 24 guarded 8-byte loads per thread and
+// chunk, every one its own exec-masked branch)
+template <int WN, bool FAST>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
     constexpr int BN = 32 * WN;
     extern __shared__ __attribute__((aligned(16))) double gsm[];
@@ -52,6 +55,23 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
     constexpr int NA = G_BM * G_KC / 256, NW = BN * G_KC / 256;
     double ra[NA], rw[NW];
     auto fetch = [&](int k0) {
+        if (FAST) {
+            const double* src = k0 < a.K0 ? a.A0 + k0 : a.A1 + (k0 - a.K0);
+            const int ld = k0 < a.K0 ? a.lda0 : a.lda1;
+#pragma unroll
+            for (int u = 0; u < NA / 2; ++u) {
+                const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+                const f64x2 v = *reinterpret_cast<const f64x2*>(src + (size_t)(row0 + r) * ld + c);
+                ra[2 * u] = v[0]; ra[2 * u + 1] = v[1];
+            }
+#pragma unroll
+            for (int u = 0; u < NW / 2; ++u) {
+                const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+                const f64x2 v = *reinterpret_cast<const f64x2*>(a.W + (size_t)(col0 + r) * a.ldw + k0 + c);
+                rw[2 * u] = v[0]; rw[2 * u + 1] = v[1];
+            }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) {
             const int idx = tid + 256 * u, r = idx >> 5, c = idx & 31;
@@ -68,6 +88,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
         }
     };
     auto stash = [&]() {
+        if (FAST) {
+#pragma unroll
+            for (int u = 0; u < NA / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(As + (idx >> 4) * G_LD + (idx & 15) * 2) = f64x2{ra[2 * u], ra[2 * u + 1]}; }
+#pragma unroll
+            for (int u = 0; u < NW / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(Ws + (idx >> 4) * G_LD + (idx & 15) * 2) = f64x2{rw[2 * u], rw[2 * u + 1]}; }
+            return;
+        }
 #pragma unroll
         for (int u = 0; u < NA; ++u) { const int idx = tid + 256 * u; As[(idx >> 5) * G_LD + (idx & 31)] = ra[u]; }
 #pragma unroll
@@ -571,16 +598,22 @@ __global__ void mfma64_probe_fill(double* p, int n) {
 // ================================================================================================ launchers
 int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MDGAT_OK;
-    static std::atomic<unsigned long long> done2{0}, done4{0};
-    if (a.N > 64) {
-        const size_t lds = (size_t)(G_BM + 128) * G_LD * sizeof(double);
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(gemm_f64_kernel<4>), lds, done4, "gemm_f64 LDS")) return rc;
-        hipLaunchKernelGGL(gemm_f64_kernel<4>, dim3((a.M + G_BM - 1) / G_BM, (a.N + 127) / 128), dim3(256), lds, s, a);
-    } else {
-        const size_t lds = (size_t)(G_BM + 64) * G_LD * sizeof(double);
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(gemm_f64_kernel<2>), lds, done2, "gemm_f64 LDS")) return rc;
-        hipLaunchKernelGGL(gemm_f64_kernel<2>, dim3((a.M + G_BM - 1) / G_BM, (a.N + 63) / 64), dim3(256), lds, s, a);
-    }
+    static std::atomic<unsigned long long> done2{0}, done4{0}, done2f{0}, done4f{0};
+    const int wn = a.N > 64 ? 4 : 2, bn = 32 * wn;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool fast = a.M % G_BM == 0 && a.N % bn == 0 && a.K % G_KC == 0 && a.K0 % G_KC == 0 && a.lda0 % 2 == 0 && a.ldw % 2 == 0 && al16(a.A0) && al16(a.W) &&
+                      (a.K0 >= a.K || (a.lda1 % 2 == 0 && al16(a.A1)));
+    const size_t lds = (size_t)(G_BM + bn) * G_LD * sizeof(double);
+    const dim3 grid((a.M + G_BM - 1) / G_BM, (a.N + bn - 1) / bn);
+    auto go = [&](auto kern, std::atomic<unsigned long long>& done) -> int {
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), lds, done, "gemm_f64 LDS")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+        return MDGAT_OK;
+    };
+    int rc;
+    if (wn == 4) rc = fast ? go(gemm_f64_kernel<4, true>, done4f) : go(gemm_f64_kernel<4, false>, done4);
+    else rc = fast ? go(gemm_f64_kernel<2, true>, done2f) : go(gemm_f64_kernel<2, false>, done2);
+    if (rc) return rc;
     return mdgat_check_hip(hipGetLastError(), "gemm_f64 launch");
 }
 

@@ -1120,25 +1120,47 @@ int launch_sk(const SkArgs& a, int B, hipStream_t s) {
 
 }  // namespace
 
-// tiling of a pair: GR row slabs of 128 rows x GC column slabs of 512 columns, one workgroup each
-static void sk_tiling(int N, int M, int& GR, int& GC) { GR = (N + 127) / 128; GC = (M + 511) / 512; }
-static int sk_max_groups(int N, int M) {      // pairs in flight on a 256-CU part (upper bound used for sizing)
+// rows per wave for launches of few pairs (see sk_rpw); 16 = the throughput shape everywhere until measured otherwise
+static int mdgat_sk_small_rpw(int B, int N, int M) { (void)B; (void)N; (void)M; return 16; }
+// tiling of a pair: GR row slabs of 8 RPW rows (RPW rows per wave: 16) x GC column slabs of 512 columns, one workgroup each
+static void sk_tiling(int N, int M, int& GR, int& GC, int rpw = 16) { GR = (N + 8 * rpw - 1) / (8 * rpw); GC = (M + 511) / 512; }
+// Rows per wave of a launch.  16 (128-row slabs) is the throughput shape.  Few pairs leave most of the part idle - one pair of
+// 512 keypoints is 4 workgroups on 256 CUs - and thinner slabs (RPW = 8, 4: 8 / 16 workgroups per pair, an iteration's
+// issue-bound row and column passes 2x / 4x shorter, 7 / 15 partners to poll instead of 3) trade that idleness for exchange:
+// MDGAT_SK_RPW (measurements) forces a value where the shape allows it (one column slab, at most 16 row slabs).
+static int sk_rpw(int B, int N, int M) {
+    static const int forced = [] { const char* e = getenv("MDGAT_SK_RPW"); return e ? atoi(e) : 0; }();
+    int rpw = 16;
+    if (forced == 4 || forced == 8) rpw = forced;
+    else if (forced == 0) rpw = mdgat_sk_small_rpw(B, N, M);
+    if (rpw != 16 && (M > 512 || (N + 8 * rpw - 1) / (8 * rpw) > 16)) rpw = 16;
+    return rpw;
+}
+// (sizes are taken for the thinnest slabs a shape may run with: the layout inside is the launch's own)
+static int sk_max_groups(int N, int M, int rpw = 16) {      // pairs in flight on a 256-CU part (upper bound used for sizing)
     int GR, GC;
-    sk_tiling(N, M, GR, GC);
+    sk_tiling(N, M, GR, GC, rpw);
     int g = 256 / (GR * GC);
     return g > 64 ? 64 : (g < 1 ? 1 : g);
 }
-static size_t slots_bytes(int N, int M) {
+static size_t slots_bytes_rpw(int N, int M, int rpw) {
     int GR, GC;
-    sk_tiling(N, M, GR, GC);
+    sk_tiling(N, M, GR, GC, rpw);
     const size_t per_group = ((size_t)2 * GC * GR * SLOT_STRIDE + (size_t)2 * GR * GC * ROW_STRIDE) * sizeof(unsigned long long);
-    return (256 + per_group * sk_max_groups(N, M) + 255) & ~(size_t)255;
+    return (256 + per_group * sk_max_groups(N, M, rpw) + 255) & ~(size_t)255;
+}
+static size_t slots_bytes(int N, int M) {
+    size_t b = slots_bytes_rpw(N, M, 16);
+    for (int rpw : {8, 4})
+        if (M <= 512 && (N + 8 * rpw - 1) / (8 * rpw) <= 16) { const size_t x = slots_bytes_rpw(N, M, rpw); b = x > b ? x : b; }
+    return b;
 }
 static size_t flags_bytes(int B) { return ((size_t)B * sizeof(unsigned) + 255) & ~(size_t)255; }
 size_t sinkhorn_cluster_workspace_bytes(int B, int N, int M) {
     if (N > 2048 || M > 2048) return 0;
     int GR, GC;
     sk_tiling(N, M, GR, GC);
+    if (M <= 512 && (N + 31) / 32 <= 16) GR = (N + 31) / 32;       // (the thinnest slabs the shape may run with: sk_rpw)
     // exchange slots + per-pair range flags + fused arg-max scratch: row bests [B][GC][N] (int + float), column bests [B][GR][M] (int + float)
     return slots_bytes(N, M) + flags_bytes(B) + ((size_t)B * GC * N * 2 + (size_t)B * GR * M * 2) * sizeof(float);
 }
@@ -1161,14 +1183,14 @@ static int launch_streaming(const SkArgs& a, int B, hipStream_t s) {
 
 size_t sinkhorn_slots_clear_bytes(int B, int N, int M) { return (N > 2048 || M > 2048) ? 0 : slots_bytes(N, M) + flags_bytes(B); }
 
+template <int RPW>
 static int launch_scaling(int B, int N, int M, const float* scores, const float* alpha_dev, float alpha_host, int iters,
                           float* Z, void* ws, int num_cu, const SkExtract* ex, unsigned* status, float* Zfb, bool slots_cleared, hipStream_t s) {
-    constexpr int RPW = 16;
     int GR, GC;
-    sk_tiling(N, M, GR, GC);
+    sk_tiling(N, M, GR, GC, RPW);
     const int P = GR * GC;                         // workgroups per pair, one per CU
     int ngroups = num_cu / P;
-    if (ngroups > sk_max_groups(N, M)) ngroups = sk_max_groups(N, M);
+    if (ngroups > sk_max_groups(N, M, RPW)) ngroups = sk_max_groups(N, M, RPW);
     if (ngroups > B) ngroups = B;
     // Placement: the workgroups of a pair exchange through L2 every iteration, which is fast and steady only inside one XCD
     // (workgroup i runs on XCD i % 8): group g takes the workgroups with blockIdx % 8 == g % 8, and the grid is padded to a
@@ -1201,9 +1223,12 @@ static int launch_scaling(int B, int N, int M, const float* scores, const float*
         a.cbest_val = reinterpret_cast<float*>(p);
     }
     void* args[] = {&a};
-    const void* kern = GC > 1 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, true, 16>)
-                     : GR > 4 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 16>)
-                              : reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 4>);
+    const void* kern;
+    if constexpr (RPW == 16)
+        kern = GC > 1 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, true, 16>)
+             : GR > 4 ? reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 16>)
+                      : reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 4>);
+    else kern = reinterpret_cast<const void*>(sinkhorn_scaling_kernel<RPW, false, 16>);      // (one column slab, up to 16 row slabs: sk_rpw)
     // The workgroups of a pair wait for each other, so all of them must become resident.  A workgroup takes a whole CU
     // (512 threads x 256 registers), and ngroups * P <= num_cu by construction: every workgroup gets a CU as soon as the
     // stragglers of earlier launches leave.  A plain launch therefore suffices when this launch has the device to itself, and
@@ -1250,7 +1275,10 @@ int launch_sinkhorn(int B, int N, int M, const float* scores, const float* bin_s
         int dev = 0, num_cu = 0;
         if (int rc = mdgat_check_hip(hipGetDevice(&dev), "hipGetDevice")) return rc;
         if (int rc = mdgat_check_hip(hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev), "CU count")) return rc;
-        return launch_scaling(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
+        const int rpw = sk_rpw(B, N, M);
+        if (rpw == 4) return launch_scaling<4>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
+        if (rpw == 8) return launch_scaling<8>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
+        return launch_scaling<16>(B, N, M, scores, bin_score_dev, bin_score_host, iters, Z, ws, num_cu, ex, status, Zfb, slots_cleared, s);
     }
     if (!Z) { mdgat_set_error("sinkhorn: the streaming kernel needs a Z buffer"); return MDGAT_ERR_BAD_ARG; }
     SkArgs a{scores, bin_score_dev, bin_score_host, Z, N, M, iters, nullptr, nullptr, nullptr};

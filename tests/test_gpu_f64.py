@@ -248,3 +248,27 @@ def test_f64_dict_api_slices_and_errors():
     rec1 = torch.cat([data['keypoints1'], data['scores1'][..., None], data['descriptors1']], -1).float()
     mf = net.match_frames(rec0, rec1, normalize=False)
     assert (mf[0] == m0).float().mean() > 0.95
+
+
+def test_fuzz_forward_f64_short():
+    """20 s of tools/fuzz_forward_f64.py: random shapes, depths, top-k schedules, extraction modes, bin scores through the exact
+    mode against the UNFORCED oracle - literal 1e-4 on Z, no top-k row selected differently, matches consistent."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('fuzz_forward_f64', os.path.join(root, 'tools', 'fuzz_forward_f64.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    cases, fails, worst = fz.run(20.0, seed=3, verbose=True)
+    assert cases >= 5 and fails == 0 and worst < Z_TOL
+
+
+def test_fuzz_f64_topk_short():
+    """15 s of tools/fuzz_f64_topk.py: the fp64 dynamic attention's kept keys = torch.topk on fp64 logits, random shapes, k, logit
+    scales and duplicated keypoints (it found the radix select's one bug)."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location('fuzz_f64_topk', os.path.join(root, 'tools', 'fuzz_f64_topk.py'))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    cases, rows, bad = fz.run(15.0, seed=7, verbose=True)
+    assert cases >= 20 and rows > 10000 and not bad
