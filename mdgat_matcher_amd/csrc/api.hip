@@ -102,6 +102,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     if (cfg->L < 0 || 2 * cfg->L > MDGAT_MAX_LAYERS) { mdgat_set_error("mdgat_create: L=%d out of range", cfg->L); return MDGAT_ERR_BAD_ARG; }
     if (cfg->attention_mode != MDGAT_ATTENTION_FP32 && cfg->attention_mode != MDGAT_ATTENTION_F16) { mdgat_set_error("mdgat_create: bad attention_mode %d", cfg->attention_mode); return MDGAT_ERR_BAD_ARG; }
     if (cfg->arithmetic != MDGAT_ARITH_FP32 && cfg->arithmetic != MDGAT_ARITH_FP64) { mdgat_set_error("mdgat_create: bad arithmetic %d", cfg->arithmetic); return MDGAT_ERR_BAD_ARG; }
+    if (cfg->arithmetic == MDGAT_ARITH_FP64 && cfg->attention_mode != MDGAT_ATTENTION_FP32) { mdgat_set_error("mdgat_create: MDGAT_ARITH_FP64 and MDGAT_ATTENTION_F16 exclude each other"); return MDGAT_ERR_BAD_ARG; }
     if (cfg->arithmetic == MDGAT_ARITH_FP64 && cfg->f64_layers > 2 * cfg->L) { mdgat_set_error("mdgat_create: f64_layers=%d > 2L", cfg->f64_layers); return MDGAT_ERR_BAD_ARG; }
     if (cfg->extract_mode < 0 || cfg->extract_mode > 3) { mdgat_set_error("mdgat_create: bad extract_mode %d", cfg->extract_mode); return MDGAT_ERR_BAD_ARG; }
     for (int i = 0; i < 2 * cfg->L; ++i)

@@ -397,6 +397,10 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         for (int q = wave; q < QT; q += 4) {
             const float* row = sm.img + q * imgld;
             int* hist = sm.hist + wave * RS_HIST_INTS;
+#ifdef F64_KO_SEARCH
+            if (lane == 0) sm.sel[q] = RowSel{0.f, 0, 0, 0};
+            continue;
+#endif
             const RowSel rs = nk <= 512 ? f64_row_select<8>(row, nk, a.topk, lane, hist)
                             : nk <= 1024 ? f64_row_select<16>(row, nk, a.topk, lane, hist) : f64_row_select<32>(row, nk, a.topk, lane, hist);
             if (lane == 0) sm.sel[q] = rs;

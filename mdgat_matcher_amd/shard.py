@@ -88,9 +88,11 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
     return blob
 
 
-def broadcast_weights(net, device, rank: int, world: int):
+def broadcast_weights(net, device, rank: int, world: int, out64=None):
     """Rank 0 packs its parameters (BN fold etc., pack.py); the packed blob travels once by RCCL broadcast
-    and every rank installs it into its library handle.  Without a process group the module just packs lazily."""
+    and every rank installs it into its library handle.  Without a process group the module just packs lazily.
+    A module in the reference-exact mode (arithmetic='fp64') also needs the blob before its rounding to fp32: it travels in a
+    second broadcast (``out64``, a list, receives it - tests)."""
     if world == 1 and not _group_active():
         return None
     from . import pack
@@ -109,6 +111,8 @@ def broadcast_weights(net, device, rank: int, world: int):
         else:
             blob64 = torch.empty(n, dtype=torch.float64, device=device)
         broadcast_blob(blob64, 0)
+        if out64 is not None:
+            out64.append(blob64)
     if blob.is_cuda:
         net.load_packed(blob, blob64)
     return blob

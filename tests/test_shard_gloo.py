@@ -55,6 +55,46 @@ def test_two_rank_gloo():
     np.testing.assert_array_equal(res[0][4][:, 0], np.arange(12))
 
 
+def _worker_f64(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from mdgat_matcher_amd import MDGAT, shard, synth
+    r, w, _ = shard.init_distributed(world, backend='gloo')
+    net = MDGAT(synth.default_config(L=2, arithmetic='fp64')).double()
+    if r == 0:
+        net.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    got64 = []
+    blob = shard.broadcast_weights(net, 'cpu', r, w, out64=got64)
+    shard.barrier(w)
+    q.put((r, blob.numpy().copy(), got64[0].numpy().copy()))
+    shard.finalize(w)
+
+
+def test_two_rank_gloo_exact_mode_broadcasts_both_blobs():
+    """arithmetic='fp64': the fp64 blob (the folded weights before their rounding) travels next to the fp32 one, and a rank that
+    never loaded a checkpoint receives rank 0's, bit for bit."""
+    world, port = 2, 29711 + (os.getpid() % 200)
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_f64, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in range(world)], key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, ROOT)
+    from mdgat_matcher_amd import MDGAT, synth
+    ref = MDGAT(synth.default_config(L=2, arithmetic='fp64')).double()
+    ref.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    e32, e64 = ref.packed_weights(), ref.packed_weights(np.float64)
+    for r in range(2):
+        np.testing.assert_array_equal(res[r][1], e32)
+        np.testing.assert_array_equal(res[r][2], e64)
+        assert res[r][2].dtype == np.float64
+    np.testing.assert_array_equal(e64.astype(np.float32), e32)
+
+
 def _install_worker(rank, world, port, q):
     """The per-rank control flow of bench.py (init -> rank 0 loads the checkpoint -> broadcast of the packed blob ->
     load_packed -> net.double().eval() -> forward on the rank's shard) with the HIP library replaced at the _lib
