@@ -207,16 +207,16 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     assert (err < Z_TOL).all(), err
     assert es < Z_TOL
     assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
-    # the selections are the fp64 oracle's own on the same trajectory: zero rows differ
-    if n <= 512:
-        cap = {}
-        ref = O.mdgat_forward(sd, cfg, data, cap, forced_topk=forced)
-        rows = sum(r['rows'] for reps in cap.get('topk_report', {}).values() for r in reps)
-        bad = sum(r['bad_count'] for reps in cap.get('topk_report', {}).values() for r in reps)
-        print(f'[parity-f64] {name}: top-k rows differing from the fp64 selection: {rows}; full Z max|d| {np.abs(Zc - cap["Z"].numpy()).max():.2e}')
-        assert rows == 0 and bad == 0
-        assert np.abs(Zc - cap['Z'].numpy()).max() < Z_TOL
-        assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
+    # the selections are the fp64 oracle's own on the same trajectory: zero rows differ (every shape: at 2048 keypoints the oracle
+    # takes a minute on the box's 16 cores)
+    cap = {}
+    ref = O.mdgat_forward(sd, cfg, data, cap, forced_topk=forced)
+    rows = sum(r['rows'] for reps in cap.get('topk_report', {}).values() for r in reps)
+    bad = sum(r['bad_count'] for reps in cap.get('topk_report', {}).values() for r in reps)
+    print(f'[parity-f64] {name}: top-k rows differing from the fp64 selection: {rows}; full Z max|d| {np.abs(Zc - cap["Z"].numpy()).max():.2e}')
+    assert rows == 0 and bad == 0
+    assert np.abs(Zc - cap['Z'].numpy()).max() < Z_TOL
+    assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
     # the untapped kernels (what ships) give the same bits
     plain = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=True)
     assert torch.equal(plain[0], m0) and torch.equal(plain[1], m1) and torch.equal(plain[4], Z)
