@@ -198,8 +198,8 @@ struct RowSel { float thr; int mode; int aux; int pad; };
 
 // the row search of row_search.hpp in the terms of this kernel's pass B
 template <int NV>
-__device__ RowSel f64_row_select(const float* row, int nk, int k, int lane, int* hist) {
-    const RowSearch r = topk_row_search<NV>(row, nk, k, lane, A_LIST, hist);
+__device__ RowSel f64_row_select(const float* row, int nk, int k, float zq, int lane, int* hist) {
+    const RowSearch r = topk_row_search<NV>(row, nk, k, zq, lane, A_LIST, hist);
     if (k >= nk || r.c_ge == k) return RowSel{r.thr, 0, 0, 0};
     if (r.c_ge - r.c_gt <= A_LIST) return RowSel{r.thr, 2, k - r.c_gt, 0};
     return RowSel{r.thr, 1, r.keylim, 0};
@@ -401,8 +401,8 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             if (lane == 0) sm.sel[q] = RowSel{0.f, 0, 0, 0};
             continue;
 #endif
-            const RowSel rs = nk <= 512 ? f64_row_select<8>(row, nk, a.topk, lane, hist)
-                            : nk <= 1024 ? f64_row_select<16>(row, nk, a.topk, lane, hist) : f64_row_select<32>(row, nk, a.topk, lane, hist);
+            const RowSel rs = nk <= 512 ? f64_row_select<8>(row, nk, a.topk, a.zq, lane, hist)
+                            : nk <= 1024 ? f64_row_select<16>(row, nk, a.topk, a.zq, lane, hist) : f64_row_select<32>(row, nk, a.topk, a.zq, lane, hist);
             if (lane == 0) sm.sel[q] = rs;
         }
         __syncthreads();

@@ -37,6 +37,12 @@ __device__ __forceinline__ unsigned rs_wave_max_u(unsigned v) {
 __device__ __forceinline__ unsigned rs_wave_min_u(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane(rs_wave_scan((int)v, -1, [](int a, int b) { return (int)min((unsigned)a, (unsigned)b); }), 63);
 }
+// (a float sum through the same six steps; returned as bits so that the callers' lambdas stay integer-typed)
+__device__ __forceinline__ int rs_wave_sum_i_bits(float v) {
+    auto f = [](int x) { return __builtin_bit_cast(float, x); };
+    const int r = rs_wave_scan(__builtin_bit_cast(int, v), 0, [&](int a, int b) { return __builtin_bit_cast(int, f(a) + f(b)); });
+    return __builtin_amdgcn_readlane(r, 63);
+}
 __device__ __forceinline__ int rs_wave_sum_i(int v) { return __builtin_amdgcn_readlane(rs_wave_scan(v, 0, [](int a, int b) { return a + b; }), 63); }
 
 struct RowSearch {
@@ -59,7 +65,7 @@ typedef __attribute__((address_space(3))) int rs_lds_int;
 typedef __attribute__((address_space(3))) const float rs_lds_cfloat;
 constexpr int RS_HIST_INTS = 320;       // 256 bins + one waste bin per lane
 template <int NV>
-__device__ RowSearch topk_row_search(const float* row_, int nk, int k, int lane, int list_cap, int* hist_, bool* near = nullptr) {
+__device__ RowSearch topk_row_search(const float* row_, int nk, int k, float zq, int lane, int list_cap, int* hist_, bool* near = nullptr) {
     // (both pointers are LDS: said here, or the function addresses them as flat memory)
     rs_lds_cfloat* row = (rs_lds_cfloat*)row_;
     rs_lds_int* hist = (rs_lds_int*)hist_;
@@ -67,19 +73,37 @@ __device__ RowSearch topk_row_search(const float* row_, int nk, int k, int lane,
     nk = __builtin_amdgcn_readfirstlane(nk);
     k = __builtin_amdgcn_readfirstlane(k);
     list_cap = __builtin_amdgcn_readfirstlane(list_cap);
+    zq = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, zq)));
     unsigned o[NV];                      // pads: 0, below the image of every float (-inf is 0x007fffff)
     unsigned omn = ~0u, omx = 0u;
+    float s1 = 0.f, s2 = 0.f;            // moments of the row from every STEPth register: they only choose where the select starts
+    constexpr int STEP = NV >= 8 ? 4 : 1;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int idx = lane + 64 * i;
-        o[i] = idx < nk ? f2ord(row[idx] + 0.f) : 0u;
+        const float f = idx < nk ? row[idx] + 0.f : 0.f;
+        o[i] = idx < nk ? f2ord(f) : 0u;
         omn = min(omn, idx < nk ? o[i] : ~0u); omx = max(omx, o[i]);
+        if (i % STEP == 0) { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
     }
     omn = rs_wave_min_u(omn); omx = rs_wave_max_u(omx);
     RowSearch out{-__builtin_inff(), nk, 0, ord2f(omx), 1 << 30};
     if (k >= nk) return out;             // keep everything
+    // Where the select starts.  The top byte of a float's image is sign and exponent: over the whole row [min, max] the first level's
+    // digits pile most of the values into two or three bins, and 64 lanes adding to one LDS address serialise (measured on rows of
+    // 2048: 25 000 cycles a row).  The k-th largest of a bell-shaped row sits near mean + zq sd: the select starts one deviation
+    // below that, where the values left in play (a third of the row for k = nk / 16) spread over a hundred bins and the first
+    // level already resolves 2^-6 of an octave; a row that does not hold k values above the start starts over from its minimum.
     unsigned base = omn;
-    int sh = 24 - __builtin_clz((omx - omn) | 0xffu);        // ((omx - omn) >> sh) < 256
+    {
+        s1 = __builtin_bit_cast(float, rs_wave_sum_i_bits(s1)); s2 = __builtin_bit_cast(float, rs_wave_sum_i_bits(s2));
+        const float inv_n = (float)STEP / (float)nk;
+        const float mu = s1 * inv_n;
+        const float sd = sqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f));
+        const unsigned cand = f2ord(mu + (zq - 1.0f) * sd);
+        if (cand > omn && cand < omx) base = cand;
+    }
+    int sh = 24 - __builtin_clz((omx - base) | 0xffu);       // ((omx - base) >> sh) < 256
     int above = 0, ceq = 0;
     unsigned width = 256u;               // digits in play at this level: the last step of a bin narrower than 256 values has fewer
     for (;;) {
@@ -95,6 +119,11 @@ __device__ RowSearch topk_row_search(const float* row_, int nk, int k, int lane,
         h.x = hist[4 * lane]; h.y = hist[4 * lane + 1]; h.z = hist[4 * lane + 2]; h.w = hist[4 * lane + 3];
         const int pre = rs_wave_scan(h.x + h.y + h.z + h.w, 0, [](int a, int b) { return a + b; });
         const int tot = __builtin_amdgcn_readlane(pre, 63);
+        if (above + tot < k) {            // (first level only: fewer than k values above the start - not a bell-shaped row)
+            base = omn;
+            sh = 24 - __builtin_clz((omx - omn) | 0xffu);
+            continue;
+        }
         // values in play above this lane's four bins, then bin by bin from the top
         const int a3 = above + tot - pre, a2 = a3 + h.w, a1 = a2 + h.z, a0 = a1 + h.y;
         int bin = -1, ab = 0, cnt = 0;
