@@ -250,6 +250,29 @@ def test_f64_dict_api_slices_and_errors():
     assert (mf[0] == m0).float().mean() > 0.95
 
 
+def test_f64_large_batch_runs_in_slices_on_two_lanes():
+    """40 pairs of 512 keypoints are more than 32 768 keypoints: the library cuts the batch into two slices on two lanes (csrc/api.hip:
+    forward_batched) - in the exact mode too, each lane with its own fp64 workspace.  What a pair returns does not depend on the
+    batch it travels in: bit-identical to the pair run alone, and the lanes setting changes nothing."""
+    L = 2
+    cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=20, arithmetic='fp64')
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=9))
+    net = net.eval().to(DEV)
+    data = synth.make_batch(40, 512, 512, device=DEV, first_pair=500)
+    args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
+    m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
+    torch.cuda.synchronize()
+    net.check(DEV)
+    for b in (0, 19, 20, 39):
+        one = net.match(*[a[b:b + 1] for a in args], return_scores=True)
+        assert torch.equal(one[0][0], m0[b]) and torch.equal(one[1][0], m1[b]) and torch.equal(one[4][0], Z[b]), b
+    net.set_lanes(1)
+    again = net.match(*args, return_scores=True)
+    assert torch.equal(again[0], m0) and torch.equal(again[4], Z)
+    net.set_lanes(2)
+
+
 def test_fuzz_forward_f64_short():
     """20 s of tools/fuzz_forward_f64.py: random shapes, depths, top-k schedules, extraction modes, bin scores through the exact
     mode against the UNFORCED oracle - literal 1e-4 on Z, no top-k row selected differently, matches consistent."""
