@@ -256,6 +256,26 @@ __device__ __forceinline__ float wave_sum16(float (&acc)[16], int lane) {
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(16 * lane, __builtin_bit_cast(int, w)));
 }
 
+// Eight wave-wide sums at once (the same scheme one stage shorter): returns, in lane r (< 8), the wave total of row r.
+__device__ __forceinline__ float wave_sum8(float (&acc)[8], int lane) {
+    float s[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { float x = acc[r], y = acc[r + 4]; swap_halves32(x, y); s[r] = x + y; }   // lanes < 32: row r, others row r + 4
+    float t[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { float x = s[r], y = s[r + 2]; swap_rows16(x, y); t[r] = x + y; }      // 16-lane row q: row r + 2 q
+    const bool b3 = (lane & 8) != 0;
+    const float keep = b3 ? t[1] : t[0], give = b3 ? t[0] : t[1];
+    float w = keep + dpp_bank_move<0x128, 0xf>(0.f, give);             // row_ror:8: lanes 16 q + 0..7 row 2 q, lanes 16 q + 8..15 row 2 q + 1
+    float o = dpp_bank_move<0x104, 0x5>(0.f, w);                       // the value of lane ^ 4
+    o = dpp_bank_move<0x114, 0xa>(o, w);
+    w += o;
+    w += dpp_bank_move<0xb1, 0xf>(0.f, w);                             // quad_perm [1, 0, 3, 2]
+    w += dpp_bank_move<0x4e, 0xf>(0.f, w);                             // quad_perm [2, 3, 0, 1]
+    // lanes 8 q .. 8 q + 7 hold the total of row q: bring it to lane q
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(32 * lane, __builtin_bit_cast(int, w)));
+}
+
 typedef __attribute__((address_space(1))) unsigned long long gu64;
 // cache policy of the polling loads: agent scope (served by the L2, never by a CU's L1).  "nt" measures the same and had
 // been used until round 3; "sc0" alone hits stale L1 lines (partners time out).
@@ -622,6 +642,17 @@ __global__ __launch_bounds__(SKS_THREADS, 2) void sinkhorn_scaling_kernel(SksArg
                 SK_TP(1);
                 psum = wave_sum16(racc, lane);                 // lane r: row r (lanes >= 16 are not used)
                 psum = lane < 16 ? psum : 0.f;
+            } else if (RPW == 8) {
+                float racc[8];
+#pragma unroll
+                for (int r = 0; r < 8; ++r) {
+                    float acc = K[r][0] * b[0];
+#pragma unroll
+                    for (int c = 1; c < 8; ++c) acc = fmaf(K[r][c], b[c], acc);
+                    racc[r] = acc;
+                }
+                psum = wave_sum8(racc, lane);                  // lane r: row r
+                psum = lane < 8 ? psum : 0.f;
             } else {
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {

@@ -21,7 +21,7 @@ def timed(fn, n=20, warm=5):
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
 out = []
-for (B, n, S) in ((1, 512, 100), (2, 512, 100), (4, 512, 100), (8, 512, 100), (16, 512, 100), (1, 256, 20)):
+for (B, n, S) in ((1, 512, 100), (2, 512, 100), (4, 512, 100), (8, 512, 100), (16, 512, 100), (64, 512, 100), (1, 256, 20), (1, 300, 100), (3, 450, 37)):
     s = torch.randn(B, n, n, device=dev) * 2
     ref = ops.sinkhorn(s, 1.0, S, streaming=True)
     Z = ops.sinkhorn(s, 1.0, S)
@@ -39,8 +39,13 @@ for B in (1, 4, 8):
     out.append(f"forward B={B} N=512 L=9 S=100: {t:.1f} us per call")
 print("\n".join(out))
 '''
-for rpw in ('16', '8', '4'):
-    env = dict(os.environ, MDGAT_SK_RPW=rpw, MDGAT_ROOT=ROOT)
+SETTINGS = sys.argv[1:] or ['16', '8', '4']        # 'w16': 16 waves of 8 rows (MDGAT_SK_WAVES=16)
+for rpw in SETTINGS:
+    env = dict(os.environ, MDGAT_ROOT=ROOT)
+    if rpw == 'w16':
+        env['MDGAT_SK_WAVES'] = '16'
+    else:
+        env['MDGAT_SK_RPW'] = rpw
     p = subprocess.run([sys.executable, '-c', WORKER], env=env, capture_output=True, text=True, timeout=900)
     print(f'--- MDGAT_SK_RPW={rpw}')
     print(p.stdout.strip() or p.stderr[-2000:])
