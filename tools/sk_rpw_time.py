@@ -39,13 +39,8 @@ for B in (1, 4, 8):
     out.append(f"forward B={B} N=512 L=9 S=100: {t:.1f} us per call")
 print("\n".join(out))
 '''
-SETTINGS = sys.argv[1:] or ['16', '8', '4']        # 'w16': 16 waves of 8 rows (MDGAT_SK_WAVES=16)
-for rpw in SETTINGS:
-    env = dict(os.environ, MDGAT_ROOT=ROOT)
-    if rpw == 'w16':
-        env['MDGAT_SK_WAVES'] = '16'
-    else:
-        env['MDGAT_SK_RPW'] = rpw
+for rpw in sys.argv[1:] or ['16', '8', '4']:
+    env = dict(os.environ, MDGAT_SK_RPW=rpw, MDGAT_ROOT=ROOT)
     p = subprocess.run([sys.executable, '-c', WORKER], env=env, capture_output=True, text=True, timeout=900)
     print(f'--- MDGAT_SK_RPW={rpw}')
     print(p.stdout.strip() or p.stderr[-2000:])
