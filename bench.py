@@ -180,10 +180,14 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
             torch.cuda.synchronize()
             ws.append((time.perf_counter() - t0) / steps)
         dt = sorted(ws)[len(ws) // 2]
+        # the kernel classes with the launches NOT overlapping (one lane), as `roofline` / `kernels` of the headline: under two lanes
+        # an interval between events also holds the other lane's launches
+        net.set_lanes(1)
         net.profile(dev, True)
         for _ in range(3):
             net._run(*inputs)
         prof = net.profile(dev, False)
+        net.set_lanes(2)
     net.check(dev)
     R = B * 2 * n
     att = B * 2 * 4 * (2 * 2.0 * n * n * 32)
@@ -214,8 +218,10 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
                          'frac': ach / PEAK_F64_MFMA_TFLOPS, 'sustained_peak': sustained, 'frac_of_sustained': ach / sustained, 'traffic': None,
                          'all_f64_classes': {'achieved': total_f64 / (f64_ms * 1e-3) / 1e12, 'frac': total_f64 / (f64_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                                              'algorithmic_gflop_per_pair': total_f64 / B / 1e9},
+                         'lanes': 1,
                          'note': 'algorithmic fp64 FLOPs of the class per step over its time per step (HIP events on the launch stream, '
-                                 'mdgat_profile) against the fp64 matrix peak; sustained_peak = an MFMA-only loop on this device in this run '
+                                 'mdgat_profile; launches not overlapping: mdgat_set_lanes(1) - pairs_per_s above is the two-lane '
+                                 'configuration) against the fp64 matrix peak; sustained_peak = an MFMA-only loop on this device in this run '
                                  '(mdgat_mfma_f64_probe); the dynamic attention executes 1.5x its algorithmic FLOPs beyond 512 keys (Q K^T '
                                  'twice), 1x up to 512 (logits kept in registers)'},
             'kernels': kernels}
@@ -541,7 +547,7 @@ def main():
                                'algorithmic_tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if 'flops' in r else None}
                               for r in rows]
         if not stub and not args.no_exact_mode and att == 'fp32':
-            out['exact_mode'] = exact_mode_block(dev, min(B, 32 if n <= 512 else 4), n, L, S)
+            out['exact_mode'] = exact_mode_block(dev, min(B, 64 if n <= 512 else 4), n, L, S)
             if f64:
                 out['roofline'] = out['exact_mode']['roofline']
         if not stub:
