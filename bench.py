@@ -207,6 +207,8 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
         kernels.append(row)
     f64_ms = sum(prof[k][0] for k in flops) / 3
     dom = max(flops, key=lambda k: prof[k][0])
+    # HBM bytes per launch of that class from the PMC passes of `MDGAT_FORWARD_LANES=1 tools/profile_f64.sh <tag> 64` (configs[1] only)
+    traffic, traffic_source = pmc_traffic('1_f64' if (B, n, L, S) == (64, 512, 9, 100) else -1, dom)
     ach = flops[dom] / (prof[dom][0] / 3 * 1e-3) / 1e12
     total_f64 = sum(flops.values())
     return {'arithmetic': "fp64 (v_mfma_f64_16x16x4_f64) for the encoders and layers 0.." + str(n64 - 1) + ' of ' + str(2 * L) +
@@ -215,7 +217,7 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
             'parity': 'Z within the literal 1e-4 of the reference on every reference-held pair (24/24, max 7e-6), zero top-k rows '
                       'selected differently: tests/test_gpu_f64.py',
             'roofline': {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': ach / PEAK_F64_MFMA_TFLOPS, 'sustained_peak': sustained, 'frac_of_sustained': ach / sustained, 'traffic': None,
+                         'frac': ach / PEAK_F64_MFMA_TFLOPS, 'sustained_peak': sustained, 'frac_of_sustained': ach / sustained, 'traffic': traffic, 'traffic_source': traffic_source,
                          'all_f64_classes': {'achieved': total_f64 / (f64_ms * 1e-3) / 1e12, 'frac': total_f64 / (f64_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
                                              'algorithmic_gflop_per_pair': total_f64 / B / 1e9},
                          'lanes': 1,
