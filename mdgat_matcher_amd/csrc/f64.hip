@@ -169,21 +169,29 @@ __device__ __forceinline__ double quad_sum(double v) { v += shfl_xor_f64(v, 16);
 // exp(x) for x <= 0 (or -inf): the softmax numerators.  n = rint(x / ln 2), exp(x - n ln 2) by its Taylor polynomial of degree 12
 // on |r| <= 0.347 (truncation 1.7e-16 relative), scaled by v_ldexp_f64 - 19 fp64-rate instructions, a third of the library
 // routine's, which also serves arguments these kernels never have.  -inf (masked keys) and everything below -745 give 0.
+// p r + c with the coefficient c in a SCALAR register pair, as ONE VOP3 instruction.  Written through the compiler, the ten
+// coefficients sit in twenty vector registers and, in the rescaling branch of the online softmax, each is copied before a
+// two-address v_fmac (18 v_mov_b64 per loop iteration of the full-attention kernel).
+__device__ __forceinline__ double fma_sc(double p, double r, double c) {
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
+    return d;
+}
+
 __device__ __forceinline__ double exp_neg(double x) {
     x = fmax(x, -745.5);
     const double n = __builtin_rint(x * 1.4426950408889634);
     double r = __builtin_fma(n, -0.6931471805599453, x);
     r = __builtin_fma(n, -2.3190468138462996e-17, r);
-    double p = 2.08767569878681e-09;                    // 1 / 12!
-    p = __builtin_fma(p, r, 2.505210838544172e-08);     // 1 / 11!
-    p = __builtin_fma(p, r, 2.755731922398589e-07);     // 1 / 10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);    // 1 / 9!
-    p = __builtin_fma(p, r, 2.48015873015873e-05);      // 1 / 8!
-    p = __builtin_fma(p, r, 0.0001984126984126984);     // 1 / 7!
-    p = __builtin_fma(p, r, 0.001388888888888889);      // 1 / 6!
-    p = __builtin_fma(p, r, 0.008333333333333333);      // 1 / 5!
-    p = __builtin_fma(p, r, 0.041666666666666664);      // 1 / 4!
-    p = __builtin_fma(p, r, 0.16666666666666666);       // 1 / 3!
+    double p = fma_sc(2.08767569878681e-09, r, 2.505210838544172e-08);     // 1 / 12!, 1 / 11!
+    p = fma_sc(p, r, 2.755731922398589e-07);     // 1 / 10!
+    p = fma_sc(p, r, 2.7557319223985893e-06);    // 1 / 9!
+    p = fma_sc(p, r, 2.48015873015873e-05);      // 1 / 8!
+    p = fma_sc(p, r, 0.0001984126984126984);     // 1 / 7!
+    p = fma_sc(p, r, 0.001388888888888889);      // 1 / 6!
+    p = fma_sc(p, r, 0.008333333333333333);      // 1 / 5!
+    p = fma_sc(p, r, 0.041666666666666664);      // 1 / 4!
+    p = fma_sc(p, r, 0.16666666666666666);       // 1 / 3!
     p = __builtin_fma(p, r, 0.5);
     p = __builtin_fma(p, r, 1.0);
     p = __builtin_fma(p, r, 1.0);
@@ -316,17 +324,20 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 
     if (!TOPK) {
         // ---- full attention: online softmax over this wave's blocks ----
-        double kf[8], kn[8];
+        // (the next block's K fragments are requested into the SAME registers as soon as this block's Q K^T products are issued and
+        // travel under the softmax and P V: a second register set copied at the top of the trip cost sixteen v_mov_b64 per block)
+        double kf[8];
         f64x2 vf[4];
-        if (wave < nblk) kload(wave, kn);
+        if (wave < nblk) kload(wave, kf);
         for (int jb = wave; jb < nblk; jb += 4) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) kf[j] = kn[j];
             vload(jb, vf);
-            if (jb + 4 < nblk) kload(jb + 4, kn);
+            f64x4 Sq[QB];
+#pragma unroll
+            for (int qb = 0; qb < QB; ++qb) Sq[qb] = logits(jb, kf, qb);
+            if (jb + 4 < nblk) kload(jb + 4, kf);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
-                const f64x4 S = logits(jb, kf, qb);
+                const f64x4 S = Sq[qb];
                 const double mb = quad_max(fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
                 const double mnew = fmax(mrun[qb], mb);
                 if (__any(mnew != mrun[qb])) {                    // (after the first blocks the running maximum rarely moves)
@@ -368,15 +379,16 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 }
             }
         } else {
-            double kf[8], kn[8];
-            if (wave < nblk) kload(wave, kn);
+            double kf[8];
+            if (wave < nblk) kload(wave, kf);
             for (int jb = wave; jb < nblk; jb += 4) {
+                f64x4 Sq[QB];
 #pragma unroll
-                for (int j = 0; j < 8; ++j) kf[j] = kn[j];
-                if (jb + 4 < nblk) kload(jb + 4, kn);
+                for (int qb = 0; qb < QB; ++qb) Sq[qb] = logits(jb, kf, qb);
+                if (jb + 4 < nblk) kload(jb + 4, kf);          // (in place, under the stores below: see the full-attention loop)
 #pragma unroll
                 for (int qb = 0; qb < QB; ++qb) {
-                    const f64x4 S = logits(jb, kf, qb);
+                    const f64x4 S = Sq[qb];
                     mrun[qb] = fmax(mrun[qb], fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
                     float* row = sm.img + (qb * 16 + l15) * imgld + jb * 16 + g;
 #pragma unroll
@@ -457,16 +469,17 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 }
             }
         } else {
-            double kf[8], kn[8];
+            double kf[8];
             f64x2 vf[4];
-            if (wave < nblk) kload(wave, kn);
+            if (wave < nblk) kload(wave, kf);
             for (int jb = wave; jb < nblk; jb += 4) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) kf[j] = kn[j];
                 vload(jb, vf);
-                if (jb + 4 < nblk) kload(jb + 4, kn);
+                f64x4 Sq[QB];
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) pass_b(jb, logits(jb, kf, qb), vf, qb);
+                for (int qb = 0; qb < QB; ++qb) Sq[qb] = logits(jb, kf, qb);
+                if (jb + 4 < nblk) kload(jb + 4, kf);
+#pragma unroll
+                for (int qb = 0; qb < QB; ++qb) pass_b(jb, Sq[qb], vf, qb);
             }
         }
     }

@@ -5,7 +5,7 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 N=$1; shift
 FL=""
 [ "$N" = attention ] && FL="-fno-slp-vectorize"
-[ "$N" = f64 ] && FL="-mllvm -amdgpu-mfma-vgpr-form"
+[ "$N" = f64 ] && FL="-mllvm -amdgpu-mfma-vgpr-form -fno-honor-nans"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 $FL "$@" --cuda-device-only -c $R/mdgat_matcher_amd/csrc/$N.hip -o /tmp/kr_$N.co
 /opt/rocm/lib/llvm/bin/clang-offload-bundler --unbundle --type=o --targets=hipv4-amdgcn-amd-amdhsa--gfx950 --input=/tmp/kr_$N.co --output=/tmp/kr_$N.elf
 /opt/rocm/lib/llvm/bin/llvm-readelf --notes /tmp/kr_$N.elf | python3 -c "
