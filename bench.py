@@ -549,8 +549,12 @@ def main():
                                'algorithmic_tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if 'flops' in r else None}
                               for r in rows]
         if not stub and not args.no_exact_mode and att == 'fp32':
-            out['exact_mode'] = exact_mode_block(dev, min(B, 64 if n <= 512 else 4), n, L, S)
-            if f64:
+            try:
+                out['exact_mode'] = exact_mode_block(dev, min(B, 64 if n <= 512 else 4), n, L, S)
+            except RuntimeError as e:      # (the headline above is measured and stands; the failure is reported, not hidden)
+                print(f'[bench] exact_mode: {e}', file=sys.stderr, flush=True)
+                out['exact_mode'] = {'error': str(e)}
+            if f64 and 'roofline' in out['exact_mode']:
                 out['roofline'] = out['exact_mode']['roofline']
         if not stub:
             # the legs behind the timed windows (dict API, latency, breakdown) ran more forwards: their status as well
