@@ -178,7 +178,10 @@ int mdgat_forward_f64(mdgat_handle* h, int B, int N, int M,
 /* The same forward fed with the loader's raw frame records instead of separate arrays: frames [B][N][37] fp32,
  * one record per keypoint = xyz(3) | saliency(1) | FPFH(33), the layout of the KITTI keypoint files that
  * SparseDataset.__getitem__ reads (load_data.py:146-165).  normalize_fpfh != 0 applies the loader's L2
- * normalisation of the FPFH part (load_data.py:290-292) inside the encoder kernel. */
+ * normalisation of the FPFH part (load_data.py:290-292) inside the encoder kernel.  On a MDGAT_ARITH_FP64 handle the records are
+ * taken through the loader's own sequence - the normalisation in float32 exactly as numpy computes it (its pairwise summation
+ * order, correctly rounded square root / reciprocal / products), then widened to double (load_data.py:294-295) - so that the
+ * forward sees bit for bit the inputs the reference's forward sees. */
 int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* frames0, const float* frames1,
                          int normalize_fpfh,
                          int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,

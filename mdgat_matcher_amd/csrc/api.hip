@@ -353,8 +353,10 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
     const float *kpts0 = in.kpts0, *sigma0 = in.sigma0, *fpfh0 = in.fpfh0, *kpts1 = in.kpts1, *sigma1 = in.sigma1, *fpfh1 = in.fpfh1;
     const float *rec0 = in.rec0, *rec1 = in.rec1;
     const int normalize_fpfh = in.normalize_fpfh;
-    const bool f64 = in.dk0 != nullptr;
     if (!h) { mdgat_set_error("mdgat_forward: null handle"); return MDGAT_ERR_BAD_ARG; }
+    // fp64 inputs, or raw float32 records on a handle that computes in fp64 (the loader's own sequence: float32 records, FPFH
+    // normalised in float32, widened to double - load_data.py:146-165, 290-295)
+    const bool f64 = in.dk0 != nullptr || (in.rec0 != nullptr && h->cfg.arithmetic == MDGAT_ARITH_FP64);
     if (!h->loaded) { mdgat_set_error("mdgat_forward: weights not loaded"); return MDGAT_ERR_NO_WEIGHTS; }
     if (f64 && (h->cfg.arithmetic != MDGAT_ARITH_FP64 || !h->loaded64)) {
         mdgat_set_error("mdgat_forward_f64: the handle needs MDGAT_ARITH_FP64 and mdgat_load_weights_f64");
@@ -453,7 +455,9 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         double* hk3 = hk2 + Rz * 64;
         double* hd1 = hk3 + Rz * 128;
         double* hd2 = hd1 + Rz * 64;
-        if ((rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, s))) return rc;
+        if (in.rec0) rc = launch_assemble_frames_f64(B, N, M, in.rec0, in.rec1, normalize_fpfh, in4, in33, s);
+        else rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, s);
+        if (rc) return rc;
         mark(MDGAT_PROF_F64_OTHER);
         // KeypointEncoder (mdgat.py:184-188), DescriptorEncoder (152-155), their sum (392-393) as one product over [hd ; hk]
         if ((rc = gemm(in4, 4, 4, nullptr, 0, bl.kenc0_w, bl.kenc0_b, 1, nullptr, hk1, 32, 32, 4))) return rc;

@@ -572,6 +572,50 @@ __global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, 
     }
 }
 
+// The same from the loader's raw records [B][N][37] float32 = x y z saliency FPFH (load_data.py:146-165), one thread per keypoint.
+// The reference normalises the FPFH row in FLOAT32 with numpy and widens afterwards (load_data.py:290-295:
+// `np.linalg.norm(descs, axis=1)`, `np.multiply(descs, 1 / norm)`, `torch.tensor(..., dtype=torch.double)`); an input that
+// differs from the reference's in its last float32 bit moves every logit by that much and flips near-tie top-k rows like an fp32
+// network would.  So the arithmetic is numpy's to the bit: the squares rounded one by one, their sum in the order of numpy's
+// pairwise reduction for 8 <= n <= 128 (eight strided partial sums, combined as a tree, the tail added last), correctly rounded
+// square root, reciprocal and products, nothing contracted into an FMA.  tests/test_oracle_golden.py pins this order against the
+// reference loader's own outputs; tests/test_gpu_f64.py asks for a bit-identical Z.
+__global__ __launch_bounds__(256) void assemble_frames_f64_kernel(const float* rec0, const float* rec1, int normalize, double* in4, double* in33,
+                                                                   int B, int N, int M) {
+    // (every operation rounded by itself: no product contracted into the sum behind it.  Plain operators - HIP's __fmul_rn /
+    // __fadd_rn ARE plain operators in this toolchain and __fsqrt_rn is the native approximation; `/` and __builtin_sqrtf are
+    // correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt)
+#pragma clang fp contract(off)
+    const int P = N + M;
+    const size_t rows = (size_t)B * P;
+    for (size_t row = (size_t)blockIdx.x * 256 + threadIdx.x; row < rows; row += (size_t)gridDim.x * 256) {
+        const int b = (int)(row / P), p = (int)(row - (size_t)b * P);
+        const bool f1 = p >= N;
+        const float* rec = (f1 ? rec1 + ((size_t)b * M + (p - N)) * 37 : rec0 + ((size_t)b * N + p) * 37);
+        float v[37];
+#pragma unroll
+        for (int c = 0; c < 37; ++c) v[c] = rec[c];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) in4[row * 4 + c] = (double)v[c];
+        float inv = 1.f;
+        if (normalize) {
+            float r[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) r[j] = v[4 + j] * v[4 + j];
+#pragma unroll
+            for (int i = 8; i < 32; i += 8)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { const float q = v[4 + i + j] * v[4 + i + j]; r[j] = r[j] + q; }
+            float sum = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+            const float q = v[36] * v[36];
+            sum = sum + q;
+            inv = 1.f / __builtin_sqrtf(sum);
+        }
+#pragma unroll
+        for (int c = 0; c < 33; ++c) in33[row * 33 + c] = (double)(normalize ? v[4 + c] * inv : v[4 + c]);
+    }
+}
+
 __global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* in, float* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
 }
@@ -689,6 +733,14 @@ int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* 
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(assemble_f64_kernel, dim3(blocks), dim3(256), 0, s, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, in4, in33, B, N, M);
     return mdgat_check_hip(hipGetLastError(), "assemble_f64 launch");
+}
+
+int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const float* rec1, int normalize, double* in4, double* in33, hipStream_t s) {
+    const size_t rows = (size_t)B * (N + M);
+    if (!rows) return MDGAT_OK;
+    const int blocks = (int)((rows + 255) / 256 < 8192 ? (rows + 255) / 256 : 8192);
+    hipLaunchKernelGGL(assemble_frames_f64_kernel, dim3(blocks), dim3(256), 0, s, rec0, rec1, normalize, in4, in33, B, N, M);
+    return mdgat_check_hip(hipGetLastError(), "assemble_frames_f64 launch");
 }
 
 int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s) {

@@ -478,20 +478,6 @@ class MDGAT(nn.Module):
                                'device; there is no CPU fallback')
         dev = probe.device
         f64 = getattr(self, 'arithmetic', 'fp32') == 'fp64'
-        if f64 and frames is not None:
-            # the loader's record handling (load_data.py:152-165, 290-292: split, FPFH normalised in float32, cast to double)
-            # on the device; the library's fp64 entry point takes the arrays
-            r0, r1 = (f.to(device=dev, dtype=torch.float32) for f in frames)
-            if r0.shape[-1] != 37 or r1.shape[-1] != 37 or r0.dim() != 3:
-                raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
-
-            def _split(r):
-                d = r[..., 4:]
-                if normalize:
-                    d = d * (1 / d.norm(dim=-1, keepdim=True))
-                return r[..., :3], r[..., 3], d
-            (kpts0, sigma0, fpfh0), (kpts1, sigma1, fpfh1) = _split(r0), _split(r1)
-            frames = None
         if frames is not None:
             if frames[0].shape[-1] != 37 or frames[1].shape[-1] != 37 or frames[0].dim() != 3:
                 raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')

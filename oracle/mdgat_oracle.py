@@ -307,6 +307,28 @@ def decode_frames(records):
             torch.tensor(desc, dtype=torch.double))
 
 
+def fpfh_normalise_float32_steps(desc):
+    """The float32 operations behind ``np.multiply(descs, 1 / np.linalg.norm(descs, axis=1))`` (load_data.py:290-292) one by one,
+    for rows of 33 values: squares rounded to float32, summed in the order of numpy's pairwise reduction for 8 <= n <= 128 (eight
+    strided partial sums over the first 32 values, combined as a balanced tree, the 33rd added last), square root, reciprocal and
+    products each rounded once.  This is the order ``assemble_frames_f64_kernel`` (csrc/f64.hip) implements for the exact
+    mode's record entry; tests/test_oracle_golden.py holds it to numpy's own result and to the reference loader's outputs."""
+    import numpy as np
+    f = np.float32
+    d = np.asarray(desc, dtype=f)
+    assert d.shape[-1] == 33
+    sq = (d * d).astype(f)
+    r = [sq[..., j].copy() for j in range(8)]
+    for i in (8, 16, 24):
+        for j in range(8):
+            r[j] = (r[j] + sq[..., i + j]).astype(f)
+    s = (((r[0] + r[1]).astype(f) + (r[2] + r[3]).astype(f)).astype(f) + ((r[4] + r[5]).astype(f) + (r[6] + r[7]).astype(f)).astype(f)).astype(f)
+    s = (s + sq[..., 32]).astype(f)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        inv = (f(1) / np.sqrt(s).astype(f)).astype(f)
+        return (d * inv[..., None]).astype(f)
+
+
 # ----------------------------------------------------------------------------- pose from matches (evaluation)
 def solve_icp(P, Q):
     """utils/utils_test.py:73-110 (numpy, float64): rigid transform taking P onto Q from one SVD, R = U Vh, no

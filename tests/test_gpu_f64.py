@@ -243,11 +243,47 @@ def test_f64_dict_api_slices_and_errors():
     cap = {}
     ref = O.mdgat_forward(sd, cfg, {k: v.cpu() for k, v in data.items()}, cap)
     assert torch.equal(m0.cpu(), ref['matches0']) and (Z.cpu().double() - cap['Z']).abs().max() < 2e-5
-    # records in: the loader's split and normalisation on the device, then the same path
+    # records in (mdgat_forward_frames on the fp64 handle): the same path
     rec0 = torch.cat([data['keypoints0'], data['scores0'][..., None], data['descriptors0']], -1).float()
     rec1 = torch.cat([data['keypoints1'], data['scores1'][..., None], data['descriptors1']], -1).float()
     mf = net.match_frames(rec0, rec1, normalize=False)
     assert (mf[0] == m0).float().mean() > 0.95
+
+
+def test_f64_records_in_equal_the_reference_loaders_arrays(golden_dir):
+    """Exact mode from the raw keypoint records (mdgat_forward_frames on an fp64 handle): the library takes the float32 records
+    through the loader's own sequence (load_data.py:146-165, 290-295: FPFH normalised in float32 as numpy does it, then widened),
+    so matching the records equals matching the arrays the REFERENCE loader made of them (tests/golden/aux_loader.npz) - not
+    approximately: every output bit for bit.  (The fp32-class path normalises with its own summation order: 1e-5.)"""
+    g = np.load(os.path.join(golden_dir, 'aux_loader.npz'))
+    L = 2
+    cfg = synth.default_config(L=L, k=[32, None, 16, None], sinkhorn_iterations=20, arithmetic='fp64')
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=4))
+    net = net.eval().to(DEV)
+    for j in range(int(g['n_items'])):
+        r0 = torch.from_numpy(g[f'item{j}_rec0']).to(DEV)
+        r1 = torch.from_numpy(g[f'item{j}_rec1']).to(DEV)
+        a = net.match_frames(r0, r1, return_scores=True)
+        t = {k: torch.from_numpy(g[f'item{j}_{k}']).to(DEV) for k in ('keypoints0', 'keypoints1', 'descriptors0', 'descriptors1',
+                                                                         'scores0', 'scores1')}
+        b = net.match(t['keypoints0'], t['descriptors0'], t['keypoints1'], t['descriptors1'], t['scores0'], t['scores1'],
+                      return_scores=True)
+        for x, y in zip(a, b):
+            assert torch.equal(x, y)
+    # a batch of records in slices on two lanes, normalisation off: the arrays widened on the host
+    data = synth.make_batch(5, 200, 168, device=DEV)
+    rec0 = torch.cat([data['keypoints0'], data['scores0'][..., None], data['descriptors0']], -1).float()
+    rec1 = torch.cat([data['keypoints1'], data['scores1'][..., None], data['descriptors1']], -1).float()
+    os.environ['MDGAT_FORWARD_SLICE_POINTS'] = '900'
+    try:
+        a = net.match_frames(rec0, rec1, normalize=False, return_scores=True)
+        b = net.match(rec0[..., :3].double(), rec0[..., 4:].double(), rec1[..., :3].double(), rec1[..., 4:].double(),
+                      rec0[..., 3].double(), rec1[..., 3].double(), return_scores=True)
+    finally:
+        os.environ.pop('MDGAT_FORWARD_SLICE_POINTS', None)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
 
 
 def test_f64_large_batch_runs_in_slices_on_two_lanes():

@@ -220,6 +220,24 @@ def test_loader_vs_reference(golden_dir, mutual):
         assert rep == int(g[tag + 'rep']) and rep > 10
 
 
+def test_fpfh_normalisation_order_is_numpys(golden_dir):
+    """The exact mode's record entry (mdgat_forward_frames on an fp64 handle: csrc/f64.hip assemble_frames_f64_kernel) normalises
+    the FPFH rows in float32 in numpy's own operation order, so that the forward sees the reference loader's inputs bit for bit.
+    The order, restated step by step in the oracle, against numpy (load_data.py:290-292) and against the loader's outputs."""
+    g = _load(golden_dir, 'aux_loader')
+    for j in range(int(g['n_items'])):
+        for side in (0, 1):
+            rec = g[f'item{j}_rec{side}']
+            out = O.fpfh_normalise_float32_steps(rec[:, 4:]).astype(np.float64)
+            np.testing.assert_array_equal(out, g[f'item{j}_descriptors{side}'])
+    rs = np.random.RandomState(5)
+    d = (rs.standard_normal((50000, 33)) * 10.0 ** rs.uniform(-6, 6, (50000, 1))).astype(np.float32)
+    d[rs.rand(50000, 33) < 0.3] = 0.0                                   # sparse histograms
+    d[:7] = 0.0                                                         # empty rows: 0 * inf = NaN, as in the reference
+    ref = np.multiply(d, 1 / np.linalg.norm(d, axis=1).reshape(-1, 1))
+    np.testing.assert_array_equal(O.fpfh_normalise_float32_steps(d), ref)
+
+
 def test_committed_fixtures_are_what_the_generator_writes():
     """Fixture guard: tools/make_goldens.py --check regenerates the small fixtures from the imported reference
     into a scratch directory and compares keys and values with the committed files.  Only where /root/reference exists (the
