@@ -234,7 +234,8 @@ def test_fpfh_normalisation_order_is_numpys(golden_dir):
     d = (rs.standard_normal((50000, 33)) * 10.0 ** rs.uniform(-6, 6, (50000, 1))).astype(np.float32)
     d[rs.rand(50000, 33) < 0.3] = 0.0                                   # sparse histograms
     d[:7] = 0.0                                                         # empty rows: 0 * inf = NaN, as in the reference
-    ref = np.multiply(d, 1 / np.linalg.norm(d, axis=1).reshape(-1, 1))
+    with np.errstate(divide='ignore', invalid='ignore'):
+        ref = np.multiply(d, 1 / np.linalg.norm(d, axis=1).reshape(-1, 1))
     np.testing.assert_array_equal(O.fpfh_normalise_float32_steps(d), ref)
 
 
