@@ -657,10 +657,37 @@ __global__ void mfma64_probe_fill(double* p, int n) {
 }  // namespace
 
 // ================================================================================================ launchers
+// compute units of the current device (asked once per device)
+static int f64_cu_count() {
+    static std::atomic<int> cached[16];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+    int n = cached[dev].load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
 int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MDGAT_OK;
     static std::atomic<unsigned long long> done2{0}, done4{0}, done2f{0}, done4f{0};
-    const int wn = a.N > 64 ? 4 : 2, bn = 32 * wn;
+    // Tile width.  64 x 128 tiles do a third more arithmetic per byte staged through LDS; 64 x 64 tiles are twice as many workgroups
+    // (four resident per CU instead of three).  Up to a few rounds of workgroups the launch is bound by how evenly it fills the
+    // CUs, not by its inner loop: one pair of 512 keypoints is 16 row tiles - 48 wide workgroups on 256 CUs for the q|k|v product,
+    // 96 narrow ones, 20 -> 17 us; 8192 rows x 128 outputs 31 -> 21 us (profiles/NOTES_r5.md section 9).  The narrow tile is taken
+    // when its rounds of resident workgroups, priced at 0.55 of a wide round, come out below the wide tile's.
+    static const int wn_env = [] { const char* e = getenv("MDGAT_F64_GEMM_WN"); return e ? atoi(e) : 0; }();      // (measurements)
+    int wn = 2;
+    if (a.N > 64) {
+        const int cus = f64_cu_count();
+        const long tiles_m64 = (a.M + G_BM - 1) / G_BM;
+        const long tw = tiles_m64 * ((a.N + 127) / 128), tn = tiles_m64 * ((a.N + 63) / 64);
+        const long rw = (tw + 3 * cus - 1) / (3 * cus), rn = (tn + 4 * cus - 1) / (4 * cus);
+        wn = (tw <= 6L * cus && rn * 55 < rw * 100) ? 2 : 4;
+        if (wn_env == 2 || wn_env == 4) wn = wn_env;
+    }
+    const int bn = 32 * wn;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool fast = a.M % G_BM == 0 && a.N % bn == 0 && a.K % G_KC == 0 && a.K0 % G_KC == 0 && a.lda0 % 2 == 0 && a.ldw % 2 == 0 && al16(a.A0) && al16(a.W) &&
                       (a.K0 >= a.K || (a.lda1 % 2 == 0 && al16(a.A1)));
