@@ -37,14 +37,17 @@ namespace {
 __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
 // ================================================================================================ GEMM
-constexpr int G_BM = 64, G_KC = 32, G_LD = G_KC + 2;      // row pitch 34 doubles = 68 dwords: the 64 lanes of a fragment read (row l15, k g) hit 64 banks
+constexpr int G_BM = 64, G_KC = 32;      // row pitch KC + 2 doubles (34: 68 dwords; 66: 132): the 64 lanes of a fragment read (row l15, k g) hit 64 banks
 
 // FAST: whole tiles only (M a multiple of 64, N of 32 WN, K and K0 of 32, 16-byte aligned rows): a chunk comes from ONE source,
 // the tile copies are 16-byte loads without a predicate each (the general form runs 24 guarded 8-byte loads per thread and
 // chunk, every one its own exec-masked branch)
-template <int WN, bool FAST>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
+// KC: depth of a chunk.  32; 64 (FAST only) for launches of less than a round of workgroups, which are a chain of chunk round trips
+// (load -> registers -> LDS -> barrier, ~2 us each with nothing else on the CU to cover it): half as many.
+template <int WN, bool FAST, int KC = G_KC>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
-    constexpr int BN = 32 * WN;
+    static_assert(KC == 32 || (KC == 64 && FAST), "chunk depth");
+    constexpr int BN = 32 * WN, G_LD = KC + 2, G_KC = KC, RSH = KC == 64 ? 5 : 4, RMASK = (1 << RSH) - 1;
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double* As = gsm;                       // [64][G_LD]
     double* Ws = gsm + G_BM * G_LD;         // [BN][G_LD]
@@ -60,13 +63,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
             const int ld = k0 < a.K0 ? a.lda0 : a.lda1;
 #pragma unroll
             for (int u = 0; u < NA / 2; ++u) {
-                const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+                const int idx = tid + 256 * u, r = idx >> RSH, c = (idx & RMASK) * 2;
                 const f64x2 v = *reinterpret_cast<const f64x2*>(src + (size_t)(row0 + r) * ld + c);
                 ra[2 * u] = v[0]; ra[2 * u + 1] = v[1];
             }
 #pragma unroll
             for (int u = 0; u < NW / 2; ++u) {
-                const int idx = tid + 256 * u, r = idx >> 4, c = (idx & 15) * 2;
+                const int idx = tid + 256 * u, r = idx >> RSH, c = (idx & RMASK) * 2;
                 const f64x2 v = *reinterpret_cast<const f64x2*>(a.W + (size_t)(col0 + r) * a.ldw + k0 + c);
                 rw[2 * u] = v[0]; rw[2 * u + 1] = v[1];
             }
@@ -90,9 +93,9 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
     auto stash = [&]() {
         if (FAST) {
 #pragma unroll
-            for (int u = 0; u < NA / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(As + (idx >> 4) * G_LD + (idx & 15) * 2) = f64x2{ra[2 * u], ra[2 * u + 1]}; }
+            for (int u = 0; u < NA / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(As + (idx >> RSH) * G_LD + (idx & RMASK) * 2) = f64x2{ra[2 * u], ra[2 * u + 1]}; }
 #pragma unroll
-            for (int u = 0; u < NW / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(Ws + (idx >> 4) * G_LD + (idx & 15) * 2) = f64x2{rw[2 * u], rw[2 * u + 1]}; }
+            for (int u = 0; u < NW / 2; ++u) { const int idx = tid + 256 * u; *reinterpret_cast<f64x2*>(Ws + (idx >> RSH) * G_LD + (idx & RMASK) * 2) = f64x2{rw[2 * u], rw[2 * u + 1]}; }
             return;
         }
 #pragma unroll
@@ -671,7 +674,7 @@ static int f64_cu_count() {
 
 int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0 || a.K <= 0) return MDGAT_OK;
-    static std::atomic<unsigned long long> done2{0}, done4{0}, done2f{0}, done4f{0};
+    static std::atomic<unsigned long long> done2{0}, done4{0}, done2f{0}, done4f{0}, done2d{0};
     // Tile width.  64 x 128 tiles do a third more arithmetic per byte staged through LDS; 64 x 64 tiles are twice as many workgroups
     // (four resident per CU instead of three).  Up to a few rounds of workgroups the launch is bound by how evenly it fills the
     // CUs, not by its inner loop: one pair of 512 keypoints is 16 row tiles - 48 wide workgroups on 256 CUs for the q|k|v product,
@@ -691,7 +694,12 @@ int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool fast = a.M % G_BM == 0 && a.N % bn == 0 && a.K % G_KC == 0 && a.K0 % G_KC == 0 && a.lda0 % 2 == 0 && a.ldw % 2 == 0 && al16(a.A0) && al16(a.W) &&
                       (a.K0 >= a.K || (a.lda1 % 2 == 0 && al16(a.A1)));
-    const size_t lds = (size_t)(G_BM + bn) * G_LD * sizeof(double);
+    // (chunks of 64 for whole-tile launches of at most one 64 x 64 tile per CU: one or two pairs of 512 keypoints - 19.0 -> 17.8 us
+    // at K = 256, the one-pair forward 1.54 -> 1.48 ms; from eight pairs on the shallower chunks' third resident workgroup wins)
+    static const bool deep_off = [] { const char* e = getenv("MDGAT_F64_GEMM_DEEP"); return e && atoi(e) == 0; }();      // (measurements)
+    const bool deep = !deep_off && fast && wn == 2 && a.K % 64 == 0 && (a.K0 >= a.K || a.K0 % 64 == 0) &&
+                      (long)((a.M + G_BM - 1) / G_BM) * ((a.N + 63) / 64) <= (long)f64_cu_count();
+    const size_t lds = (size_t)(G_BM + bn) * ((deep ? 64 : G_KC) + 2) * sizeof(double);
     const dim3 grid((a.M + G_BM - 1) / G_BM, (a.N + bn - 1) / bn);
     auto go = [&](auto kern, std::atomic<unsigned long long>& done) -> int {
         if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), lds, done, "gemm_f64 LDS")) return rc;
@@ -700,6 +708,7 @@ int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     };
     int rc;
     if (wn == 4) rc = fast ? go(gemm_f64_kernel<4, true>, done4f) : go(gemm_f64_kernel<4, false>, done4);
+    else if (deep) rc = go(gemm_f64_kernel<2, true, 64>, done2d);
     else rc = fast ? go(gemm_f64_kernel<2, true>, done2f) : go(gemm_f64_kernel<2, false>, done2);
     if (rc) return rc;
     return mdgat_check_hip(hipGetLastError(), "gemm_f64 launch");
