@@ -760,7 +760,8 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
     // fp64 logits stay in registers between the passes (KEEP), beyond that the rounding images of 32 rows would not fit the LDS
     if (!dyn) {
         // (fewer than two workgroups per CU with 32 queries each - a pair or two of 512 keypoints: 16 queries per workgroup, the
-        // same arithmetic per row; MDGAT_F64_ATT_QB=1|2 forces one for measurements)
+        // same arithmetic per row; MDGAT_F64_ATT_QB=1|2 forces one for measurements.  64 queries per workgroup - 234 registers, two
+        // waves per SIMD - lose: 236 -> 289 us at batch 32)
         static const int qb_env = [] { const char* e = getenv("MDGAT_F64_ATT_QB"); return e ? atoi(e) : 0; }();
         const bool small = 8L * ((nk_max + 31) / 32) * ugroups < 2L * f64_cu_count();
         if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false);
