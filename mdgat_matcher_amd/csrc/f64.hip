@@ -229,10 +229,15 @@ struct AttnLds {
     int* hist;           // [4 waves][RS_HIST_INTS] radix-select histograms (row_search.hpp)
     float* img;          // [QT][imgld]  (aliases obuf)
 };
-__device__ __forceinline__ AttnLds attn_lds(double* base, int QT) {
+__device__ __forceinline__ AttnLds attn_lds(double* base, int QT, bool topk) {
     AttnLds s;
     s.mw = base; base += 4 * QT;
     s.lw = base; base += 4 * QT;
+    if (!topk) {         // full attention: the row statistics and the output partials only (34 KB at 32 queries: four workgroups per CU)
+        s.lS = nullptr; s.lkey = nullptr; s.lcount = nullptr; s.sel = nullptr; s.hist = nullptr;
+        s.obuf = base; s.img = nullptr;
+        return s;
+    }
     s.lS = base; base += QT * A_LIST;
     s.lkey = reinterpret_cast<int*>(base);
     s.lcount = s.lkey + QT * A_LIST;
@@ -243,20 +248,23 @@ __device__ __forceinline__ AttnLds attn_lds(double* base, int QT) {
     return s;
 }
 size_t attn_lds_bytes(int QT, int nk_max, bool topk) {
-    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel) + 4 * RS_HIST_INTS * 4;
     const size_t ob = (size_t)4 * QT * 32 * 8;
+    if (!topk) return (size_t)8 * QT * 8 + ob;
+    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel) + 4 * RS_HIST_INTS * 4;
     const size_t im = topk ? (size_t)QT * (((nk_max + 63) & ~63) + 4) * 4 : 0;
     return fixed + (ob > im ? ob : im);
 }
 
 // KEEP (dynamic attention, at most 512 keys = 8 blocks per wave, QB = 1): the fp64 logits of pass A stay in registers (64 of them)
 // and pass B neither reads K nor multiplies again - a third of the matrix work of the recomputing form.
+// (32-query full attention: 146 registers, three waves per SIMD.  Held to 128 for a fourth - amdgpu_waves_per_eu(4), 16 spilled - it
+// loses: 239 -> 260 us at batch 32.)
 template <bool TOPK, int QB, bool TAP, bool KEEP = false>
 __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
     static_assert(!KEEP || (TOPK && QB == 1), "KEEP: dynamic attention, one query block");
     constexpr int QT = 16 * QB;
     extern __shared__ __attribute__((aligned(16))) double asmem[];
-    const AttnLds sm = attn_lds(asmem, QT);
+    const AttnLds sm = attn_lds(asmem, QT, TOPK);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
