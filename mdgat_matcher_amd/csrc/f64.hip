@@ -11,12 +11,15 @@
 // gfx950 mapping.  v_mfma_f64_16x16x4_f64: A 16x4, B 4x16 one double per lane (row / col = lane & 15, k = lane >> 4); C/D
 // col = lane & 15, row = (lane >> 4) + 4 reg - NOT the f32 layout (cdna_hip_programming.md section 3).  64 cycles per
 // instruction and SIMD: 32 FLOP/clk/SIMD, 78.6 TFLOP/s at 2.4 GHz - the vector fp64 rate; what the matrix instruction buys
-// is operand economy (1024 FMAs from two register pairs), not rate.  At that rate everything else hides behind the matrix
-// pipe as long as there is a second wave per SIMD: the kernels below are plain - LDS tiles for the GEMM, fragments straight
-// from L2 for the attention - and sized for two to three workgroups per CU.
+// is operand economy (1024 FMAs from two register pairs), not rate.  And it SHARES the SIMD's issue with the fp64 vector
+// instructions (PMC: MFMA-busy + vector-busy add up to the kernels' time, profiles/NOTES_r5.md section 1): a vector
+// instruction in a loop costs a sixteenth of a matrix instruction, so the loops are written for few of them (section 8: no NaN
+// canonicalisation, the exponential's coefficients as scalar operands, fragments reloaded in place).  Otherwise the kernels are
+// plain - LDS tiles for the GEMM, fragments straight from L2 for the attention - three resident workgroups per CU, and each
+// launcher sizes its tiles by the launch (64 x 64 tiles, 64-deep chunks, 16-query workgroups for a pair or two: section 9).
 //
 //   gemm_f64_kernel       C = act(A W^T + b) (+ R): every Conv1d(k=1) of the path (mdgat.py:34-46 after BN folding; 152-155,
-//                         184-188, 227-232, 246-248, 274), 64 x 64 / 64 x 128 tiles, 32-deep K chunks through LDS.
+//                         184-188, 227-232, 246-248, 274), 64 x 64 / 64 x 128 tiles, 32- (64-) deep K chunks through LDS.
 //   attention_f64_kernel  attention / dynamic_attention (mdgat.py:190-210) for 16 (or 32) queries of a (pair, frame, head) per
 //                         workgroup, the KEYS split over the four waves: S^T = K Q^T puts a query's logits into the four lanes
 //                         (q, q + 16, q + 32, q + 48), the D fragment of a 16-key block is the B operand of the P.V product as
