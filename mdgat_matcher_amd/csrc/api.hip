@@ -455,8 +455,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         double* hk3 = hk2 + Rz * 64;
         double* hd1 = hk3 + Rz * 128;
         double* hd2 = hd1 + Rz * 64;
-        if (in.rec0) rc = launch_assemble_frames_f64(B, N, M, in.rec0, in.rec1, normalize_fpfh, in4, in33, s);
-        else rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, s);
+        if (in.rec0) rc = launch_assemble_frames_f64(B, N, M, in.rec0, in.rec1, normalize_fpfh, in4, in33, status_dev + MDGAT_STATUS_RANGE, s);
+        else rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, status_dev + MDGAT_STATUS_RANGE, s);
         if (rc) return rc;
         mark(MDGAT_PROF_F64_OTHER);
         // KeypointEncoder (mdgat.py:184-188), DescriptorEncoder (152-155), their sum (392-393) as one product over [hd ; hk]
@@ -468,7 +468,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         if ((rc = gemm(hd2, 128, 128, hk3, 128, bl.encl_w, bl.encl_b, 0, nullptr, ws.x64, 128, 128, 256))) return rc;
         mark(MDGAT_PROF_F64_GEMM);
         if (taps && taps->x_enc)
-            if ((rc = launch_f64_to_f32(ws.x64, taps->x_enc, Rz * 128, s))) return rc;
+            if ((rc = launch_f64_to_f32(ws.x64, taps->x_enc, Rz * 128, nullptr, s))) return rc;
         first = f64_layer_count(h->cfg);
         for (int i = 0; i < first; ++i) {
             const size_t lo = bl.layer0 + (size_t)i * bl.layer_stride;
@@ -483,10 +483,10 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
             if ((rc = gemm(ws.hid64, 256, 256, nullptr, 0, lo + bl.mlp2_w, lo + bl.mlp2_b, 0, ws.x64, ws.x64, 128, 128, 256))) return rc;
             mark(MDGAT_PROF_F64_GEMM);
             if (taps && taps->x_layers)
-                if ((rc = launch_f64_to_f32(ws.x64, taps->x_layers + (size_t)i * Rz * 128, Rz * 128, s))) return rc;
+                if ((rc = launch_f64_to_f32(ws.x64, taps->x_layers + (size_t)i * Rz * 128, Rz * 128, nullptr, s))) return rc;
         }
         // hand-over: nothing behind the last dynamic layer is discontinuous
-        if ((rc = launch_f64_to_f32(ws.x64, ws.x, Rz * 128, s))) return rc;
+        if ((rc = launch_f64_to_f32(ws.x64, ws.x, Rz * 128, status_dev + MDGAT_STATUS_RANGE, s))) return rc;
         mark(MDGAT_PROF_F64_OTHER);
     }
 

@@ -565,11 +565,22 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 }
 
 // ================================================================================================ small kernels
+// Non-finite fp64 value, by its bits (this file is compiled with -fno-honor-nans: a floating-point test for NaN may be folded away).
+// The reference lets NaN / inf inputs run through to NaN outputs; here ReLU would turn a NaN into 0 and the call would return
+// plausible numbers - so the inputs (and the stream handed over to the fp32 kernels) are tested and the call is refused like
+// any other out-of-range activation (mdgat_async_status: range_violation).
+// (The values are LOADED as integers: applied to a floating-point value the same mask test is recognised as a class test and,
+// under the flag, reduced to "is infinite" - measured: a NaN input went through unnoticed.)
+__device__ __forceinline__ bool f64_bits_nonfinite(unsigned long long b) { return (b & 0x7ff0000000000000ull) == 0x7ff0000000000000ull; }
+__device__ __forceinline__ bool f32_bits_nonfinite(unsigned b) { return (b & 0x7f800000u) == 0x7f800000u; }
+__device__ __forceinline__ void f64_raise(unsigned* guard) { if (guard) __hip_atomic_store(guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // encoder inputs (mdgat.py:186-187, 154): in4 [R][4] = x y z saliency, in33 [R][33] = FPFH, rows pair-major (frame 0 then frame 1)
 __global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
-                                                            const double* sigma1, const double* fpfh1, double* in4, double* in33, int B, int N, int M) {
+                                                            const double* sigma1, const double* fpfh1, double* in4, double* in33, int B, int N, int M,
+                                                            unsigned* guard) {
     const int P = N + M;
     const size_t total = (size_t)B * P * 37;
+    bool bad = false;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const size_t row = idx / 37;
         const int c = (int)(idx - row * 37);
@@ -580,10 +591,13 @@ __global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, 
         const double* sg = f1 ? sigma1 : sigma0;
         const double* fp = f1 ? fpfh1 : fpfh0;
         const size_t r = (size_t)b * cnt + n;
-        if (c < 3) in4[row * 4 + c] = kp[r * 3 + c];
-        else if (c == 3) in4[row * 4 + 3] = sg[r];
-        else in33[row * 33 + (c - 4)] = fp[r * 33 + (c - 4)];
+        typedef const unsigned long long* bits_p;
+        const unsigned long long v = c < 3 ? bits_p(kp)[r * 3 + c] : c == 3 ? bits_p(sg)[r] : bits_p(fp)[r * 33 + (c - 4)];
+        bad |= f64_bits_nonfinite(v);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(c < 4 ? in4 + row * 4 + c : in33 + row * 33 + (c - 4));
+        *dst = v;
     }
+    if (bad) f64_raise(guard);
 }
 
 // The same from the loader's raw records [B][N][37] float32 = x y z saliency FPFH (load_data.py:146-165), one thread per keypoint.
@@ -595,7 +609,7 @@ __global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, 
 // square root, reciprocal and products, nothing contracted into an FMA.  tests/test_oracle_golden.py pins this order against the
 // reference loader's own outputs; tests/test_gpu_f64.py asks for a bit-identical Z.
 __global__ __launch_bounds__(256) void assemble_frames_f64_kernel(const float* rec0, const float* rec1, int normalize, double* in4, double* in33,
-                                                                   int B, int N, int M) {
+                                                                   int B, int N, int M, unsigned* guard) {
     // (every operation rounded by itself: no product contracted into the sum behind it.  Plain operators - HIP's __fmul_rn /
     // __fadd_rn ARE plain operators in this toolchain and __fsqrt_rn is the native approximation; `/` and __builtin_sqrtf are
     // correctly rounded under hipcc's default -fhip-fp32-correctly-rounded-divide-sqrt)
@@ -607,8 +621,13 @@ __global__ __launch_bounds__(256) void assemble_frames_f64_kernel(const float* r
         const bool f1 = p >= N;
         const float* rec = (f1 ? rec1 + ((size_t)b * M + (p - N)) * 37 : rec0 + ((size_t)b * N + p) * 37);
         float v[37];
+        bool bad = false;
 #pragma unroll
-        for (int c = 0; c < 37; ++c) v[c] = rec[c];
+        for (int c = 0; c < 37; ++c) {
+            const unsigned b = reinterpret_cast<const unsigned*>(rec)[c];
+            bad |= f32_bits_nonfinite(b);
+            v[c] = __builtin_bit_cast(float, b);
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) in4[row * 4 + c] = (double)v[c];
         float inv = 1.f;
@@ -625,13 +644,21 @@ __global__ __launch_bounds__(256) void assemble_frames_f64_kernel(const float* r
             sum = sum + q;
             inv = 1.f / __builtin_sqrtf(sum);
         }
+        bad |= !(inv < 3.0e38f);                 // (a row of zeros: 1 / 0 - NaN descriptors in the reference)
 #pragma unroll
         for (int c = 0; c < 33; ++c) in33[row * 33 + c] = (double)(normalize ? v[4 + c] * inv : v[4 + c]);
+        if (bad) f64_raise(guard);
     }
 }
 
-__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* in, float* out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+__global__ __launch_bounds__(256) void f64_to_f32_kernel(const double* in, float* out, size_t n, unsigned* guard) {
+    bool bad = false;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const unsigned long long b = reinterpret_cast<const unsigned long long*>(in)[i];
+        bad |= f64_bits_nonfinite(b);
+        out[i] = (float)__builtin_bit_cast(double, b);
+    }
+    if (bad) f64_raise(guard);
 }
 
 // measurement only: what v_mfma_f64_16x16x4_f64 sustains (two waves per SIMD, operands in registers, four accumulator chains)
@@ -783,25 +810,26 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
 }
 
 int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
-                        const double* sigma1, const double* fpfh1, double* in4, double* in33, hipStream_t s) {
+                        const double* sigma1, const double* fpfh1, double* in4, double* in33, unsigned* guard, hipStream_t s) {
     const size_t total = (size_t)B * (N + M) * 37;
     const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(assemble_f64_kernel, dim3(blocks), dim3(256), 0, s, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, in4, in33, B, N, M);
+    hipLaunchKernelGGL(assemble_f64_kernel, dim3(blocks), dim3(256), 0, s, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, in4, in33, B, N, M, guard);
     return mdgat_check_hip(hipGetLastError(), "assemble_f64 launch");
 }
 
-int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const float* rec1, int normalize, double* in4, double* in33, hipStream_t s) {
+int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const float* rec1, int normalize, double* in4, double* in33, unsigned* guard,
+                               hipStream_t s) {
     const size_t rows = (size_t)B * (N + M);
     if (!rows) return MDGAT_OK;
     const int blocks = (int)((rows + 255) / 256 < 8192 ? (rows + 255) / 256 : 8192);
-    hipLaunchKernelGGL(assemble_frames_f64_kernel, dim3(blocks), dim3(256), 0, s, rec0, rec1, normalize, in4, in33, B, N, M);
+    hipLaunchKernelGGL(assemble_frames_f64_kernel, dim3(blocks), dim3(256), 0, s, rec0, rec1, normalize, in4, in33, B, N, M, guard);
     return mdgat_check_hip(hipGetLastError(), "assemble_frames_f64 launch");
 }
 
-int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s) {
+int launch_f64_to_f32(const double* in, float* out, size_t n, unsigned* guard, hipStream_t s) {
     if (!n) return MDGAT_OK;
     const int blocks = (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
-    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, s, in, out, n);
+    hipLaunchKernelGGL(f64_to_f32_kernel, dim3(blocks), dim3(256), 0, s, in, out, n, guard);
     return mdgat_check_hip(hipGetLastError(), "f64_to_f32 launch");
 }
 

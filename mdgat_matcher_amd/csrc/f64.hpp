@@ -31,7 +31,9 @@ struct AttnF64Args {
 int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s);
 // in4 [R][4] = x y z saliency, in33 [R][33] = FPFH; rows pair-major, frame 0 then frame 1
 int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
-                        const double* sigma1, const double* fpfh1, double* in4, double* in33, hipStream_t s);
+                        const double* sigma1, const double* fpfh1, double* in4, double* in33, unsigned* guard, hipStream_t s);
 // the same from raw float32 records [B][N][37] (load_data.py:146-165; FPFH normalised as numpy does it in float32, 290-292)
-int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const float* rec1, int normalize, double* in4, double* in33, hipStream_t s);
-int launch_f64_to_f32(const double* in, float* out, size_t n, hipStream_t s);
+int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const float* rec1, int normalize, double* in4, double* in33, unsigned* guard,
+                               hipStream_t s);
+// guard (all three): host-mapped status word raised when a value is not finite (tested by its bits), or nullptr
+int launch_f64_to_f32(const double* in, float* out, size_t n, unsigned* guard, hipStream_t s);

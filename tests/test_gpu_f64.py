@@ -286,6 +286,40 @@ def test_f64_records_in_equal_the_reference_loaders_arrays(golden_dir):
         assert torch.equal(x, y)
 
 
+def test_f64_refuses_non_finite_inputs():
+    """The reference lets a NaN / inf input run through to NaN outputs.  In the exact mode a ReLU would turn the NaN into 0 and the
+    call would return plausible numbers: the inputs are tested by their bits (csrc/f64.hip is compiled with -fno-honor-nans) and the
+    call is refused like any out-of-range activation - arrays and raw records, and a record whose FPFH row is all zero
+    (1 / 0 in the loader's normalisation: NaN descriptors in the reference)."""
+    L = 2
+    cfg = synth.default_config(L=L, k=[16, None, 8, None], sinkhorn_iterations=10, arithmetic='fp64')
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=3))
+    net = net.eval().to(DEV)
+    clean = synth.make_batch(2, 96, 80, device=DEV)
+    net(clean)                                            # a clean call passes
+    for key, idx in (('descriptors0', (1, 5, 7)), ('keypoints1', (0, 3, 1)), ('scores0', (1, 9))):
+        for bad in (float('nan'), float('inf'), -float('inf')):
+            data = {k: v.clone() for k, v in clean.items()}
+            data[key][idx] = bad
+            with pytest.raises(RuntimeError):
+                net(data)
+    rec0 = torch.cat([clean['keypoints0'], clean['scores0'][..., None], clean['descriptors0']], -1).float()
+    rec1 = torch.cat([clean['keypoints1'], clean['scores1'][..., None], clean['descriptors1']], -1).float()
+    net.match_frames(rec0, rec1)
+    net.check(DEV)
+    for poke in ('nan', 'zero_row'):
+        r0 = rec0.clone()
+        if poke == 'nan':
+            r0[1, 4, 20] = float('nan')
+        else:
+            r0[0, 7, 4:] = 0.0
+        net.match_frames(r0, rec1)
+        with pytest.raises(RuntimeError):
+            net.check(DEV)
+    net(clean)                                            # and the module keeps working afterwards
+
+
 def test_f64_large_batch_runs_in_slices_on_two_lanes():
     """40 pairs of 512 keypoints are more than 32 768 keypoints: the library cuts the batch into two slices on two lanes (csrc/api.hip:
     forward_batched) - in the exact mode too, each lane with its own fp64 workspace.  What a pair returns does not depend on the
