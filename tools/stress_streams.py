@@ -1,5 +1,5 @@
 """Several forwards in flight on several streams at shapes whose Sinkhorn pair spans many CUs (GPU box):
-    python tools/stress_streams.py [streams] [rounds] [N] [B]
+    python tools/stress_streams.py [streams] [rounds] [N] [B]          (MDGAT_STRESS_ARITH=fp64: the exact mode)
 N = 2048: 64 workgroups per pair, spread over all XCDs - the case in which concurrent cluster launches can leave every CU
 with a workgroup whose partners cannot be dispatched.  Every result must equal the serial result (bit for bit, or - when a
 launch fell back to the streaming kernel - to 1e-4 on Z with at most a handful of near-tie arg-maxes apart)."""
@@ -9,10 +9,13 @@ from mdgat_matcher_amd import MDGAT, synth
 ns, rounds, N, B = (int(sys.argv[i]) if len(sys.argv) > i else d for i, d in ((1, 4), (2, 3), (3, 2048), (4, 2)))
 dev = 'cuda:0'
 L = 9          # (synthetic weights are scaled for L = 9: shallower nets produce scores beyond the Sinkhorn range guard)
-net = MDGAT(synth.default_config(L=L, sinkhorn_iterations=50))
+arith = os.environ.get('MDGAT_STRESS_ARITH', 'fp32')      # fp64: the reference-exact mode
+net = MDGAT(synth.default_config(L=L, sinkhorn_iterations=50, arithmetic=arith))
+if arith == 'fp64':
+    net = net.double()
 net.load_state_dict(synth.make_state_dict(L=L, seed=0))
 net = net.eval().to(dev)
-batches = [synth.make_batch(B, N, N, first_pair=10 * i, device=dev, dtype=torch.float32) for i in range(ns)]
+batches = [synth.make_batch(B, N, N, first_pair=10 * i, device=dev, dtype=torch.float64 if arith == 'fp64' else torch.float32) for i in range(ns)]
 args = [(d['keypoints0'], d['descriptors0'], d['keypoints1'], d['descriptors1'], d['scores0'], d['scores1']) for d in batches]
 serial = [net.match(*a, return_scores=True) for a in args]
 torch.cuda.synchronize()
