@@ -27,6 +27,10 @@ the MEDIAN window is the reported value (`timing` lists them all).  Rank 0 print
   roofline_qk  - the Q K^T contraction of full attention (the north star's "QK^T roofline"): the phase in isolation
                  (same kernel, softmax and P.V knocked out; mdgat_attention_qk_probe) timed with HIP events on the
                  launch stream, as algorithmic (`frac`) and executed (`frac_executed`) fraction of the dense f16 MFMA peak;
+  parity       - measured in this run, outside the timed windows: the reference-held pairs of the workload's shape
+                 (tests/golden/cfg_*.npz: inputs by seed, the imported reference's own fp64 outputs) through both arithmetic
+                 modes - pairs within the literal 1e-4 on Z, max|dZ|, matches identical;
+  roofline_sinkhorn - the Sinkhorn class against the fp32 vector peak (2 S (n+1)^2 FMA visits per pair);
   cpu_baseline - the CPU oracle (fp64 PyTorch restatement of the reference, "port") timed on this box's
                  host cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -230,8 +234,6 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
                           ' (through the last dynamic layer); split-f16 kernels behind it',
             'pairs_per_s': B / dt, 'ms_per_pair': 1e3 * dt / B, 'ms_per_step': 1e3 * dt, 'batch': B, 'steps': steps, 'windows': windows,
             'one_pair_per_call_ms': one_ms,
-            'parity': 'Z within the literal 1e-4 of the reference on every reference-held pair (24/24, max 7e-6), zero top-k rows '
-                      'selected differently: tests/test_gpu_f64.py',
             'roofline': {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F64_MFMA_TFLOPS, 'sustained_peak': sustained, 'frac_of_sustained': ach / sustained, 'traffic': traffic, 'traffic_source': traffic_source,
                          'all_f64_classes': {'achieved': total_f64 / (f64_ms * 1e-3) / 1e12, 'frac': total_f64 / (f64_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
@@ -243,6 +245,57 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
                                  '(mdgat_mfma_f64_probe); the dynamic attention executes 1.5x its algorithmic FLOPs beyond 512 keys (Q K^T '
                                  'twice), 1x up to 512 (logits kept in registers)'},
             'kernels': kernels}
+
+
+PARITY_FIXTURES = {(256, 4, 20): 'cfg_n256_L4_S20', (512, 9, 100): 'cfg_n512_L9_S100', (2048, 9, 200): 'cfg_n2048_L9_S200_b'}
+
+
+def parity_block(dev, n, L, S, stub=False):
+    """Where both arithmetic modes stand against the north star's bar ON THIS BOX, IN THIS RUN (not a quoted string): the pairs the
+    repository holds the REFERENCE's own outputs for at this workload's shape (tests/golden/cfg_*.npz, written by
+    tools/make_goldens.py from the imported /root/reference; inputs and weights are regenerated from the seeds in the fixture)
+    are matched in the fp32-class throughput mode and in the reference-exact mode; per mode: pairs whose Z lies within the
+    literal 1e-4 of the reference on every held entry (every 8th row / column, the whole dustbin row and column), the largest
+    |dZ|, whether matches0 / matches1 are bit-identical, the largest matching-score difference.  A few ms of GPU time, outside
+    the timed windows."""
+    import numpy as np
+    name = PARITY_FIXTURES.get((n, L, S))
+    path = os.path.join(ROOT, 'tests', 'golden', f'{name}.npz') if name else None
+    if not path or not os.path.exists(path):
+        return {'error': f'no reference-held fixture for N={n} L={L} S={S}'}
+    g = np.load(path)
+    B, gn, gm, gL, gS, seed, first_pair = [int(x) for x in g['meta']]
+    k = [None if x < 0 else int(x) for x in g['k']]
+    sub = int(g['sub']) if 'sub' in g else 8
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    sd = synth.make_state_dict(L=gL, seed=seed, bin_score=float(g['bin_score']) if 'bin_score' in g else 1.0)
+    data = synth.make_batch(B, gn, gm, first_pair=first_pair, device=dev)
+    modes = {}
+    for mode in ('fp32', 'fp64'):
+        net = MDGAT(synth.default_config(L=gL, k=k, sinkhorn_iterations=gS, arithmetic=mode)).double()
+        net.load_state_dict(sd)
+        net = net.eval().to(dev)
+        with torch.no_grad():
+            m0, m1, s0, s1, Z = net._run(data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'],
+                                         data['descriptors1'], want_Z=True)
+        if not stub:
+            torch.cuda.synchronize()
+            net.check(dev)
+        Zc = Z.cpu().double().numpy()
+        mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+        err = np.abs(mine - ref_Z).max(1)
+        es = max(np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max(), np.abs(s1.cpu().double().numpy() - g['default_mscores1']).max())
+        modes[mode] = {'pairs': B, 'pairs_within_1e-4': int((err < 1e-4).sum()), 'max_abs_dZ': float(err.max()),
+                       'matches_identical': bool(np.array_equal(m0.cpu().numpy(), g['default_matches0']) and
+                                                 np.array_equal(m1.cpu().numpy(), g['default_matches1'])),
+                       'max_abs_d_mscores': float(es)}
+        net._invalidate()
+    return {'fixture': f'tests/golden/{name}.npz: {B} pairs, N={gn} M={gm} L={gL} S={gS}, weights seed {seed} - outputs of the imported '
+                       'reference (tools/make_goldens.py)',
+            'bar': 'Z within 1e-4 of the reference on every held entry of a pair; matches bit-identical',
+            'modes': modes,
+            'note': 'fp32 = the throughput path (value / roofline above): a flipped top-k near-tie moves Z by a few 1e-4 around one '
+                    'keypoint; fp64 = the reference-exact mode (exact_mode), what a float64 module - net.double(), test.py:193 - runs'}
 
 
 def cpu_baseline(n, L, S, budget_s=15.0, max_pairs=64):
@@ -312,7 +365,6 @@ def main():
     ap.add_argument('--no-breakdown', action='store_true')
     ap.add_argument('--no-dict-api', action='store_true', help='skip the forward(dict) throughput leg')
     ap.add_argument('--no-latency', action='store_true', help='skip the one-pair-per-call latency block')
-    ap.add_argument('--exact-topk', action='store_true', help='mdgat_config.exact_topk (exact re-decision of near-threshold top-k rows)')
     ap.add_argument('--arithmetic', default='fp32', choices=['fp32', 'fp64'],
                     help="'fp64': time the reference-exact mode (MDGAT(arithmetic='fp64')) as the step; never the headline")
     ap.add_argument('--no-exact-mode', action='store_true', help='skip the exact_mode block (reference-exact fp64 mode on a bounded batch)')
@@ -342,7 +394,6 @@ def main():
 
     cfg = synth.default_config(L=L, sinkhorn_iterations=S)
     cfg['attention_dtype'] = att
-    cfg['exact_topk'] = bool(args.exact_topk)
     cfg['arithmetic'] = args.arithmetic
     f64 = args.arithmetic == 'fp64'
     net = MDGAT(cfg).double().eval() if f64 else MDGAT(cfg).eval()
@@ -422,19 +473,24 @@ def main():
                        'collectives': torch.distributed.get_backend() if torch.distributed.is_initialized() else 'none',
                        # what the communicator saw (RCCL when collectives == 'nccl'): must equal n_gpus
                        'rccl_world_size': torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1,
-                       'pairs_per_rank': [int(v) for v in per_rank[:, 0].tolist()],
-                       'exact_topk': bool(net.exact_topk)},
+                       'pairs_per_rank': [int(v) for v in per_rank[:, 0].tolist()]},
             'timing': {'windows': len(windows), 'value_is': 'median window', 'window_ms': [round(1e3 * w, 3) for w in windows],
                        'best_pairs_per_s': pairs / min(windows), 'worst_pairs_per_s': pairs / max(windows),
                        'per_rank_ms_per_step': [round(v, 4) for v in per_rank[:, 1].tolist()]},
             # mdgat_async_status after the timed windows (the timed step is the asynchronous MDGAT._run)
-            'status': {'sinkhorn_fallback': bool(status['sinkhorn_fallback']), 'range_violation': bool(range_violation),
-                       # where the DEFAULT (fp32-class) path stands against the literal bar, so that the number does not live in
-                       # profiles/ only: matches identical on every pair; Z within 1e-4 of the unforced fp64 reference on the pairs
-                       # in which no top-k near-tie flipped (profiles/parity_r4b.txt), on all pairs in the exact mode (exact_mode)
-                       'literal_1e-4_pairs': '4/16 at configs[1], 16/16 at configs[0], 0/2 at configs[4] on the default fp32-class path '
-                                             '(matches identical on every pair); 24/24 with arithmetic=fp64 (exact_mode)'},
+            'status': {'sinkhorn_fallback': bool(status['sinkhorn_fallback']), 'range_violation': bool(range_violation)},
         }
+        # where both modes stand against the literal bar, MEASURED here on the reference-held pairs of this shape (parity_block)
+        try:
+            out['parity'] = parity_block(dev, n, L, S, stub=stub)
+        except RuntimeError as e:
+            print(f'[bench] parity: {e}', file=sys.stderr, flush=True)
+            out['parity'] = {'error': str(e)}
+        if 'modes' in out['parity']:
+            pm = out['parity']['modes']
+            out['status']['literal_1e-4_pairs'] = {m: f"{pm[m]['pairs_within_1e-4']}/{pm[m]['pairs']}" for m in pm}
+            out['status']['matches_identical'] = {m: pm[m]['matches_identical'] for m in pm}
+            out['status']['parity_source'] = 'measured in this run: `parity`'
         if f64:
             args.no_breakdown = True        # (the fp64 classes are broken down in exact_mode; `roofline` is then that block's)
         if stub:
@@ -558,11 +614,25 @@ def main():
                                  'and layer over the whole batch) - the timed windows above run two half-batch lanes concurrently, '
                                  'see roofline_two_lanes')
             out['roofline'] = roof
+            sk = next((r for r in rows if r['kernel'] == 'sinkhorn'), None)
+            if sk is not None:
+                v = sk['vector_flops'] / (sk['ms'] * 1e-3) / 1e12
+                out['roofline_sinkhorn'] = {
+                    'kernel': 'sinkhorn', 'bound': 'vector', 'achieved': v, 'peak': PEAK_VECTOR_F32_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': v / PEAK_VECTOR_F32_TFLOPS, 'avg_launch_ms': sk['ms'], 'flops_per_launch': sk['vector_flops'],
+                    'fma_visits_per_s': sk['vector_flops'] / 2.0 / (sk['ms'] * 1e-3), 'step_ms': sk['step_ms'],
+                    'hbm': {'achieved': sk['bytes'] / (sk['ms'] * 1e-3) / 1e9, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                            'frac': sk['bytes'] / (sk['ms'] * 1e-3) / 1e9 / PEAK_HBM_GBS, 'bytes_per_launch': sk['bytes']},
+                    'note': '2 S (n+1)^2 FMA visits per pair (one FMA = 2 FLOP) on the vector pipe, coupling block register-resident '
+                            'for all S iterations, against the fp32 vector peak; hbm = the on-chip-resident algorithmic traffic '
+                            '2 (n+1)^2 4 B per pair (SURVEY 8d).  Bound by neither: 100 dependent iterations of reduction -> LDS -> '
+                            'barrier -> partner hand-off through L2 (profiles/NOTES_r5.md section 6)'}
             if n % 64 == 0 and att == 'fp32':
                 out['roofline_qk'] = qk_roofline(dev, B, n)
             out['kernels'] = [{'kernel': r['kernel'], 'launches_per_step': r['launches_per_step'], 'avg_ms': round(r['ms'], 4),
                                'step_ms': round(r['step_ms'], 3),
-                               'algorithmic_tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if 'flops' in r else None}
+                               'algorithmic_tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if 'flops' in r else None,
+                               **({'vector_tflops': round(r['vector_flops'] / (r['ms'] * 1e-3) / 1e12, 2)} if 'vector_flops' in r else {})}
                               for r in rows]
         if not stub and not args.no_exact_mode and att == 'fp32':
             try:
@@ -572,6 +642,9 @@ def main():
                 out['exact_mode'] = {'error': str(e)}
             if f64 and 'roofline' in out['exact_mode']:
                 out['roofline'] = out['exact_mode']['roofline']
+            if 'modes' in out.get('parity', {}) and 'error' not in out['exact_mode']:
+                out['exact_mode']['parity'] = {**out['parity']['modes']['fp64'], 'fixture': out['parity']['fixture'],
+                                               'source': 'measured in this run (`parity`)'}
         if not stub:
             # the legs behind the timed windows (dict API, latency, breakdown) ran more forwards: their status as well
             try:

@@ -86,22 +86,13 @@ typedef struct {
     int32_t extract_mode;              /* mdgat_extract_mode */
     float match_threshold;             /* config['match_threshold'] (322) */
     int32_t attention_mode;            /* mdgat_attention_mode; not a reference key (BASELINE configs[2]) */
-    int32_t exact_topk;                /* != 0: rows of a dynamic layer whose k-th and (k+1)-th largest logit are closer than the
-                                          fp32-class arithmetic of the attention kernels resolves (or exactly tied) are re-decided
-                                          from an fp64 evaluation of those logits (q / k re-projected from the layer's input with
-                                          the fp64 weights; csrc/repair.hip: one more small launch per dynamic layer), so that
-                                          `logits.topk(k)` (mdgat.py:202) selects what exact arithmetic selects on the same layer
-                                          input.  Not a reference key (the reference IS fp64); fp32 attention mode only;
-                                          MDGAT_TOPK_REPAIR=0 / 1 in the environment overrides it.  Default of the Python side: 0 -
-                                          it removes the flips a layer causes itself but not those that arrive with its input
-                                          (the accumulated fp32-class error of the layers before), which dominate: the number
-                                          of rows selected differently from the fp64 reference does not change
-                                          (profiles/parity_r4.txt), at 3-6 % of the step. */
     int32_t arithmetic;                /* mdgat_arithmetic; not a reference key (the reference IS fp64) */
-    int32_t f64_layers;                /* MDGAT_ARITH_FP64: how many leading propagation layers run in fp64; < 0 (default):
-                                          up to and including the last layer with topk > 0 (0 layers when there is none: the
-                                          encoders only); 2L: all of them */
+    int32_t f64_layers;                /* MDGAT_ARITH_FP64: how many leading propagation layers run in fp64.  0 (what a
+                                          zero-initialised config holds): automatic - up to and including the last layer with
+                                          topk > 0 (the encoders only when no layer has one); n > 0: exactly n (2L: all of them);
+                                          MDGAT_F64_ENCODERS_ONLY (-1): none, the encoders only */
 } mdgat_config;
+#define MDGAT_F64_ENCODERS_ONLY (-1)
 
 typedef struct mdgat_handle mdgat_handle;
 
@@ -116,9 +107,6 @@ typedef struct {
                            bit j of word w = key 32 w + j of the query's source frame; slices of full-attention layers are
                            left untouched.  Parity tests feed this selection to the oracle to separate near-tie flips of
                            the discontinuous top-k from arithmetic error. */
-    int32_t* repair_stats; /* [2L][4], zeroed by the caller: per dynamic layer the near-threshold rows examined by the exact
-                              re-decision (mdgat_config.exact_topk), corrected (exact arithmetic keeps other keys than the
-                              attention kernel did), unused, and given up (more than 16 candidates: masses of equal logits) */
 } mdgat_taps;
 size_t mdgat_topk_sel_words(int B, int N, int M);
 
@@ -130,8 +118,7 @@ int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out);
 
 /* net.load_state_dict(...) (test.py:159) after host-side packing (BN folded into the convs, heads
  * de-interleaved, merge folded into mlp.0; mdgat_matcher_amd/pack.py).  Every weight is the fp32
- * rounding of the folded fp64 value; the q and k projection rows also carry their fp32 RESIDUAL
- * (fp64 weight - fp32 weight), which the exact top-k re-decision uses.  `blob` holds
+ * rounding of the folded fp64 value.  `blob` holds
  * mdgat_blob_floats(L) fp32 values; `on_device` != 0 when it is device memory (e.g. received by
  * an RCCL broadcast), else host memory. */
 int mdgat_load_weights(mdgat_handle* h, const float* blob, size_t n_floats, int on_device);
@@ -191,17 +178,13 @@ int mdgat_forward_frames(mdgat_handle* h, int B, int N, int M, const float* fram
 /* Asynchronous status of the handle's forwards since the last call with clear != 0 (read it after synchronising the
  * stream: the forward itself never synchronises).  *range_violation != 0: an activation left the f16 operand range
  * (|v| >= 6e4) or a non-finite value reached a kernel - every operand is carried as f16 head + f16 residual (DESIGN.md
- * section 3), so the outputs of those calls are invalid; the function then returns MDGAT_ERR_UNSUPPORTED (and the next
+ * section 3), so the outputs of those calls are invalid.  The fp64 layers of MDGAT_ARITH_FP64 raise it as well: every fp64
+ * product tests its outputs by their exponent bits (not finite, or |v| >= 2^500 - beyond which a logit could overflow and the
+ * softmax meet inf - inf; csrc/f64.hip: f64_out_of_range), between the layers, not only at the hand-over; the function then returns MDGAT_ERR_UNSUPPORTED (and the next
  * mdgat_forward on the handle does, if nobody asked before).  *sinkhorn_fallback != 0: informational - a Sinkhorn cluster
  * launch lost a partner workgroup (device shared with other work) and was redone by the streaming kernel inside the same
  * call; the results are valid.  The reference has no counterpart (ATen raises nothing either: it returns inf / NaN). */
 int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn_fallback, unsigned* range_violation);
-
-/* mdgat_config.exact_topk only, after the caller's synchronisation: *given_up = near-threshold rows the exact re-decision left
- * as the attention kernel wrote them since the last call with clear != 0 - rows with more than 16 logits inside the window
- * around their threshold (masses of equal logits, e.g. duplicated keypoints: such a row keeps EVERY logit >= its threshold,
- * possibly more than k, where torch.topk keeps exactly k) and rows that did not fit the list.  Informational. */
-int mdgat_topk_repair_status(mdgat_handle* h, int clear, unsigned* given_up);
 
 /* After the caller's synchronisation: *matched = 1 when the forward that carried `token` matched at least one frame-0 keypoint
  * anywhere in its batch (matches0 >= 0), else 0.  This is the reference's host-side test `valid0.sum() == 0`

@@ -4,7 +4,10 @@
 ``MDGAT`` is ``mdgat_matcher_amd.MDGAT``: same constructor config, parameter names, ``forward(dict) -> dict``.  The free
 functions of ``/root/reference/models/mdgat.py`` that have a kernel behind them are exported under their reference
 names and signatures (channel-major ``[B, dh, H, N]`` tensors in and out, like ``mdgat.py:190-210``); they run on the
-gfx950 library through ``mdgat_matcher_amd.ops`` - there is no CPU path here either.
+gfx950 library through ``mdgat_matcher_amd.ops`` - there is no CPU path here either.  As in ``MDGAT`` itself the dtype of
+the tensors is the arithmetic request: float64 q / k / v (what the reference's ``net.double()`` produces) run the fp64
+kernels of ``csrc/f64.hip`` - ``dynamic_attention`` then keeps exactly the keys ``torch.topk`` keeps on the fp64 logits -
+float32 tensors the fp32-class kernels.
 """
 from __future__ import annotations
 
@@ -30,7 +33,7 @@ def _to_lib(q, k, v, min_rows=0):
     B, dh, H, N = q.shape
     M = k.shape[3]
     Np = max(N, min_rows)
-    qkv = torch.zeros(B, Np + M, 3, H, dh, dtype=torch.float32, device=q.device)
+    qkv = torch.zeros(B, Np + M, 3, H, dh, dtype=torch.float64 if q.dtype == torch.float64 else torch.float32, device=q.device)
     qkv[:, :N, 0] = q.permute(0, 3, 2, 1)
     qkv[:, Np:, 1] = k.permute(0, 3, 2, 1)
     qkv[:, Np:, 2] = v.permute(0, 3, 2, 1)
@@ -46,7 +49,8 @@ def attention(query, key, value):
     """mdgat.py:190-194.  Returns ``(message [B, dh, H, N], None)``: the probability tensor the reference returns second
     is write-only there (``self.prob.append``, mdgat.py:236) and is never materialised here."""
     qkv, Np, M = _to_lib(query, key, value)
-    return _from_lib(_ops.attention(qkv, Np, M, cross=True, topk=0), query.shape[3], query), None
+    op = _ops.attention_f64 if qkv.dtype == torch.float64 else _ops.attention
+    return _from_lib(op(qkv, Np, M, cross=True, topk=0), query.shape[3], query), None
 
 
 def dynamic_attention(query, key, value, k):
@@ -55,7 +59,8 @@ def dynamic_attention(query, key, value, k):
     if int(k) > key.shape[3]:
         raise RuntimeError(f'selected index k out of range: k={int(k)} exceeds the number of keys {key.shape[3]}')
     qkv, Np, M = _to_lib(query, key, value, min_rows=int(k))
-    return _from_lib(_ops.attention(qkv, Np, M, cross=True, topk=int(k)), query.shape[3], query), None
+    op = _ops.attention_f64 if qkv.dtype == torch.float64 else _ops.attention
+    return _from_lib(op(qkv, Np, M, cross=True, topk=int(k)), query.shape[3], query), None
 
 
 def log_optimal_transport(scores, alpha, iters: int):

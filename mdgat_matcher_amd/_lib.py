@@ -22,6 +22,7 @@ PROF_CLASSES = ('encoder', 'layer', 'attention_full', 'attention_topk', 'scores'
 
 ARITH_FP32 = 0
 ARITH_FP64 = 1
+F64_ENCODERS_ONLY = -1
 
 OK = 0
 ERR_BAD_ARG = -1
@@ -38,7 +39,6 @@ class MdgatConfig(C.Structure):
         ('extract_mode', C.c_int32),
         ('match_threshold', C.c_float),
         ('attention_mode', C.c_int32),
-        ('exact_topk', C.c_int32),
         ('arithmetic', C.c_int32),
         ('f64_layers', C.c_int32),
     ]
@@ -46,10 +46,10 @@ class MdgatConfig(C.Structure):
 
 class MdgatTaps(C.Structure):
     _fields_ = [('x_enc', C.c_void_p), ('x_layers', C.c_void_p), ('mdesc', C.c_void_p), ('scores', C.c_void_p),
-                ('topk_sel', C.c_void_p), ('repair_stats', C.c_void_p)]
+                ('topk_sel', C.c_void_p)]
 
 
-TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel', 'repair_stats')
+TAP_NAMES = ('x_enc', 'x_layers', 'mdesc', 'scores', 'topk_sel')
 
 
 # name -> (restype, argtypes); every symbol include/mdgat_hip.h declares
@@ -70,7 +70,6 @@ SIGNATURES = {
     'mdgat_forward_frames': (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
                              [C.c_void_p, C.POINTER(MdgatTaps), C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_async_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
-    'mdgat_topk_repair_status': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_uint)]),
     'mdgat_last_token': (C.c_uint, [C.c_void_p]),
     'mdgat_matched_any': (C.c_int, [C.c_void_p, C.c_uint, C.POINTER(C.c_uint)]),
     'mdgat_profile': (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

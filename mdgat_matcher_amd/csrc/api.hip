@@ -44,7 +44,6 @@ BlobLayout mdgat_blob_layout(int L) {
     b.qkv_w = ltake(384 * 128);  b.qkv_b = ltake(384);
     b.mlp1_w = ltake(256 * 256); b.mlp1_b = ltake(256);
     b.mlp2_w = ltake(128 * 256); b.mlp2_b = ltake(128);
-    b.qk_lo_w = ltake(256 * 128); b.qk_lo_b = ltake(256);
     b.layer_stride = lo;
     o += lo * (size_t)(2 * L);
     b.final_w = take(128 * 128); b.final_b = take(128);
@@ -64,7 +63,6 @@ struct mdgat_handle {
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     double* weights64;   // device, the blob in fp64 (MDGAT_ARITH_FP64: f64.hip), else nullptr
     bool loaded, loaded64;
-    bool repair;         // exact re-decision of near-threshold top-k rows (repair.hip): cfg.exact_topk (or MDGAT_TOPK_REPAIR in the environment), fp32 attention mode
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard,
                           // token of the last forward that matched a frame-0 keypoint
     unsigned match_token; // the running forward's token (a new one per mdgat_forward / mdgat_forward_frames call, never 0)
@@ -123,10 +121,6 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights64 = nullptr;
     h->loaded = false;
     h->loaded64 = false;
-    {
-        const char* e = getenv("MDGAT_TOPK_REPAIR");      // (measurements: 0 / 1 override the configuration)
-        h->repair = (e ? atoi(e) != 0 : cfg->exact_topk != 0) && cfg->attention_mode == MDGAT_ATTENTION_FP32;
-    }
     h->host_error = nullptr;
     h->match_token = 0;
     h->prof_on = false;
@@ -274,14 +268,9 @@ struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
     double *x64, *qkv64, *hid64, *msg64;   // MDGAT_ARITH_FP64 only: the residual stream, q|k|v, hidden layer and message of the fp64 layers
     _Float16* qkv16;
-    int* near_count;        // [MDGAT_MAX_LAYERS] near-threshold rows listed by each dynamic layer (zeroed at the start of a forward)
-    RepairRec* near_recs;   // [near_cap] the list itself, reused layer after layer (a layer's repair runs before the next layer lists)
-    int near_cap;
     size_t sk_bytes;
     size_t total;   // floats
 };
-// capacity of the near-threshold list: ~1-2 rows in 10^3 are listed; 1/16 of all (pair, head, query) rows is never reached
-int near_capacity(size_t R) { const size_t c = R * 4 / 16; return (int)(c < 1024 ? 1024 : c > (1u << 20) ? (1u << 20) : c); }
 Workspace carve(float* base, int B, int N, int M, bool f64) {
     const size_t R = (size_t)B * (N + M);
     Workspace w{};
@@ -296,9 +285,6 @@ Workspace carve(float* base, int B, int N, int M, bool f64) {
     w.sk_bytes = mdgat_sinkhorn_ws_bytes_impl(B, N, M);
     w.sk = take((w.sk_bytes + 3) / 4);
     w.qkv16 = reinterpret_cast<_Float16*>(take((mdgat_qkv16_halves(B, N, M) + 1) / 2));
-    w.near_count = reinterpret_cast<int*>(take(MDGAT_MAX_LAYERS));
-    w.near_cap = near_capacity(R);
-    w.near_recs = reinterpret_cast<RepairRec*>(take((size_t)w.near_cap * (sizeof(RepairRec) / sizeof(float))));
     if (f64) {
         w.x64 = reinterpret_cast<double*>(take(R * 128 * 2));
         w.qkv64 = reinterpret_cast<double*>(take(R * 384 * 2));     // qkv64 and hid64 are contiguous: the encoder stages live there
@@ -339,7 +325,8 @@ struct FwdIn {
 
 // MDGAT_ARITH_FP64: the number of leading propagation layers that run in fp64 (mdgat_config.f64_layers)
 static int f64_layer_count(const mdgat_config& cfg) {
-    if (cfg.f64_layers >= 0) return cfg.f64_layers;
+    if (cfg.f64_layers > 0) return cfg.f64_layers;
+    if (cfg.f64_layers < 0) return 0;       // MDGAT_F64_ENCODERS_ONLY
     int n = 0;
     for (int i = 0; i < 2 * cfg.L; ++i)
         if (cfg.topk[i] > 0) n = i + 1;
@@ -370,8 +357,8 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         // the forward is asynchronous: what an earlier launch found surfaces here unless the caller asked first
         // (mdgat_async_status after its own synchronisation - MDGAT.forward does)
         h->host_error[MDGAT_STATUS_RANGE] = 0;
-        mdgat_set_error("mdgat_forward: a previous call on this handle met activations outside the f16 operand range (|v| >= 6e4) or "
-                        "non-finite values; its outputs are invalid");
+        mdgat_set_error("mdgat_forward: a previous call on this handle met activations outside the f16 operand range (|v| >= 6e4; fp64 "
+                        "layers of the exact mode: |v| >= 2^500) or non-finite values; its outputs are invalid");
         return MDGAT_ERR_UNSUPPORTED;
     }
     if (B <= 0 || N <= 0 || M <= 0) { mdgat_set_error("mdgat_forward: empty batch/keypoints (B=%d N=%d M=%d) must be handled by the caller", B, N, M); return MDGAT_ERR_BAD_ARG; }
@@ -417,12 +404,6 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
     };
     mark(-1);
 
-    // near-threshold lists of the dynamic layers (repair.hip): one counter per layer, cleared once per forward
-    bool repair = false;
-    for (int i = 0; i < L2; ++i) repair |= h->repair && h->cfg.topk[i] > 0 && !(h->cfg.topk[i] == N && h->cfg.topk[i] == M);
-    if (repair)
-        if ((rc = mdgat_check_hip(hipMemsetAsync(ws.near_count, 0, MDGAT_MAX_LAYERS * sizeof(int), s), "memset(near-threshold counters)"))) return rc;
-
     const Qkv16 q16 = mdgat_qkv16_carve(ws.qkv16, B, N, M);
     if ((N & 31) || (M & 31))   // the attention kernel reads V^T in whole 32-key blocks: pad columns must be zero
         if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
@@ -444,7 +425,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         const size_t Rz = (size_t)R;
         auto gemm = [&](const double* A0, int lda0, int K0, const double* A1, int lda1, size_t wofs, size_t bofs, int relu, const double* Rs, double* C, int ldc,
                         int cout, int K) {
-            GemmF64Args g{A0, lda0, K0, A1, lda1, w64 + wofs, K, w64 + bofs, Rs, ldc, C, ldc, R, cout, K, relu};
+            GemmF64Args g{A0, lda0, K0, A1, lda1, w64 + wofs, K, w64 + bofs, Rs, ldc, C, ldc, R, cout, K, relu, status_dev + MDGAT_STATUS_RANGE};
             return launch_gemm_f64(g, s);
         };
         // encoder stages in the (contiguous) q|k|v + hidden area: 4 + 33 + 32 + 64 + 128 + 64 + 128 = 453 of 640 doubles per point
@@ -476,7 +457,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
             if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, lo + bl.qkv_w, lo + bl.qkv_b, 0, nullptr, ws.qkv64, 384, 384, 128))) return rc;
             mark(MDGAT_PROF_F64_GEMM);
             uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
-            if ((rc = launch_attention_f64(B, N, M, i & 1, h->cfg.topk[i], ws.qkv64, ws.msg64, sel, s))) return rc;
+            if ((rc = launch_attention_f64(B, N, M, i & 1, h->cfg.topk[i], ws.qkv64, ws.msg64, sel, s, status_dev + MDGAT_STATUS_RANGE))) return rc;
             mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_F64_ATTENTION_TOPK : MDGAT_PROF_F64_ATTENTION_FULL);
             // AttentionalPropagation + residual (mdgat.py:246-248, 274)
             if ((rc = gemm(ws.x64, 128, 128, ws.msg64, 128, lo + bl.mlp1_w, lo + bl.mlp1_b, 1, nullptr, ws.hid64, 256, 256, 256))) return rc;
@@ -510,15 +491,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         const int cross = i & 1;   // names = ['self', 'cross'] * L (mdgat.py:352-353)
         uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
         const int kk = h->cfg.topk[i];
-        const bool fix = repair && kk > 0 && !(kk == N && kk == M);
-        const NearList nl{ws.near_count + i, ws.near_recs, ws.near_cap};
-        if ((rc = launch_attention(B, N, M, cross, kk, q16, ws.msg, s, h->cfg.attention_mode, sel, fix ? &nl : nullptr))) return rc;
-        if (fix) {
-            // ws.x still holds this layer's input (the descriptors q / k / v were projected from)
-            RepairLaunch rp{q16, ws.msg, ws.x, lw + bl.qkv_w, lw + bl.qk_lo_w, lw + bl.qkv_b, lw + bl.qk_lo_b, B, N, M, cross, kk, nl, sel,
-                            (taps && taps->repair_stats) ? taps->repair_stats + 4 * i : nullptr, status_dev + MDGAT_STATUS_REPAIR_GIVEUP};
-            if ((rc = launch_topk_repair(rp, s))) return rc;
-        }
+        if ((rc = launch_attention(B, N, M, cross, kk, q16, ws.msg, s, h->cfg.attention_mode, sel))) return rc;
         mark(kk > 0 ? MDGAT_PROF_ATTENTION_TOPK : MDGAT_PROF_ATTENTION_FULL);
         LayerLaunch p{};
         p.x = ws.x; p.msg = ws.msg; p.R = R; p.N = N; p.M = M; p.out = q16; p.mdesc = mdesc; p.do_mlp = 1; p.guard = status_dev + MDGAT_STATUS_RANGE;
@@ -724,18 +697,11 @@ extern "C" int mdgat_async_status(mdgat_handle* h, int clear, unsigned* sinkhorn
     if (range_violation) *range_violation = rg;
     if (clear) { st[MDGAT_STATUS_SK_FALLBACK] = 0; st[MDGAT_STATUS_RANGE] = 0; }
     if (rg) {
-        mdgat_set_error("activations outside the f16 operand range (|v| >= 6e4) or non-finite values reached a kernel: the outputs of "
-                        "the calls since the last check are invalid (this checkpoint / input does not fit the split-f16 arithmetic)");
+        mdgat_set_error("activations outside the f16 operand range (|v| >= 6e4; fp64 layers of the exact mode: |v| >= 2^500) or non-finite "
+                        "values reached a kernel: the outputs of the calls since the last check are invalid (this checkpoint / input does "
+                        "not fit the arithmetic)");
         return MDGAT_ERR_UNSUPPORTED;
     }
-    return MDGAT_OK;
-}
-
-extern "C" int mdgat_topk_repair_status(mdgat_handle* h, int clear, unsigned* given_up) {
-    if (!h || !given_up) { mdgat_set_error("mdgat_topk_repair_status: null argument"); return MDGAT_ERR_BAD_ARG; }
-    volatile unsigned* st = h->host_error;
-    *given_up = st[MDGAT_STATUS_REPAIR_GIVEUP];
-    if (clear) st[MDGAT_STATUS_REPAIR_GIVEUP] = 0;
     return MDGAT_OK;
 }
 
@@ -864,7 +830,7 @@ extern "C" int mdgat_gt_matches(int B, int N, int M, const float* kpts0, const f
 extern "C" int mdgat_pointwise_f64(int M, int N, int K, const double* A, int lda, const double* W, int ldw, const double* bias,
                                    int relu, const double* R, int ldr, double* C, int ldc, void* stream) {
     if (!A || !W || !C) { mdgat_set_error("mdgat_pointwise_f64: null pointer"); return MDGAT_ERR_BAD_ARG; }
-    const GemmF64Args g{A, lda, K, nullptr, 0, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu};
+    const GemmF64Args g{A, lda, K, nullptr, 0, W, ldw, bias, R, ldr, C, ldc, M, N, K, relu, nullptr};
     return launch_gemm_f64(g, static_cast<hipStream_t>(stream));
 }
 

@@ -48,23 +48,11 @@ struct AttnArgs {
     float zq;              // standard-normal quantile of the top-k fraction (first probe of the threshold search)
     uint32_t* sel;         // TAP kernels only: [B][4][P][selW] bit j of word w = key 32 w + j of the source frame was kept
     int selW;
-    // near-threshold rows of a dynamic layer (repair.hip): a row whose (k + 1)-th largest logit lies within near_eps() of its
-    // threshold (or is tied with the k-th) is appended here and re-decided by topk_repair_kernel from an fp64 evaluation of
-    // the candidates; exact ties at the k-th place are then left to it
-    int* near_count;       // NULL: no list
-    RepairRec* near_recs;
-    int near_cap;
     // XCD-aware 1-D grids (attention_topk16_kernel, attention_topk_wide_kernel): workgroup blockIdx.x = (ugroup * grid_split + part) * 8 + xcd
     // works on part `part` of the query tiles of unit ugroup * 8 + xcd, unit = (pair * 2 + frame) * 4 + head: the parts of a unit share
     // an XCD (round-robin dispatch), so its K and V^T are fetched into one L2 only.  The grid is padded to 8 units.
     int grid_split, grid_units;
 };
-
-// append a near-threshold row (one lane per row calls this; rare: ~1 row in 10^3)
-__device__ __forceinline__ void near_append(const AttnArgs& a, int b, int side, int head, int q, float thr, float m) {
-    const int i = atomicAdd(a.near_count, 1);
-    if (i < a.near_cap) a.near_recs[i] = RepairRec{(b * 2 + side) * 4 + head, q, thr, m};
-}
 
 // parity tap (mdgat_taps.topk_sel): OR `bits` (NB consecutive keys starting at key0, NB | 32) into the row's mask
 __device__ __forceinline__ void tap_keys(uint32_t* row, int key0, unsigned bits) {
@@ -120,8 +108,6 @@ __device__ __forceinline__ float ge_const(float t) {
     const float tp = __builtin_bit_cast(float, bp);
     return t == -__builtin_inff() ? 3.0e38f : -tp * MDGAT_GE_BIG;
 }
-// the near threshold of a row (base-2 logit units; m = row maximum): what the fp32-class logits cannot resolve below thr
-__device__ __forceinline__ float near_thr(float thr, float m) { return thr - mdgat_near_eps(thr, m); }
 __device__ __forceinline__ f32x2 ge_ind(f32x2 s, float c) {
     f32x2 d;
     const f32x2 c2 = {c, c};
@@ -213,7 +199,7 @@ struct QuadComm {
 // logits (fp32 logits closer than one ulp, duplicated keypoints); the kernels count what the softmax pass keeps and
 // call topk_break_ties() for such rows, so that every row keeps exactly k keys like torch.topk.
 template <int NBLK, bool EXACT, typename Comm>
-__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm, bool want_near, bool& near) {
+__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
     const float INF = __builtin_inff();
     // the packed indicator form needs the logits in vector registers proper: not the 256-logit instance (half of its
     // row lives in accumulation registers) and not the split-key kernel (no register to spare)
@@ -394,15 +380,6 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         if (state == 3) thr = (c2 >= k) ? e2 : e1;
     }
     thr = canon_thr(thr);           // (what every later comparison uses)
-    // near-threshold rows (repair.hip): more than k logits at or above thr - near_eps means that the (k + 1)-th largest
-    // logit is closer to the threshold than the fp32-class logits resolve (or tied with the k-th).  One more counting
-    // pass per tile (want_near is uniform over the launch; MDGAT_NEAR_OFF compiles it out for A/B measurements).
-#ifndef MDGAT_NEAR_OFF
-    if (want_near) {
-        const int c = count_ge(near_thr(thr, m));      // (-inf pads never count: a finite near threshold, or nk <= k below)
-        near = nk > k && c > k;
-    }
-#endif
     return thr;
 }
 
@@ -554,8 +531,6 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
         bool redo = false;                                      // dynamic layers: exact ties at the k-th place
         int surplus = 0;
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
-        bool near_row = false;                                  // dynamic layers: a dropped logit within near_eps of the threshold
-        float thr_row = NEG_INF, m_row = NEG_INF;
 
         for (int wb0 = 0; wb0 < nblk; wb0 += wcap) {            // LDS windows (one unless LARGE)
             const int wnb = min(wcap, nblk - wb0);
@@ -612,9 +587,8 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                 float thr = NEG_INF;
                 if (TOPK) {
                     WaveComm comm;
-                    thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
-                    thr_row = thr; m_row = m;
-                    if (TAP && !a.near_count) {      // the TAP build counts first, so that the selection it records is final
+                    thr = topk_threshold<NBLK, EXACT>(S, m, a.topk, nk, a.zq, comm);
+                    if (TAP) {      // the TAP build counts first, so that the selection it records is final
                         int c = 0;
 #pragma unroll
                         for (int jb = 0; jb < NBLK; ++jb)
@@ -622,9 +596,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                             for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
                         surplus = comm.rsum(c) - kexp;
                     }
-                    // (with the near-threshold list on, exact ties at the k-th place are left to the re-decision of repair.hip:
-                    // the written row keeps every logit >= thr)
-                    if ((redo || TAP) && !a.near_count) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, c0 * 32 + 8 * hi);
+                    if (redo || TAP) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, c0 * 32 + 8 * hi);
                 }
                 if (TOPK && TAP && qw + l31 < nq) {
                     uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
@@ -689,7 +661,7 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
                     // a row kept more than k logits (exact ties at the k-th place): redo the chunk - the whole row -
                     // once, with the tie-break (topk_break_ties)
                     { const int kc = kept_count(kept); surplus = kc + xor32i(kc) - kexp; }
-                    if (!redo && !a.near_count && __any(surplus > 0)) {
+                    if (!redo && __any(surplus > 0)) {
                         redo = true;
                         c0 -= NBLK;
                         m_run = NEG_INF;
@@ -703,7 +675,6 @@ __global__ __launch_bounds__(NBLK <= 8 ? 512 : 256, NBLK <= 8 ? 2 : 1) void atte
         float l = l2[0] + l2[1];
         l += xor32(l);
         const float inv_l = 1.0f / l;
-        if (TOPK && a.near_count && near_row && hi == 0 && qw + l31 < nq) near_append(a, b, side, head, qw + l31, thr_row, m_row);
 
         // ---- message rows: lane holds column (dim) l31 of queries mfma32_row(r, hi) ----
         float* out = a.msg + ((size_t)b * P + q_off) * 128 + head * 32 + l31;
@@ -849,13 +820,10 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[c][r]);
         m = comm.rmax(m);
-        bool near_row = false;
-        const float thr = topk_threshold<NC, true>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
-        if (near_row && g == 0 && qw + l15 < nq) near_append(a, b, side, head, qw + l15, thr, m);      // -> repair list (rare)
+        const float thr = topk_threshold<NC, true>(S, m, a.topk, nk, a.zq, comm);
         if (TAP) {
             // the selection the tap records is final: count and break exact ties at the k-th place before the pass
-            // (left to the re-decision of repair.hip when the near-threshold list is on)
-            if (!a.near_count) {
+            {
                 int c = 0;
 #pragma unroll
                 for (int jb = 0; jb < NC; ++jb)
@@ -949,7 +917,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk16_kernel(AttnArgs a) {
         // with the largest key indices are found one at a time and the share of each is taken out of the rows just
         // written:  o <- (o l - P' v) / (l - P'),  l <- l - P'.  (A second pass instead costs the launch 10 % at B = 64.)
         const int surplus = comm.rsum(kept_count(kept)) - a.topk;
-        if (!a.near_count && comm.any(surplus > 0)) {
+        if (comm.any(surplus > 0)) {
             load_q(qw, qh, ql);             // (the fragment registers may have been handed to the prefetch)
             logits(S);
             const float e = __builtin_amdgcn_exp2f(thr - m11);                  // P' of a tied logit, as softmax8 computes it
@@ -1125,9 +1093,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
         m = comm.rmax(m);
         WT(2);
-        bool near_row = false;
-        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm, a.near_count != nullptr, near_row);
-        if (near_row && kw == 0 && hi == 0 && qw + l31 < nq) near_append(a, b, side, head, qw + l31, thr, m);      // -> repair list (rare)
+        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
         WT(3);
         {
             // exact ties at the k-th place (topk_break_ties): this kernel counts what the threshold keeps BEFORE its pass
@@ -1138,7 +1104,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) c += S[jb][r] >= thr;
             const int surplus = comm.rsum(c) - kexp;
-            if (!a.near_count) topk_break_ties<KeyLayout32>(S, thr, surplus, comm, kw * NBLK * 32 + 8 * hi);    // (else: repair.hip)
+            topk_break_ties<KeyLayout32>(S, thr, surplus, comm, kw * NBLK * 32 + 8 * hi);
         }
         if (TAP && qw + l31 < nq) {
             uint32_t* row = a.sel + (((size_t)b * 4 + head) * P + q_off + qw + l31) * a.selW;
@@ -1329,7 +1295,7 @@ extern "C" size_t mdgat_topk_sel_words(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
     return (size_t)B * 4 * (N + M) * (((N > M ? N : M) + 31) / 32); }
 
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode, uint32_t* sel, const NearList* near) {
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode, uint32_t* sel) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M;
     if (topk > 0) {
@@ -1340,8 +1306,7 @@ int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv,
             return MDGAT_ERR_BAD_ARG;
         }
     }
-    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f, nullptr, (nk_max + 31) / 32, nullptr, nullptr, 0};
-    if (near && near->count && topk > 0 && mode == 0) { a.near_count = near->count; a.near_recs = near->recs; a.near_cap = near->cap; }
+    AttnArgs a{qkv.q16, qkv.k16, qkv.vt16, msg, N, M, qkv.Npad, qkv.PP, cross, topk, 0.f, nullptr, (nk_max + 31) / 32};
     if (topk > 0) a.zq = normal_quantile_upper(((double)topk - 0.5) / (double)nk_max);
     const int nkp = ((nk_max + 31) / 32) * 32;
     const int wkeys = nkp > 512 ? 512 : nkp;      // keys the LDS window holds

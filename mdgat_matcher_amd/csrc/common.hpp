@@ -33,24 +33,10 @@ __device__ __forceinline__ void mdgat_split_unscaled(float x, _Float16& h, _Floa
 }
 #endif
 
-// ---- near-threshold rows of a dynamic layer (attention.hip -> repair.hip) ----------------------------------------------
-// dynamic_attention (mdgat.py:196-210) is discontinuous: a row whose k-th and (k+1)-th largest logit are closer than the
-// error of the fp32-class logits may keep the other key.  The dynamic-attention kernels append every row with a dropped
-// logit within mdgat_near_eps() below its threshold to a list; topk_repair_kernel re-decides those rows from an fp64
-// evaluation of the candidates (q / k re-projected from the fp32 descriptors with the fp64 weights) and rewrites the
-// row's message when a candidate straddles the threshold.
-struct RepairRec { int bsh; int q; float thr; float m; };   // ((pair * 2 + frame) * 4 + head), query row within its frame, threshold, row maximum
 // Key index (within the source frame) of logit register (jb, r) of a lane, relative to the lane's offset, in the S^T = K Q^T
-// fragments of the attention kernels (attention.hip) - repair.hip computes the same fragments again.
+// fragments of the attention kernels (attention.hip).
 struct KeyLayout32 { static __device__ constexpr int koff(int jb, int r) { return jb * 32 + 16 * (r >> 3) + (r & 7); } };       // 32x32 fragments, + 8 (lane >> 5)
 struct KeyLayout16 { static __device__ constexpr int koff(int jb, int r) { return 16 * (4 * jb + (r >> 2)) + (r & 3); } };      // 16x16 fragments, + 4 (lane >> 4)
-#ifdef __HIPCC__
-// base-2 logit units.  Error of a logit against exact arithmetic on the same layer input: rms 1.9e-6, max 1.4e-5 for
-// logits of standard deviation 2.8 (profiles/NOTES_r3.md), proportional to the logits' scale - (|m| + |thr|) / 10 is ~1 there.
-// What decides a flip is the DIFFERENCE of two logits, whose error can reach twice the per-logit maximum (2.8e-5): the window is
-// 4e-5 (round 5; it was 2e-5 - inside the measured worst case of a difference).  A few more rows are listed for it.
-__device__ __forceinline__ float mdgat_near_eps(float thr, float m) { return 4.0e-5f * fmaxf(1.0f, (fabsf(m) + fabsf(thr)) * 0.1f); }
-#endif
 
 // row of the 32x32 MFMA C/D fragment held in accumulator register r by a lane of half `hi`
 // (cdna_hip_programming.md section 3: row = (r&3) + 8*(r>>2) + 4*(lane>>5), col = lane&31).
@@ -84,7 +70,6 @@ struct BlobLayout {
     size_t qkv_w, qkv_b;       // [384][128] rows = which*128 + head*32 + dim, [384]
     size_t mlp1_w, mlp1_b;     // [256][256] cols = [x | head-major message (merge folded)], [256]
     size_t mlp2_w, mlp2_b;     // [128][256], [128]
-    size_t qk_lo_w, qk_lo_b;   // [256][128], [256]: fp32 residuals of the q and k rows of qkv_w / qkv_b (fp64 weight = head + residual; repair.hip)
     size_t final_w, final_b;   // [128][128], [128]
     size_t bin_score;          // [1] (+3 pad)
     size_t total;
@@ -140,22 +125,7 @@ Qkv16 mdgat_qkv16_carve(_Float16* base, int B, int N, int M);
 int launch_qkv_split(int B, int N, int M, const float* qkv, const Qkv16& out, hipStream_t s);
 // mode: mdgat_attention_mode (1 = single-f16 products where implemented)
 // sel (parity tap, may be NULL): the kept keys of a dynamic layer as bit masks [B][4][P][W], W = ceil(max(N, M) / 32)
-struct NearList { int* count; RepairRec* recs; int cap; };    // device memory; count: one int per launch, zeroed by the caller
-int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0, uint32_t* sel = nullptr,
-                     const NearList* near = nullptr);
-// repair.hip: re-decide the near-threshold rows of the dynamic layer that has just run (x = the layer's input descriptors
-// [B][P][128]; w / wlo = the layer's q|k|v weights [384][128] (fp32 heads of the fp64 weights) and the residuals of the q and k
-// rows [256][128]; b / blo likewise [384] / [256]); stats (optional) = 4 device counters: rows examined, rewritten, changed
-// against the fp32-class selection, given up
-struct RepairLaunch {
-    Qkv16 qkv; float* msg; const float* x;
-    const float *w, *wlo, *b, *blo;
-    int B, N, M, cross, topk;
-    NearList near;
-    uint32_t* sel; int* stats;
-    unsigned* giveup = nullptr;     // optional host-mapped word (MDGAT_STATUS_REPAIR_GIVEUP): rows left undecided are counted there
-};
-int launch_topk_repair(const RepairLaunch& p, hipStream_t s);
+int launch_attention(int B, int N, int M, int cross, int topk, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0, uint32_t* sel = nullptr);
 // full attention as a stream of 64-key chunks (attention_stream.hip); frames with key counts that are multiples of 64
 bool attention_stream_supported(int N, int M);
 int launch_attention_stream(int B, int N, int M, int cross, const Qkv16& qkv, float* msg, hipStream_t s, int mode = 0);
@@ -196,8 +166,6 @@ int launch_alldust_fixup(int B, int N, int M, int mode, const int64_t* m0, float
 // Asynchronous status words of a handle (host-mapped memory the kernels write; read by the host after a synchronisation).
 constexpr int MDGAT_STATUS_SK_FALLBACK = 0;   // the Sinkhorn cluster kernel lost a partner workgroup: the launch was redone by the streaming kernel
 constexpr int MDGAT_STATUS_RANGE = 1;         // an activation left the f16 operand range or is not finite: the outputs are invalid
-constexpr int MDGAT_STATUS_REPAIR_GIVEUP = 2; // exact_topk (repair.hip): near-threshold rows NOT re-decided - more than 16 candidates inside the window (masses of
-                                              // equal logits: such a row keeps every logit >= its threshold, possibly more than k) or dropped from a full list
 constexpr int MDGAT_STATUS_MATCHED = 4;       // first of MDGAT_MATCH_SLOTS words: slot (token % slots) receives the token of a forward whose extraction matched
                                               // at least one frame-0 keypoint (mdgat.py:465: the reference tests valid0.sum() on the host; mdgat_matched_any
                                               // reads the call's slot instead of a reduction + copy; a slot per call: concurrent callers of one handle)

@@ -39,6 +39,23 @@ namespace {
 
 __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
 
+// Range guard of the exact mode, BETWEEN the layers: every output of an fp64 product (q | k | v, the hidden layer before its ReLU,
+// the residual stream, the encoder stages) and every message row is tested for "not finite, or |v| >= 2^500" by its exponent field,
+// and the call is refused (MDGAT_STATUS_RANGE -> mdgat_async_status / MDGAT.check raise) instead of returning plausible numbers.
+// Why here: this file is compiled with -fno-honor-nans, and the reference's NaN propagation (mdgat.py:192-193: a NaN logit makes
+// the whole row NaN) is not what the hardware does with one - max(NaN, 0) is 0 in a ReLU, v_max_f64 drops a NaN logit from the row
+// maximum and exp_neg clamps it to exp(-745) = 0, so a NaN produced mid-stack (inf - inf in a product or in the online softmax)
+// could come out as a finite, wrong message.  With every q, k, v below 2^500 a logit is a sum of 32 products below 2^1000: finite; the
+// softmax statistics and P.V of finite logits and values are finite.  So the test on the GEMM outputs (before the ReLU, which
+// could swallow a NaN, and after the residual is added) is sufficient, and it sits in the epilogue: two integer instructions per
+// output element, none in the product loops.  (The asm hides the value's floating-point origin: a mask test the compiler can trace
+// back to a double is recognised as a class test and, under the flag, reduced to "is infinite" - a NaN would pass.)
+__device__ __forceinline__ bool f64_out_of_range(double v) {
+    unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
+    asm("" : "+v"(hi));
+    return (hi & 0x7ff00000u) >= 0x5f300000u;          // biased exponent >= 1523: |v| >= 2^500, inf, NaN
+}
+
 // ================================================================================================ GEMM
 constexpr int G_BM = 64, G_KC = 32;      // row pitch KC + 2 doubles (34: 68 dwords; 66: 132): the 64 lanes of a fragment read (row l15, k g) hit 64 banks
 
@@ -143,6 +160,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
         }
     }
     // D: lane (column l15, g), register i -> row g + 4 i of the 16 x 16 block
+    bool bad = false;
 #pragma unroll
     for (int nb = 0; nb < WN; ++nb) {
         const int n = col0 + wn * 16 * WN + nb * 16 + l15;
@@ -155,11 +173,13 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
                 const int row = row0 + wm * 32 + mb * 16 + g + 4 * i;
                 if (row >= a.M) continue;
                 double v = acc[mb][nb][i] + bias;
+                bad |= f64_out_of_range(v);
                 if (a.relu) v = v > 0.0 ? v : 0.0;
-                if (a.R) v += a.R[(size_t)row * a.ldr + n];
+                if (a.R) { v += a.R[(size_t)row * a.ldr + n]; bad |= f64_out_of_range(v); }
                 a.C[(size_t)row * a.ldc + n] = v;
             }
     }
+    if (bad && a.guard) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ================================================================================================ attention
@@ -560,7 +580,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             }
         }
         const double inv = 1.0 / l;
-        *reinterpret_cast<f64x2*>(a.msg + ((size_t)b * P + q_off + q0 + q) * 128 + head * 32 + d) = f64x2{o0 * inv, o1 * inv};
+        o0 *= inv; o1 *= inv;
+        if (a.guard && (f64_out_of_range(o0) || f64_out_of_range(o1))) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *reinterpret_cast<f64x2*>(a.msg + ((size_t)b * P + q_off + q0 + q) * 128 + head * 32 + d) = f64x2{o0, o1};
     }
 }
 
@@ -764,7 +786,7 @@ static float f64_normal_quantile_upper(double p) {
     return (float)(upper ? x : -x);
 }
 
-int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s) {
+int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s, unsigned* guard) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M, nk_min = N < M ? N : M;
     if (topk > nk_min) {   // torch.topk raises (mdgat.py:202)
@@ -782,14 +804,20 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
     a.selW = (nk_max + 31) / 32;
     a.sel = nullptr;
     a.units = B * 2 * MDGAT_HEADS;
+    a.guard = guard;
     if (sel && topk > 0) {
         if (int rc = mdgat_check_hip(hipMemsetAsync(sel, dyn ? 0 : 0xff, mdgat_topk_sel_words(B, N, M) * sizeof(uint32_t), s), "memset(top-k tap)")) return rc;
         if (dyn) a.sel = sel;
     }
     const int ugroups = (a.units + 7) / 8;
-    auto go = [&](auto kern, int QT, bool tk) -> int {
+    // (the LDS opt-in once per instantiation and device, at the largest size the instantiation is ever launched with: a limit that
+    // followed each launch's key count raced between host threads with different keypoint counts, and cost a driver call per launch.
+    // `cap` = that largest key count; the tag gives every call site its own instantiation of this lambda, hence its own `done` mask.)
+    auto go = [&](auto kern, int QT, bool tk, int cap, auto tag) -> int {
+        (void)tag;
+        static std::atomic<unsigned long long> done{0};
         const size_t lds = attn_lds_bytes(QT, nk_max, tk);
-        if (int rc = mdgat_check_hip(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds), "attention_f64 LDS")) return rc;
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), attn_lds_bytes(QT, cap, tk), done, "attention_f64 LDS")) return rc;
         a.tiles = (nk_max + QT - 1) / QT;
         hipLaunchKernelGGL(kern, dim3(8 * a.tiles * ugroups), dim3(256), lds, s, a);
         return mdgat_check_hip(hipGetLastError(), "attention_f64 launch");
@@ -802,11 +830,13 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         // waves per SIMD - lose: 236 -> 289 us at batch 32)
         static const int qb_env = [] { const char* e = getenv("MDGAT_F64_ATT_QB"); return e ? atoi(e) : 0; }();
         const bool small = 8L * ((nk_max + 31) / 32) * ugroups < 2L * f64_cu_count();
-        if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false);
-        return go(attention_f64_kernel<false, 2, false>, 32, false);
+        if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false, 0, std::integral_constant<int, 0>());
+        return go(attention_f64_kernel<false, 2, false>, 32, false, 0, std::integral_constant<int, 1>());
     }
-    if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 1, true, true>, 16, true) : go(attention_f64_kernel<true, 1, false, true>, 16, true);
-    return a.sel ? go(attention_f64_kernel<true, 1, true>, 16, true) : go(attention_f64_kernel<true, 1, false>, 16, true);
+    if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 1, true, true>, 16, true, 512, std::integral_constant<int, 2>())
+                                    : go(attention_f64_kernel<true, 1, false, true>, 16, true, 512, std::integral_constant<int, 3>());
+    return a.sel ? go(attention_f64_kernel<true, 1, true>, 16, true, 2048, std::integral_constant<int, 4>())
+                 : go(attention_f64_kernel<true, 1, false>, 16, true, 2048, std::integral_constant<int, 5>());
 }
 
 int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,

@@ -15,6 +15,8 @@ struct GemmF64Args {
     double* C; int ldc;
     int M, N, K;
     int relu;
+    unsigned* guard;                   // host-mapped status word (MDGAT_STATUS_RANGE) or nullptr: raised when an output is not finite or
+                                       // beyond 2^500 in magnitude (f64_out_of_range in f64.hip)
 };
 int launch_gemm_f64(const GemmF64Args& a, hipStream_t s);
 
@@ -26,9 +28,10 @@ struct AttnF64Args {
     uint32_t* sel;         // parity tap (mdgat_taps.topk_sel layout) or nullptr
     int selW;
     int units, tiles;      // B * 2 * 4 (pair, frame, head) units; query tiles per unit
+    unsigned* guard;       // as GemmF64Args::guard, for the message rows
 };
 // attention (topk == 0) / dynamic_attention (mdgat.py:190-210) on fp64 q / k / v; sel: optional tap of the kept keys
-int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s);
+int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s, unsigned* guard = nullptr);
 // in4 [R][4] = x y z saliency, in33 [R][33] = FPFH; rows pair-major, frame 0 then frame 1
 int launch_assemble_f64(int B, int N, int M, const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
                         const double* sigma1, const double* fpfh1, double* in4, double* in33, unsigned* guard, hipStream_t s);

@@ -60,12 +60,11 @@ struct RowSearch {
 // every row: the bracketing searches this replaces (probe a threshold, count, Newton / interpolation / bisection) average 5 probes
 // but have a tail of 20-30, and a tile waits at a barrier for its slowest row (measured at 2048 keys: 36 000 cycles of search and
 // 40 000 of waiting per tile; profiles/NOTES_r5.md section 3).
-// near (optional): receives whether more than k values lie at or above thr - mdgat_near_eps (repair.hip's near-threshold rows).
 typedef __attribute__((address_space(3))) int rs_lds_int;
 typedef __attribute__((address_space(3))) const float rs_lds_cfloat;
 constexpr int RS_HIST_INTS = 320;       // 256 bins + one waste bin per lane
 template <int NV>
-__device__ RowSearch topk_row_search(const float* row_, int nk, int k, float zq, int lane, int list_cap, int* hist_, bool* near = nullptr) {
+__device__ RowSearch topk_row_search(const float* row_, int nk, int k, float zq, int lane, int list_cap, int* hist_) {
     // (both pointers are LDS: said here, or the function addresses them as flat memory)
     rs_lds_cfloat* row = (rs_lds_cfloat*)row_;
     rs_lds_int* hist = (rs_lds_int*)hist_;
@@ -148,13 +147,6 @@ __device__ RowSearch topk_row_search(const float* row_, int nk, int k, float zq,
         sh = sh > 8 ? sh - 8 : 0;
     }
     out.thr = ord2f(base); out.c_gt = above; out.c_ge = above + ceq;
-    if (near) {
-        const unsigned on = f2ord(out.thr - mdgat_near_eps(out.thr, out.mx));
-        int c = 0;
-#pragma unroll
-        for (int i = 0; i < NV; ++i) c += o[i] >= on ? 1 : 0;
-        *near = rs_wave_sum_i(c) > k;
-    }
     if (out.c_ge == k || ceq <= list_cap) return out;
     // more than list_cap values share the k-th place: the first k - c_gt of them in key order stay (key = lane + 64 i)
     const int need = k - above;

@@ -9,11 +9,14 @@ Host-side mirror of ``/root/reference/models/mdgat.py:315-603`` (class ``MDGAT``
 * same ``forward(data: dict) -> dict`` contract: keys ``keypoints0/1, descriptors0/1, scores0/1`` in,
   ``matches0/1`` (int64, -1 = unmatched), ``matching_scores0/1`` (module dtype) and ``loss`` out, the
   empty-keypoint early-out of ``mdgat.py:374-382`` included;
-* tolerant of ``net.double().eval()`` (``test.py:193``): the kernels compute in fp32, results are cast
-  back to the module's dtype;
-* ``MDGAT(config with arithmetic='fp64')`` (not a reference key) selects the library's reference-exact mode: fp64 inputs,
+* the module's dtype is the arithmetic request, as it is in the reference: ``net.double()`` (what ``test.py:193`` and
+  ``test_registration_metric.py:194`` call before every forward) runs the library's reference-exact mode - fp64 inputs,
   fp64 weights and fp64 matrix-core arithmetic through the last dynamic layer, so that every ``logits.topk(k)``
-  (``mdgat.py:202``) selects what the reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``).
+  (``mdgat.py:202``) selects what the reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``) and Z is
+  within 1e-4 of the reference on every pair; a float32 module runs the fp32-class throughput path (5x the rate, Z within
+  1e-4 except around the ~1.5 keypoints per pair whose top-k near-tie falls the other way).  ``config['arithmetic']`` =
+  ``'fp32'`` / ``'fp64'`` (not a reference key) or ``MDGAT_ARITHMETIC`` in the environment pin one path whatever the dtype;
+  results are cast to the module's dtype either way.
 
 All arithmetic happens in ``libmdgat_hip.so``; PyTorch only owns device memory and streams.  There is no
 CPU path: tensors that are not on a gfx950 device raise.  Training (loss / backward) is out of scope:
@@ -22,6 +25,7 @@ CPU path: tensors that are not on a gfx950 device raise.  Training (loss / backw
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 import weakref
 from typing import Dict, Optional
@@ -80,9 +84,10 @@ class _DeviceState:
 
     MAX_WORKSPACES = 8                  # streams remembered per device (least recently used first out)
 
-    def __init__(self, handle, device):
+    def __init__(self, handle, device, f64=False):
         self.handle = handle
         self.device = device
+        self.f64 = f64                  # the handle computes in MDGAT_ARITH_FP64 (fixed at mdgat_create)
         self.workspaces = {}            # stream handle -> uint8 tensor, in order of last use
         self.lock = threading.Lock()
 
@@ -153,20 +158,19 @@ class MDGAT(nn.Module):
         self.lanes = int(self.config.get('lanes', 0))
         if self.lanes not in (0, 1, 2):
             raise ValueError(f'lanes={self.lanes}: expected 1 or 2 (0: library default)')
-        # not a reference key: exact re-decision of near-threshold rows of the dynamic layers (include/mdgat_hip.h:
-        # mdgat_config.exact_topk; csrc/repair.hip): `logits.topk(k)` then selects what fp64 arithmetic selects on the
-        # layer's own input.  Off by default: it removes the flips a dynamic layer causes itself (12-19 rows in 262 144 at
-        # BASELINE configs[1]) but not the ones that arrive with the layer's input, which dominate - the number of rows
-        # selected differently from the fp64 reference stays the same (profiles/parity_r4.txt) - and costs 3-6 %.
-        self.exact_topk = bool(self.config.get('exact_topk', False))
-        # not a reference key: 'fp32' (default: fp32-class arithmetic everywhere) or 'fp64' - the reference's own arithmetic
-        # (test.py:193 runs net.double()) for the encoders and the layers up to the last dynamic one, where the top-k selection
-        # of mdgat.py:202 is decided (include/mdgat_hip.h: mdgat_arithmetic; csrc/f64.hip).  'f64_layers' (optional) overrides
-        # how many leading layers run in fp64 (default -1: through the last layer with a k).
-        self.arithmetic = str(self.config.get('arithmetic', 'fp32'))
-        if self.arithmetic not in ('fp32', 'fp64'):
-            raise ValueError(f"arithmetic={self.arithmetic!r}: expected 'fp32' or 'fp64'")
-        self.f64_layers = int(self.config.get('f64_layers', -1))
+        # not a reference key: which arithmetic the forward runs in (include/mdgat_hip.h: mdgat_arithmetic).
+        #   'auto' (default): the MODULE'S DTYPE decides, as it does in the reference - a float64 module (test.py:193 and
+        #            test_registration_metric.py:194 call net.double() before every forward) runs the reference's own
+        #            arithmetic for the encoders and the layers up to the last dynamic one, where the top-k selection of
+        #            mdgat.py:202 is decided (csrc/f64.hip); a float32 module runs the fp32-class throughput path;
+        #   'fp32' / 'fp64': that path whatever the dtype (bench.py pins its headline this way).
+        # MDGAT_ARITHMETIC in the environment replaces the default for modules whose config does not carry the key.
+        # 'f64_layers' (optional): how many leading layers run in fp64 (None: through the last layer with a k; 0: encoders only).
+        self.arithmetic = str(self.config.get('arithmetic') or os.environ.get('MDGAT_ARITHMETIC') or 'auto')
+        if self.arithmetic not in ('auto', 'fp32', 'fp64'):
+            raise ValueError(f"arithmetic={self.arithmetic!r}: expected 'auto', 'fp32' or 'fp64'")
+        f64_layers = self.config.get('f64_layers')
+        self.f64_layers = None if f64_layers is None or int(f64_layers) < 0 else int(f64_layers)
         if self.arithmetic == 'fp64' and self.attention_dtype != 'fp32':
             raise ValueError("arithmetic='fp64' and attention_dtype='f16' exclude each other")
         if self.descriptor != 'FPFH':
@@ -193,7 +197,7 @@ class MDGAT(nn.Module):
         # [1] True while a blob installed by load_packed() (e.g. received by an RCCL broadcast) stands in for this
         #     module's own parameters: casts / moves of the module must not throw it away.
         self._blob_holder = [None, False]
-        self._blob64_holder = [None]        # arithmetic='fp64': the same blob before its rounding to fp32 (shared like [0] above)
+        self._blob64_holder = [None]        # exact mode: the same blob before its rounding to fp32 (shared like [0] above)
         self._sig_holder = [self._signature()]
         # replicas never run __init__, so only the original module owns (and finally frees) the handles
         weakref.finalize(self, _close_states, self._states)
@@ -227,6 +231,14 @@ class MDGAT(nn.Module):
             self._blob_holder[0] = None
             self._blob_holder[1] = False
             self._blob64_holder[0] = None
+
+    def exact(self) -> bool:
+        """Does a forward of this module, as it stands, run the reference-exact (fp64) mode?  'auto' follows the module's
+        dtype (net.double() -> True) unless attention_dtype='f16' was asked for, which is a throughput mode by definition."""
+        arith = getattr(self, 'arithmetic', 'auto')
+        if arith == 'auto':
+            return self.bin_score.dtype == torch.float64 and getattr(self, 'attention_dtype', 'fp32') == 'fp32'
+        return arith == 'fp64'
 
     def _signature(self):
         ts = list(self.parameters()) + list(self.buffers())
@@ -291,17 +303,21 @@ class MDGAT(nn.Module):
                     raise RuntimeError('this MDGAT is a DataParallel replica without packed weights: the owner module '
                                        'packs them in _replicate_for_data_parallel() - was replicate() bypassed?')
                 self._blob_holder[0] = self.packed_weights()
-                if getattr(self, 'arithmetic', 'fp32') == 'fp64':
-                    import numpy as np
-                    self._blob64_holder[0] = self.packed_weights(np.float64)
+            if self._blob64_holder[0] is None and self.exact() and 'bin_score' in self._parameters and not self._blob_holder[1]:
+                import numpy as np
+                self._blob64_holder[0] = self.packed_weights(np.float64)
             return self._blob_holder[0]
 
     def _state_for(self, device: torch.device, blob_device_tensor: Optional[torch.Tensor] = None) -> _DeviceState:
         idx = device.index if device.index is not None else torch.cuda.current_device()
         with self._states_lock:
             st = self._states.get(idx)
-            if st is not None:
+            if st is not None and (st.f64 == self.exact() or blob_device_tensor is not None):
                 return st
+            if st is not None:
+                # the module's dtype changed under a blob installed by load_packed() (casts keep such a blob): the handle's
+                # arithmetic is fixed at creation, so it is rebuilt from the host copies of the blob(s)
+                self._states.pop(idx).close()
             lib = _lib.load()
             L = self.config['L']
             cfg = _lib.MdgatConfig()
@@ -313,13 +329,13 @@ class MDGAT(nn.Module):
             cfg.extract_mode = self._extract_mode()
             cfg.match_threshold = float(self.config['match_threshold'])
             cfg.attention_mode = 0 if self.attention_dtype == 'fp32' else 1
-            cfg.exact_topk = int(getattr(self, 'exact_topk', False))
-            f64 = getattr(self, 'arithmetic', 'fp32') == 'fp64'
+            f64 = self.exact()
             cfg.arithmetic = _lib.ARITH_FP64 if f64 else _lib.ARITH_FP32
-            cfg.f64_layers = int(getattr(self, 'f64_layers', -1))
+            fl = getattr(self, 'f64_layers', None)
+            cfg.f64_layers = 0 if fl is None else (_lib.F64_ENCODERS_ONLY if fl == 0 else int(fl))     # (C ABI: 0 = automatic)
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
-            st = _DeviceState(handle, idx)
+            st = _DeviceState(handle, idx, f64)
             try:
                 if self.lanes:
                     _lib.check(lib.mdgat_set_lanes(handle, self.lanes), 'mdgat_set_lanes')
@@ -335,8 +351,8 @@ class MDGAT(nn.Module):
                 if f64:
                     blob64 = self._blob64_holder[0]
                     if blob64 is None:
-                        raise RuntimeError("arithmetic='fp64' needs the fp64 blob: load_packed(blob, blob64) on ranks that "
-                                           'received their weights by broadcast')
+                        raise RuntimeError('the exact mode (a float64 module, or arithmetic=\'fp64\') needs the fp64 blob: '
+                                           'load_packed(blob, blob64) on ranks that received their weights by broadcast')
                     _lib.check(lib.mdgat_load_weights_f64(handle, blob64.ctypes.data_as(C.c_void_p), blob64.size, 0),
                                'mdgat_load_weights_f64')
             except Exception:
@@ -361,9 +377,10 @@ class MDGAT(nn.Module):
         see shard.broadcast_weights) instead of packing this module's own parameters.  arithmetic='fp64' needs
         ``blob64`` as well: the same blob in float64 (``packed_weights(numpy.float64)``)."""
         assert blob.is_cuda and blob.dtype == torch.float32 and blob.is_contiguous()
-        if getattr(self, 'arithmetic', 'fp32') == 'fp64':
+        if self.exact():
             if blob64 is None or blob64.dtype != torch.float64 or blob64.numel() != blob.numel():
-                raise ValueError("arithmetic='fp64': load_packed needs blob64, the float64 blob of the same layout")
+                raise ValueError("the exact mode (a float64 module, or arithmetic='fp64'): load_packed needs blob64, the float64 "
+                                 'blob of the same layout')
         idx = blob.device.index
         with self._states_lock:
             old = self._states.pop(idx, None)
@@ -452,17 +469,17 @@ class MDGAT(nn.Module):
             torch.cuda.current_stream(dev).synchronize()
             with st.lock:
                 handles = list(st.workspaces)
+            cur = torch.cuda.current_stream(dev).cuda_stream
             for hnd in handles:
-                if hnd and hnd != torch.cuda.current_stream(dev).cuda_stream:
+                if hnd == cur:
+                    continue
+                if hnd == 0:        # the legacy default stream: pool streams are non-blocking and do not wait for it
+                    torch.cuda.default_stream(dev).synchronize()
+                else:
                     _sync_raw_stream(hnd, dev)
         fb, rg = C.c_uint(0), C.c_uint(0)
         _lib.check(_lib.load().mdgat_async_status(st.handle, 1, C.byref(fb), C.byref(rg)), 'mdgat_matcher_amd')
-        out = {'sinkhorn_fallback': bool(fb.value)}
-        if getattr(self, 'exact_topk', False):
-            gu = C.c_uint(0)
-            _lib.check(_lib.load().mdgat_topk_repair_status(st.handle, 1, C.byref(gu)), 'mdgat_topk_repair_status')
-            out['topk_rows_not_redecided'] = int(gu.value)
-        return out
+        return {'sinkhorn_fallback': bool(fb.value)}
 
     @staticmethod
     def _f32(t, device):
@@ -477,7 +494,8 @@ class MDGAT(nn.Module):
             raise RuntimeError('mdgat_matcher_amd runs on MI355X (gfx950) only: inputs must be on a CUDA/HIP '
                                'device; there is no CPU fallback')
         dev = probe.device
-        f64 = getattr(self, 'arithmetic', 'fp32') == 'fp64'
+        st = self._state_for(dev)
+        f64 = st.f64
         if frames is not None:
             if frames[0].shape[-1] != 37 or frames[1].shape[-1] != 37 or frames[0].dim() != 3:
                 raise ValueError('expected frame records [B, N, 37] = xyz | saliency | 33-D FPFH (load_data.py:152-165)')
@@ -489,7 +507,6 @@ class MDGAT(nn.Module):
             in_dtype = torch.float64 if f64 else torch.float32
             ins = [t.to(device=dev, dtype=in_dtype).contiguous() for t in (kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1)]
             B, N, M = kpts0.shape[0], kpts0.shape[1], kpts1.shape[1]
-        st = self._state_for(dev)
         lib = _lib.load()
         with torch.cuda.device(dev), st.lock:
             stream = torch.cuda.current_stream(dev).cuda_stream

@@ -11,9 +11,6 @@ All folding is done in fp64 and rounded to fp32 once:
 * ``merge`` (``mdgat.py:220, 237``) has no non-linearity before ``mlp.0`` (``mdgat.py:248``), so it is
   folded into the message half of ``mlp.0``: ``W1 [x ; Wm msg + bm] = W1x x + (W1m Wm) msg + W1m bm``
   (with Wm's input columns permuted to the head-major message layout);
-* the q and k rows of that matrix (and their biases) are followed by their fp32 residuals ``w - fp32(w)``
-  (``qk_lo_w``, ``qk_lo_b``): the exact re-decision of near-threshold top-k rows (``csrc/repair.hip``) rebuilds the
-  fp64 weights from head + residual;
 * GAUGE FIXING.  The network's function does not change when a hidden channel is scaled by s > 0 and the weights that
   read it by 1 / s - behind a ReLU (positively homogeneous), between v and ``merge`` (linear), and, dimension by
   dimension, between q and k (the logits are bilinear).  A checkpoint may sit anywhere in that family; the kernels carry
@@ -60,7 +57,7 @@ def blob_layout(L: int) -> Dict[str, int]:
     lay['layer0'] = o
     lo = 0
     for name, n in (('qkv_w', 384 * 128), ('qkv_b', 384), ('mlp1_w', 256 * 256), ('mlp1_b', 256),
-                    ('mlp2_w', 128 * 256), ('mlp2_b', 128), ('qk_lo_w', 256 * 128), ('qk_lo_b', 256)):
+                    ('mlp2_w', 128 * 256), ('mlp2_b', 128)):
         lay[name] = lo
         lo += _round4(n)
     lay['layer_stride'] = lo
@@ -190,11 +187,6 @@ def pack_state_dict(sd, L: int, dtype=np.float32) -> np.ndarray:
         sv = _row_scale(ws[2], bs[2])
         ws[2], bs[2] = ws[2] * sv[:, None], bs[2] * sv
         put(base + lay['qkv_w'], np.concatenate(ws, axis=0)); put(base + lay['qkv_b'], np.concatenate(bs))
-        # fp32 residuals of the q and k rows: the library's exact top-k re-decision (csrc/repair.hip) evaluates
-        # near-threshold logits with the fp64 weights, carried as fp32 head + fp32 residual (48 bits)
-        for wname, arrs in (('qk_lo_w', ws), ('qk_lo_b', bs)):
-            full = np.concatenate(arrs[:2], axis=0).reshape(-1)
-            put(base + lay[wname], full - full.astype(np.float32).astype(np.float64))
         wm, bm = _plain(sd, f'{p}.attn.merge')
         wm = wm[:, HEAD_MAJOR] / sv[None, :]       # input columns in head-major message order, the v gauge undone
         w1, b1 = _fold_bn(sd, f'{p}.mlp.0', f'{p}.mlp.1')

@@ -91,8 +91,10 @@ def broadcast_blob(blob: torch.Tensor, src: int = 0) -> torch.Tensor:
 def broadcast_weights(net, device, rank: int, world: int, out64=None):
     """Rank 0 packs its parameters (BN fold etc., pack.py); the packed blob travels once by RCCL broadcast
     and every rank installs it into its library handle.  Without a process group the module just packs lazily.
-    A module in the reference-exact mode (arithmetic='fp64') also needs the blob before its rounding to fp32: it travels in a
-    second broadcast (``out64``, a list, receives it - tests)."""
+    A module that runs the reference-exact mode - or may, once the caller casts it: a float64 module, arithmetic='fp64', and
+    every module whose arithmetic follows its dtype ('auto'; test.py:193 casts before every forward) - also needs the blob before
+    its rounding to fp32: it travels in a second broadcast (``out64``, a list, receives it - tests).  Only arithmetic='fp32'
+    (bench.py's headline) skips it."""
     if world == 1 and not _group_active():
         return None
     from . import pack
@@ -103,7 +105,7 @@ def broadcast_weights(net, device, rank: int, world: int, out64=None):
         blob = torch.empty(n, dtype=torch.float32, device=device)
     broadcast_blob(blob, 0)
     blob64 = None
-    if getattr(net, 'arithmetic', 'fp32') == 'fp64':
+    if net.exact() or getattr(net, 'arithmetic', 'auto') == 'auto':
         # the reference-exact mode loads the folded weights before their rounding to fp32 as well (29 MB at L = 9)
         import numpy as np
         if rank == 0:

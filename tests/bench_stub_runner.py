@@ -24,7 +24,7 @@ def _fake_run(self, kpts0, sigma0, fpfh0, kpts1, sigma1, fpfh1, want_Z=False, ta
         with open(f'{log}.{rank}', 'a') as f:
             f.write(f'{B} {N} {M}\n')
     z = torch.zeros
-    return (z(B, N, dtype=torch.int64), z(B, M, dtype=torch.int64), z(B, N), z(B, M), None)
+    return (z(B, N, dtype=torch.int64), z(B, M, dtype=torch.int64), z(B, N), z(B, M), z(B, N + 1, M + 1) if want_Z else None)
 
 
 MDGAT._run = _fake_run

@@ -150,11 +150,10 @@ def assert_plain_vs_oracle(res, cfg, sd, data_cpu, tag=''):
                         ref['matching_scores0'].numpy(), ref['matching_scores1'].numpy(), tag)
 
 
-def local_flips(net, sd, data_cpu, device='cuda:0', with_stats=False):
+def local_flips(net, sd, data_cpu, device='cuda:0'):
     """{dynamic layer: rows whose HIP selection differs from the fp64 top-k of the HIP path's OWN fp32 layer input}: the flips
-    caused INSIDE the layer (q / k projection + q.k products), which the exact re-decision of near-threshold rows
-    (mdgat_config.exact_topk, csrc/repair.hip) removes.  ``with_stats``: also the repair counters [2L][4] (rows examined,
-    corrected, unused, given up)."""
+    caused INSIDE the layer (q / k projection + q.k products) of the fp32-class path - the rest arrive with the layer's input
+    (tools/parity_report.py)."""
     dev = {k: v.to(device) for k, v in data_cpu.items()}
     k0 = dev['keypoints0']
     B, N, M = k0.shape[0], k0.shape[1], dev['keypoints1'].shape[1]
@@ -164,9 +163,8 @@ def local_flips(net, sd, data_cpu, device='cuda:0', with_stats=False):
     sel = torch.zeros(L2 * words, dtype=torch.int32, device=k0.device)
     xl = torch.empty(L2, B, N + M, 128, device=k0.device)
     xe = torch.empty(B, N + M, 128, device=k0.device)
-    stats = torch.zeros(L2, 4, dtype=torch.int32, device=k0.device)
     net._run(k0, dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=False,
-             taps={'topk_sel': sel, 'x_layers': xl, 'x_enc': xe, 'repair_stats': stats})
+             taps={'topk_sel': sel, 'x_layers': xl, 'x_enc': xe})
     torch.cuda.synchronize()
     xl = torch.cat([xl, xe[None]]).cpu().double()          # index -1 = the encoder output = the input of layer 0
     out = {}
@@ -186,4 +184,4 @@ def local_flips(net, sd, data_cpu, device='cuda:0', with_stats=False):
             own = torch.zeros_like(logits, dtype=torch.bool).scatter_(3, logits.topk(kk, dim=3).indices, True)
             rows += int((own ^ masks[side].cpu()).any(-1).sum())
         out[i] = rows
-    return (out, stats.cpu()) if with_stats else out
+    return out

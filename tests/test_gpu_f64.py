@@ -1,4 +1,5 @@
-"""GPU parity of the reference-exact mode (MDGAT(arithmetic='fp64'), csrc/f64.hip) through the C ABI.
+"""GPU parity of the reference-exact mode (csrc/f64.hip) through the C ABI - what a float64 module runs (net.double(), as the
+reference's callers do before every forward; config['arithmetic'] = 'fp64' pins it whatever the dtype).
 
 The point of the mode is the LITERAL north-star bar: Z within 1e-4 of the reference's fp64 output on every pair, with no
 attribution of top-k flips - because no selection flips: the encoders and the layers through the last dynamic one compute in
@@ -190,7 +191,8 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     entry, matching scores < 1e-4 - and not one top-k row selected differently from the fp64 oracle on the same trajectory."""
     from parity_util import hip_forward_with_selection
     g = _g(golden_dir, name)
-    net, cfg, sd, data, (B, n, m, L) = _build(g, arithmetic='fp64')
+    net, cfg, sd, data, (B, n, m, L) = _build(g)            # no 'arithmetic' key: the float64 module is the request (test.py:193)
+    assert net.exact()
     dev = {k: v.to(DEV) for k, v in data.items()}
     (m0, m1, s0, s1, Z), forced = hip_forward_with_selection(net, dev)
     net.check(DEV)
@@ -220,6 +222,47 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     # the untapped kernels (what ships) give the same bits
     plain = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=True)
     assert torch.equal(plain[0], m0) and torch.equal(plain[1], m1) and torch.equal(plain[4], Z)
+
+
+@pytest.mark.parametrize('name', ['var_n256_L4_S20', 'var_n512_L9_S100', 'var_n400m512_L9_S100'])
+def test_literal_bar_on_the_reference_held_variants(golden_dir, name):
+    """The other reference-held pairs at config scale (tests/golden/var_*.npz): all four extraction branches of mdgat.py:441-483 and
+    a ragged 400 x 512 pair, through the dict API of a float64 module with no extra config key.  Against the REFERENCE's own
+    outputs: matches bit-identical and matching scores within the literal 1e-4 in every branch, Z (the same for every branch)
+    within 1e-4 on every held entry, zero top-k rows selected differently from the fp64 oracle."""
+    from parity_util import hip_forward_with_selection
+    g = _g(golden_dir, name)
+    checked = 0
+    for tag, (loss_method, mutual) in {'default': ('triplet_loss', False), 'mutual': ('triplet_loss', True),
+                                       'sg': ('superglue', False), 'sgmutual': ('superglue', True)}.items():
+        if f'{tag}_matches0' not in g:
+            continue
+        net, cfg, sd, data, (B, n, m, L) = _build(g, loss_method=loss_method, mutual_check=mutual)
+        assert net.exact() and 'arithmetic' not in cfg
+        dev = {k: v.to(DEV) for k, v in data.items()}
+        with torch.no_grad():
+            out = net(dev)
+        np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g[f'{tag}_matches0'], err_msg=tag)
+        np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g[f'{tag}_matches1'], err_msg=tag)
+        es = max(np.abs(out['matching_scores0'].cpu().numpy() - g[f'{tag}_mscores0']).max(),
+                 np.abs(out['matching_scores1'].cpu().numpy() - g[f'{tag}_mscores1']).max())
+        assert es < Z_TOL, (tag, es)
+        checked += 1
+        if tag != 'default':
+            continue
+        (m0, m1, s0, s1, Z), forced = hip_forward_with_selection(net, dev)
+        net.check(DEV)
+        Zc = Z.cpu().double().numpy()
+        mine = np.concatenate([Zc[:, ::8, ::8].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+        ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+        err = np.abs(mine - ref_Z).max()
+        cap = {}
+        O.mdgat_forward(sd, cfg, data, cap, forced_topk=forced)
+        rows = sum(r['rows'] for reps in cap.get('topk_report', {}).values() for r in reps)
+        print(f'[parity-f64] {name}: max|dZ| vs the reference {err:.2e}, mscores {es:.2e}, top-k rows differing {rows}')
+        assert err < Z_TOL and rows == 0
+        assert np.abs(Zc - cap['Z'].numpy()).max() < Z_TOL
+    assert checked >= 2
 
 
 def test_f64_dict_api_slices_and_errors():
@@ -318,6 +361,49 @@ def test_f64_refuses_non_finite_inputs():
         with pytest.raises(RuntimeError):
             net.check(DEV)
     net(clean)                                            # and the module keeps working afterwards
+
+
+@pytest.mark.parametrize('plant', ['residual_overflow', 'qk_beyond_range', 'hidden_nan'])
+def test_f64_refuses_non_finite_values_mid_stack(plant):
+    """Non-finite values that arise INSIDE the fp64 layers - not at the inputs, not at the hand-over to the fp32 kernels.  The
+    reference propagates them to NaN outputs (mdgat.py:192-193); csrc/f64.hip is compiled with -fno-honor-nans and its ReLU /
+    row maximum / clamped exponential would swallow a NaN, so every fp64 product tests its outputs by their exponent bits in its
+    epilogue (f64_out_of_range: not finite or beyond 2^500, before the ReLU and after the residual) and the call is refused.
+    The plants go into the fp64 blob only (load_packed: the fp32 blob's own range check at load time would refuse them first):
+      residual_overflow  mlp.3 of layer 0 scaled by 1e300: the residual stream overflows to +-inf in layer 0's tail;
+      qk_beyond_range    the q and k rows of layer 1 scaled by 1e160: q.k would overflow and the online softmax would meet
+                         inf - inf - refused where q and k are produced, so no logit can be anything but finite;
+      hidden_nan         one mlp.0 weight of layer 1 is NaN: the hidden layer's ReLU would turn the NaN into 0."""
+    from mdgat_matcher_amd import pack
+    L = 2
+    cfg = synth.default_config(L=L, k=[16, None, 8, None], sinkhorn_iterations=10)
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=3))
+    net = net.eval().to(DEV)
+    assert net.exact()
+    data = synth.make_batch(2, 96, 80, device=DEV)
+    good = net(data)
+    lay = pack.blob_layout(L)
+    blob = net.packed_weights()
+    blob64 = net.packed_weights(np.float64).copy()
+
+    def sl(layer, name, n):
+        o = lay['layer0'] + layer * lay['layer_stride'] + lay[name]
+        return slice(o, o + n)
+    if plant == 'residual_overflow':
+        blob64[sl(0, 'mlp2_w', 128 * 256)] *= 1e300
+    elif plant == 'qk_beyond_range':
+        blob64[sl(1, 'qkv_w', 256 * 128)] *= 1e160
+        blob64[sl(1, 'qkv_b', 256)] *= 1e160
+    else:
+        blob64[sl(1, 'mlp1_w', 256 * 256)][1234] = float('nan')
+    net.load_packed(torch.from_numpy(blob).to(DEV), torch.from_numpy(blob64).to(DEV))
+    with pytest.raises(RuntimeError, match='range|finite'):
+        net(data)
+    # the clean blobs again: the module works and gives the same bits as before
+    net.load_packed(torch.from_numpy(blob).to(DEV), torch.from_numpy(net.packed_weights(np.float64)).to(DEV))
+    again = net(data)
+    assert torch.equal(again['matches0'], good['matches0']) and torch.equal(again['matching_scores0'], good['matching_scores0'])
 
 
 def test_f64_large_batch_runs_in_slices_on_two_lanes():

@@ -29,7 +29,7 @@ def test_blob_layout_matches_library():
     lib = _lib.load()
     for L in (0, 1, 4, 9, 32):
         assert lib.mdgat_blob_floats(L) == pack.blob_layout(L)['total']
-    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 6)     # L, iters, topk[64], extract_mode, threshold, attention_mode, exact_topk, arithmetic, f64_layers
+    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 5)     # L, iters, topk[64], extract_mode, threshold, attention_mode, arithmetic, f64_layers
 
 
 def test_state_dict_names_match_reference_fixture():
@@ -511,7 +511,9 @@ def test_two_device_dataparallel_with_stubbed_library():
         assert sorted(c for c in fake.calls if c[0] == 'create') == [('create', 0), ('create', 1)]
         assert len(fake.loaded) == 2 and all(np.array_equal(b, expect) for b in fake.loaded)
         assert sorted(net._states) == [0, 1] and all(r._states is net._states for r in replicas)
-        assert sum(1 for c in fake.calls if c[0] == 'forward') == 2 and all(c[1] == 2 for c in fake.calls if c[0] == 'forward')
+        # (a float64 module: the exact mode - each device's handle got the owner's fp64 blob as well)
+        assert sum(1 for c in fake.calls if c[0] == 'forward_f64') == 2 and all(c[1] == 2 for c in fake.calls if c[0] == 'forward_f64')
+        assert len(fake.loaded64) == 2 and all(np.array_equal(b, net.packed_weights(np.float64)) for b in fake.loaded64)
         gathered = torch.cat([o[0] for o in outs], dim=0)                           # DataParallel.gather of matches0
         assert gathered.shape == (4, 8)
         net._invalidate()
@@ -568,7 +570,7 @@ def test_fp64_arithmetic_host_logic():
     d = synth.make_batch(2, 8, 8)
     with _stubbed(fake, stream):
         out = net(d)
-        assert cfgs == [(_lib.ARITH_FP64, -1)]
+        assert cfgs == [(_lib.ARITH_FP64, 0)]         # f64_layers 0 = automatic: what a zero-initialised C config holds
         assert [c[0] for c in fake.calls if c[0].startswith('load')] == ['load', 'load64']
         assert any(c[0] == 'forward_f64' for c in fake.calls) and not any(c[0] == 'forward' for c in fake.calls)
         b32, b64 = fake.loaded[0], fake.loaded64[0]
@@ -585,3 +587,69 @@ def test_fp64_arithmetic_host_logic():
         MDGAT(synth.default_config(L=1, arithmetic='fp16'))
     with pytest.raises(ValueError):
         MDGAT(synth.default_config(L=1, arithmetic='fp64', attention_dtype='f16'))
+
+
+def test_module_dtype_is_the_arithmetic_request(monkeypatch):
+    """No 'arithmetic' key (the reference's config has none, test.py:137-151): a float64 module - net.double(), test.py:193 - runs the
+    reference-exact mode (MDGAT_ARITH_FP64 handle, both blobs, float64 inputs through mdgat_forward_f64), a float32 module the
+    throughput path; the handle follows the module when it is cast; an explicit key or MDGAT_ARITHMETIC in the environment pins
+    the path whatever the dtype; f64_layers reaches the C ABI as 0 = automatic / -1 = encoders only."""
+    monkeypatch.delenv('MDGAT_ARITHMETIC', raising=False)
+    fake, stream = _FakeLib(), [11]
+    fake.matched = 1
+    cfgs = []
+    orig_create = fake.mdgat_create
+
+    def create(cfg, idx, handle):
+        cfgs.append((cfg._obj.arithmetic, cfg._obj.f64_layers))
+        return orig_create(cfg, idx, handle)
+    fake.mdgat_create = create
+    d = synth.make_batch(1, 8, 8)
+    sd = synth.make_state_dict(L=2, seed=5)
+    with _stubbed(fake, stream):
+        net = MDGAT(synth.default_config(L=2))
+        assert net.arithmetic == 'auto' and not net.exact()
+        net.load_state_dict(sd)
+        net = net.eval()
+        net({k: v.float() for k, v in d.items()})
+        assert cfgs[-1] == (_lib.ARITH_FP32, 0)
+        assert any(c[0] == 'forward' for c in fake.calls) and not any(c[0] == 'forward_f64' for c in fake.calls)
+        net.double().eval()                                   # test.py:193
+        assert net.exact()
+        out = net(d)
+        assert cfgs[-1] == (_lib.ARITH_FP64, 0)
+        assert any(c[0] == 'forward_f64' for c in fake.calls) and ('load64', 0) in fake.calls
+        assert out['matching_scores0'].dtype == torch.float64
+        n_create = len(cfgs)
+        net.double().eval()                                   # every iteration of the reference's loop: nothing is rebuilt
+        net(d)
+        assert len(cfgs) == n_create
+        net.float()
+        net({k: v.float() for k, v in d.items()})
+        assert cfgs[-1] == (_lib.ARITH_FP32, 0) and len(cfgs) == n_create + 1
+        net._invalidate()
+        # pinned by the config, whatever the dtype
+        for arith, want in (('fp32', _lib.ARITH_FP32), ('fp64', _lib.ARITH_FP64)):
+            for cast in ('float', 'double'):
+                p = MDGAT(synth.default_config(L=2, arithmetic=arith))
+                p.load_state_dict(sd)
+                p = getattr(p, cast)().eval()
+                p(d)
+                assert cfgs[-1][0] == want, (arith, cast)
+                p._invalidate()
+        # pinned by the environment for modules without the key; the key wins over the environment
+        monkeypatch.setenv('MDGAT_ARITHMETIC', 'fp32')
+        p = MDGAT(synth.default_config(L=2)).double().eval()
+        assert p.arithmetic == 'fp32' and not p.exact()
+        assert MDGAT(synth.default_config(L=2, arithmetic='fp64')).exact()
+        monkeypatch.delenv('MDGAT_ARITHMETIC')
+        # attention_dtype='f16' is a throughput request: a float64 module does not turn it into the exact mode
+        assert not MDGAT(synth.default_config(L=2, attention_dtype='f16')).double().exact()
+        # f64_layers: None / negative = automatic (0 in the C config), 0 = encoders only (-1), n = n
+        for given, want in ((None, 0), (-1, 0), (0, _lib.F64_ENCODERS_ONLY), (3, 3)):
+            over = {} if given is None else {'f64_layers': given}
+            p = MDGAT(synth.default_config(L=2, **over)).double()
+            p.load_state_dict(sd)
+            p.eval()(d)
+            assert cfgs[-1] == (_lib.ARITH_FP64, want), (given, cfgs[-1])
+            p._invalidate()

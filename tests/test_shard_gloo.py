@@ -60,8 +60,11 @@ def _worker_f64(rank, world, port, q):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     from mdgat_matcher_amd import MDGAT, shard, synth
     r, w, _ = shard.init_distributed(world, backend='gloo')
-    net = MDGAT(synth.default_config(L=2, arithmetic='fp64')).double()
+    # (no 'arithmetic' key: the float64 module is the request, as for the reference's callers; rank 1 stays float32 until after the
+    # broadcast - a module whose arithmetic follows its dtype receives both blobs either way)
+    net = MDGAT(synth.default_config(L=2))
     if r == 0:
+        net = net.double()
         net.load_state_dict(synth.make_state_dict(L=2, seed=5))
     got64 = []
     blob = shard.broadcast_weights(net, 'cpu', r, w, out64=got64)
@@ -71,7 +74,7 @@ def _worker_f64(rank, world, port, q):
 
 
 def test_two_rank_gloo_exact_mode_broadcasts_both_blobs():
-    """arithmetic='fp64': the fp64 blob (the folded weights before their rounding) travels next to the fp32 one, and a rank that
+    """The exact mode (float64 module / arithmetic='fp64' / a module that may be cast later): the fp64 blob (the folded weights before their rounding) travels next to the fp32 one, and a rank that
     never loaded a checkpoint receives rank 0's, bit for bit."""
     world, port = 2, 29711 + (os.getpid() % 200)
     ctx = mp.get_context('spawn')
@@ -137,7 +140,8 @@ def _install_worker(rank, world, port, q):
     r, w, _ = shard.init_distributed(world, backend='gloo')
     L = 2
     torch.manual_seed(100 + r)                       # every rank starts from its own random init
-    net = MDGAT(synth.default_config(L=L, k=[16, None])).eval()
+    # (arithmetic='fp32': the throughput path of a sharded job, as bench.py pins it - the casts of test.py:193 then change nothing)
+    net = MDGAT(synth.default_config(L=L, k=[16, None], arithmetic='fp32')).eval()
     if r == 0:
         net.load_state_dict(synth.make_state_dict(L=L, seed=5, dtype=torch.float32))
     blob = shard.broadcast_weights(net, 'cpu', r, w)  # gloo broadcast of rank 0's packed blob (a CPU tensor: not installed)
@@ -269,11 +273,21 @@ def test_bench_eight_ranks_gloo_stub(tmp_path):
     assert len(t['per_rank_ms_per_step']) == 8 and max(range(8), key=lambda r: t['per_rank_ms_per_step'][r]) == 3     # the straggler
     assert abs(d['value'] - 4096 * 3 / (sorted(t['window_ms'])[len(t['window_ms']) // 2] * 1e-3)) < 1e-3 * d['value']      # (window_ms is rounded)
     assert d['ms_per_step'] >= max(t['per_rank_ms_per_step']) * 0.999        # the whole job waits for its slowest rank
-    assert d['status']['sinkhorn_fallback'] is False and d['status']['range_violation'] is False and '4/16' in d['status']['literal_1e-4_pairs']
+    assert d['status']['sinkhorn_fallback'] is False and d['status']['range_violation'] is False
+    # the parity fields are COMPUTED in the run (here on the recorder's zeros: presence and shape, not values)
+    pm = d['parity']['modes']
+    assert set(pm) == {'fp32', 'fp64'} and 'cfg_n512_L9_S100' in d['parity']['fixture']
+    for mode in pm.values():
+        assert mode['pairs'] == 8 and 0 <= mode['pairs_within_1e-4'] <= 8 and isinstance(mode['matches_identical'], bool)
+        assert isinstance(mode['max_abs_dZ'], float) and isinstance(mode['max_abs_d_mscores'], float)
+    assert d['status']['literal_1e-4_pairs'] == {m: f"{pm[m]['pairs_within_1e-4']}/8" for m in pm} and 'measured' in d['status']['parity_source']
     # every rank ran its own 512 pairs, and only those: 8 + warmup + windows x steps forwards of 512 x 512 x 512
     for r in range(8):
         calls = open(f'{log}.{r}').read().split('\n')[:-1]
-        assert calls and set(calls) == {'512 512 512'} and len(calls) == 8 + 1 + 2 * 3, (r, len(calls))
+        timed = calls[:8 + 1 + 2 * 3]
+        assert timed and set(timed) == {'512 512 512'} and len(timed) == 8 + 1 + 2 * 3, (r, len(calls))
+        # behind them, on rank 0 only: the parity block's two forwards over the 8 reference-held pairs (one per arithmetic mode)
+        assert calls[len(timed):] == (['8 512 512'] * 2 if r == 0 else []), (r, calls[len(timed):])
 
 
 def test_bench_plain_form_starts_its_own_ranks(tmp_path):
@@ -296,7 +310,7 @@ def test_bench_plain_form_starts_its_own_ranks(tmp_path):
     assert d['n_gpus'] == 8 and d['config']['rccl_world_size'] == 8 and d['config']['pairs_per_rank'] == [512] * 8
     assert 'starting 8 ranks' in p.stderr
     for r in range(8):
-        assert set(open(f'{log}.{r}').read().split()) == {'512'}
+        assert set(open(f'{log}.{r}').read().split()) == ({'512', '8'} if r == 0 else {'512'})     # ('8': rank 0's parity block)
     # a launcher that started 2 ranks for a --gpus 4 request: every rank refuses, nothing is printed
     port = 29911 + (os.getpid() % 80)
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

@@ -128,7 +128,7 @@ def one_case(rs):
     S = int(rs.choice([3, 10, 30]))
     kmax = min(N, M)
     k = [None if rs.uniform() < 0.4 else int(rs.randint(1, kmax + 1)) for _ in range(int(rs.choice([0, 2, 2 * L])))]
-    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S)
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, arithmetic='fp32')      # (the fp32-class path and its f16 range guard are the subject)
     sd = synth.make_state_dict(L=L, seed=int(rs.randint(100)))
     notes = perturb_state_dict(rs, sd, L)
     data = synth.make_batch(B, N, M, first_pair=int(rs.randint(1000)))

@@ -35,7 +35,7 @@ def one_case(rs):
         mutual = False                      # (the reference's dustbin-mutual branch only works for batch 1)
     bin_score = float(rs.choice([1.0, 0.37, -2.0, 6.0]))
     wseed, fp = int(rs.randint(100)), int(rs.randint(1000))
-    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual)
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=S, loss_method=loss_method, mutual_check=mutual, arithmetic='fp32')
     sd = synth.make_state_dict(L=L, seed=wseed, bin_score=bin_score)
     net = MDGAT(cfg).double()
     net.load_state_dict(sd)
