@@ -62,6 +62,7 @@ struct mdgat_handle {
     float* weights;      // device, fp32 blob (pack.py layout)
     _Float16* wsplit;    // device, split-f16 copies of the GNN / final_proj matrices (layer.hip)
     double* weights64;   // device, the blob in fp64 (MDGAT_ARITH_FP64: f64.hip), else nullptr
+    double* wfrag64;     // device, per layer mlp.0 | mlp.3 | q|k|v once more in MFMA fragment order (layer_f64.hip), else nullptr
     bool loaded, loaded64;
     unsigned* host_error; // MDGAT_STATUS_WORDS host-mapped words the kernels set (common.hpp): Sinkhorn fallback taken, f16 range guard,
                           // token of the last forward that matched a frame-0 keypoint
@@ -94,6 +95,8 @@ static size_t wsplit_halves(int L) { return WS_LAYER * (size_t)(2 * L) + WS_FINA
 // so that a wave's load instruction reads one contiguous KB (launch_frag_image; no pads)
 static constexpr size_t WF_W1 = 0, WF_W2 = 256 * 512, WF_QKV = WF_W2 + 128 * 512, WF_LAYER = WF_QKV + 384 * 256, WF_FINAL = 128 * 256;
 static size_t wfrag_halves(int L) { return WF_LAYER * (size_t)(2 * L) + WF_FINAL; }
+// fp64 fragment copies (layer_f64.hip: launch_frag64), per layer
+static constexpr size_t WF64_W1 = 0, WF64_W2 = 256 * 256, WF64_QKV = WF64_W2 + 128 * 256;
 
 extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** out) {
     if (!cfg || !out) { mdgat_set_error("mdgat_create: null argument"); return MDGAT_ERR_BAD_ARG; }
@@ -119,6 +122,7 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     h->weights = nullptr;
     h->wsplit = nullptr;
     h->weights64 = nullptr;
+    h->wfrag64 = nullptr;
     h->loaded = false;
     h->loaded64 = false;
     h->host_error = nullptr;
@@ -136,6 +140,8 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
     if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64) rc = mdgat_check_hip(hipMalloc(&h->weights64, h->bl.total * sizeof(double)), "hipMalloc(fp64 weights)");
+    if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64 && cfg->L > 0)
+        rc = mdgat_check_hip(hipMalloc(&h->wfrag64, layer_f64_frag_doubles() * (size_t)(2 * cfg->L) * sizeof(double)), "hipMalloc(fp64 weight fragments)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMalloc(split weights)");
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMemset(split weights)");
     if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
@@ -243,6 +249,21 @@ extern "C" int mdgat_load_weights_f64(mdgat_handle* h, const double* blob, size_
         if (int rc = mdgat_check_hip(hipMemcpy(h->weights64, blob, n_doubles * sizeof(double), on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice),
                                      "hipMemcpy(fp64 weights)"))
             return rc;
+    // the layer-tail kernel's copies in fragment order (synchronous, like the copy above)
+    int prev = 0;
+    (void)hipGetDevice(&prev);
+    int rc = mdgat_check_hip(hipSetDevice(h->device), "hipSetDevice");
+    const BlobLayout& bl = h->bl;
+    for (int i = 0; i < 2 * h->cfg.L && !rc; ++i) {
+        const double* lw = h->weights64 + bl.layer0 + (size_t)i * bl.layer_stride;
+        double* lf = h->wfrag64 + layer_f64_frag_doubles() * (size_t)i;
+        rc = launch_frag64(lw + bl.mlp1_w, lf + WF64_W1, 256, 256, nullptr);
+        if (!rc) rc = launch_frag64(lw + bl.mlp2_w, lf + WF64_W2, 128, 256, nullptr);
+        if (!rc) rc = launch_frag64(lw + bl.qkv_w, lf + WF64_QKV, 384, 128, nullptr);
+    }
+    if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "fp64 weight fragments");
+    (void)hipSetDevice(prev);
+    if (rc) return rc;
     h->loaded64 = true;
     return MDGAT_OK;
 }
@@ -252,6 +273,7 @@ extern "C" void mdgat_destroy(mdgat_handle* h) {
     if (h->weights) (void)hipFree(h->weights);
     if (h->wsplit) (void)hipFree(h->wsplit);
     if (h->weights64) (void)hipFree(h->weights64);
+    if (h->wfrag64) (void)hipFree(h->wfrag64);
     if (h->host_error) (void)hipHostFree(h->host_error);
     if (h->lane_stream) { (void)hipStreamSynchronize(h->lane_stream); (void)hipStreamDestroy(h->lane_stream); }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -451,24 +473,43 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         if (taps && taps->x_enc)
             if ((rc = launch_f64_to_f32(ws.x64, taps->x_enc, Rz * 128, nullptr, s))) return rc;
         first = f64_layer_count(h->cfg);
+        // The tail of a layer - mlp.0 + ReLU, mlp.3 + residual (mdgat.py:246-248, 274) - and the NEXT layer's q | k | v projection
+        // (227-232) run as one launch (layer_f64.hip), the hidden activation never leaving the chip; the last fp64 layer's launch
+        // also writes the fp32 rounding of x, the hand-over.  mdgat_set_f64_layer_fusion(0) keeps the three-launch form (bit-identical).
+        const bool fused = layer_f64_fused() && h->wfrag64;
+        bool handed_over = false;
         for (int i = 0; i < first; ++i) {
             const size_t lo = bl.layer0 + (size_t)i * bl.layer_stride;
             // MultiHeadedAttention (mdgat.py:223-237; merge is folded into mlp.0 by pack.py), attention / dynamic_attention (190-210)
-            if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, lo + bl.qkv_w, lo + bl.qkv_b, 0, nullptr, ws.qkv64, 384, 384, 128))) return rc;
-            mark(MDGAT_PROF_F64_GEMM);
+            if (i == 0 || !fused) {
+                if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, lo + bl.qkv_w, lo + bl.qkv_b, 0, nullptr, ws.qkv64, 384, 384, 128))) return rc;
+                mark(MDGAT_PROF_F64_GEMM);
+            }
             uint32_t* sel = (taps && taps->topk_sel) ? taps->topk_sel + (size_t)i * mdgat_topk_sel_words(B, N, M) : nullptr;
             if ((rc = launch_attention_f64(B, N, M, i & 1, h->cfg.topk[i], ws.qkv64, ws.msg64, sel, s, status_dev + MDGAT_STATUS_RANGE))) return rc;
             mark(h->cfg.topk[i] > 0 ? MDGAT_PROF_F64_ATTENTION_TOPK : MDGAT_PROF_F64_ATTENTION_FULL);
             // AttentionalPropagation + residual (mdgat.py:246-248, 274)
-            if ((rc = gemm(ws.x64, 128, 128, ws.msg64, 128, lo + bl.mlp1_w, lo + bl.mlp1_b, 1, nullptr, ws.hid64, 256, 256, 256))) return rc;
-            if ((rc = gemm(ws.hid64, 256, 256, nullptr, 0, lo + bl.mlp2_w, lo + bl.mlp2_b, 0, ws.x64, ws.x64, 128, 128, 256))) return rc;
+            if (fused) {
+                const double* lf = h->wfrag64 + layer_f64_frag_doubles() * (size_t)i;
+                const bool last = i + 1 == first;
+                const LayerF64Args t{ws.x64, ws.msg64, lf + WF64_W1, w64 + lo + bl.mlp1_b, lf + WF64_W2, w64 + lo + bl.mlp2_b,
+                                     last ? nullptr : lf + layer_f64_frag_doubles() + WF64_QKV, last ? nullptr : w64 + lo + bl.layer_stride + bl.qkv_b,
+                                     ws.qkv64, last ? ws.x : nullptr, R, status_dev + MDGAT_STATUS_RANGE};
+                if ((rc = launch_layer_tail_f64(t, s))) return rc;
+                handed_over = last;
+            } else {
+                if ((rc = gemm(ws.x64, 128, 128, ws.msg64, 128, lo + bl.mlp1_w, lo + bl.mlp1_b, 1, nullptr, ws.hid64, 256, 256, 256))) return rc;
+                if ((rc = gemm(ws.hid64, 256, 256, nullptr, 0, lo + bl.mlp2_w, lo + bl.mlp2_b, 0, ws.x64, ws.x64, 128, 128, 256))) return rc;
+            }
             mark(MDGAT_PROF_F64_GEMM);
             if (taps && taps->x_layers)
                 if ((rc = launch_f64_to_f32(ws.x64, taps->x_layers + (size_t)i * Rz * 128, Rz * 128, nullptr, s))) return rc;
         }
         // hand-over: nothing behind the last dynamic layer is discontinuous
-        if ((rc = launch_f64_to_f32(ws.x64, ws.x, Rz * 128, status_dev + MDGAT_STATUS_RANGE, s))) return rc;
-        mark(MDGAT_PROF_F64_OTHER);
+        if (!handed_over) {
+            if ((rc = launch_f64_to_f32(ws.x64, ws.x, Rz * 128, status_dev + MDGAT_STATUS_RANGE, s))) return rc;
+            mark(MDGAT_PROF_F64_OTHER);
+        }
     }
 
     // ---- 2L attentional propagation layers (mdgat.py:259-276) ----

@@ -30,31 +30,10 @@
 //                         after the pass).  Rounding is monotone, so the selection is the fp64 top-k exactly.
 #include "common.hpp"
 #include "f64.hpp"
+#include "f64_dev.hpp"
 #include "row_search.hpp"
 
-typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef double f64x2 __attribute__((ext_vector_type(2)));
-
 namespace {
-
-__device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-
-// Range guard of the exact mode, BETWEEN the layers: every output of an fp64 product (q | k | v, the hidden layer before its ReLU,
-// the residual stream, the encoder stages) and every message row is tested for "not finite, or |v| >= 2^500" by its exponent field,
-// and the call is refused (MDGAT_STATUS_RANGE -> mdgat_async_status / MDGAT.check raise) instead of returning plausible numbers.
-// Why here: this file is compiled with -fno-honor-nans, and the reference's NaN propagation (mdgat.py:192-193: a NaN logit makes
-// the whole row NaN) is not what the hardware does with one - max(NaN, 0) is 0 in a ReLU, v_max_f64 drops a NaN logit from the row
-// maximum and exp_neg clamps it to exp(-745) = 0, so a NaN produced mid-stack (inf - inf in a product or in the online softmax)
-// could come out as a finite, wrong message.  With every q, k, v below 2^500 a logit is a sum of 32 products below 2^1000: finite; the
-// softmax statistics and P.V of finite logits and values are finite.  So the test on the GEMM outputs (before the ReLU, which
-// could swallow a NaN, and after the residual is added) is sufficient, and it sits in the epilogue: two integer instructions per
-// output element, none in the product loops.  (The asm hides the value's floating-point origin: a mask test the compiler can trace
-// back to a double is recognised as a class test and, under the flag, reduced to "is infinite" - a NaN would pass.)
-__device__ __forceinline__ bool f64_out_of_range(double v) {
-    unsigned hi = (unsigned)(__builtin_bit_cast(unsigned long long, v) >> 32);
-    asm("" : "+v"(hi));
-    return (hi & 0x7ff00000u) >= 0x5f300000u;          // biased exponent >= 1523: |v| >= 2^500, inf, NaN
-}
 
 // ================================================================================================ GEMM
 constexpr int G_BM = 64, G_KC = 32;      // row pitch KC + 2 doubles (34: 68 dwords; 66: 132): the 64 lanes of a fragment read (row l15, k g) hit 64 banks
@@ -179,7 +158,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
                 a.C[(size_t)row * a.ldc + n] = v;
             }
     }
-    if (bad && a.guard) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (bad) f64_raise(a.guard);
 }
 
 // ================================================================================================ attention
@@ -581,7 +560,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         }
         const double inv = 1.0 / l;
         o0 *= inv; o1 *= inv;
-        if (a.guard && (f64_out_of_range(o0) || f64_out_of_range(o1))) __hip_atomic_store(a.guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (f64_out_of_range(o0) || f64_out_of_range(o1)) f64_raise(a.guard);
         *reinterpret_cast<f64x2*>(a.msg + ((size_t)b * P + q_off + q0 + q) * 128 + head * 32 + d) = f64x2{o0, o1};
     }
 }
@@ -595,7 +574,6 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 // under the flag, reduced to "is infinite" - measured: a NaN input went through unnoticed.)
 __device__ __forceinline__ bool f64_bits_nonfinite(unsigned long long b) { return (b & 0x7ff0000000000000ull) == 0x7ff0000000000000ull; }
 __device__ __forceinline__ bool f32_bits_nonfinite(unsigned b) { return (b & 0x7f800000u) == 0x7f800000u; }
-__device__ __forceinline__ void f64_raise(unsigned* guard) { if (guard) __hip_atomic_store(guard, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); }
 // encoder inputs (mdgat.py:186-187, 154): in4 [R][4] = x y z saliency, in33 [R][33] = FPFH, rows pair-major (frame 0 then frame 1)
 __global__ __launch_bounds__(256) void assemble_f64_kernel(const double* kpts0, const double* sigma0, const double* fpfh0, const double* kpts1,
                                                             const double* sigma1, const double* fpfh1, double* in4, double* in33, int B, int N, int M,

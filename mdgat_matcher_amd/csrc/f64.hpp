@@ -40,3 +40,21 @@ int launch_assemble_frames_f64(int B, int N, int M, const float* rec0, const flo
                                hipStream_t s);
 // guard (all three): host-mapped status word raised when a value is not finite (tested by its bits), or nullptr
 int launch_f64_to_f32(const double* in, float* out, size_t n, unsigned* guard, hipStream_t s);
+
+// ---- layer_f64.hip: the tail of a propagation layer (mlp.0 + ReLU, mlp.3 + residual, the next layer's q | k | v) as ONE launch ----
+struct LayerF64Args {
+    double* x;                 // [R][128] residual stream, updated in place
+    const double* msg;         // [R][128] the layer's message (attention output; merge is folded into w1)
+    const double *w1f, *b1;    // mlp.0 [256][256] in fragment order (launch_frag64), bias [256]
+    const double *w2f, *b2;    // mlp.3 [128][256]
+    const double *w3f, *b3;    // the NEXT layer's q | k | v projection [384][128], or nullptr (last fp64 layer)
+    double* qkv;               // [R][384] (w3f != nullptr)
+    float* x32;                // optional: the new x rounded to fp32 as well (the hand-over to the fp32-class layers)
+    int R;
+    unsigned* guard;           // as GemmF64Args::guard
+};
+int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s);
+// W [N][K] row-major -> the fragment order layer_tail_f64_kernel loads ([N / 16][K / 8][64 lanes][2]); N % 16 == 0, K % 8 == 0
+int launch_frag64(const double* W, double* out, int N, int K, hipStream_t s);
+size_t layer_f64_frag_doubles();      // per layer: mlp.0 | mlp.3 | q|k|v
+bool layer_f64_fused();               // mdgat_set_f64_layer_fusion / MDGAT_F64_LAYER_FUSION

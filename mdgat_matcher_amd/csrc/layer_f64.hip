@@ -1,0 +1,244 @@
+// Reference-exact mode: the TAIL of a propagation layer in fp64 as one launch -
+//     hid  = ReLU(W1 [x ; msg] + b1)            mlp.0 + folded BN + ReLU   (mdgat.py:246-248; merge folded into W1 by pack.py)
+//     x   += W2 hid + b2                        mlp.3 + residual           (mdgat.py:274)
+//     qkv  = W3 x + b3                          the NEXT layer's q | k | v (mdgat.py:227-232)
+// - what csrc/layer.hip does for the fp32-class path.  The three-launch form (three gemm_f64_kernel launches, f64.hip) writes the
+// hidden activation to memory and reads it back (65 536 x 256 x 8 B = 134 MB each way per layer at batch 64), pays a launch's fixed
+// 12-15 us three times per layer (start, first fetch, tail: profiles/NOTES_r5.md section 7), and at one pair per call (test.py:132)
+// is three dependent launches of a few dozen workgroups each.
+//
+// gfx950 mapping.  A workgroup of eight waves owns TM = 16 NRB keypoints.  The waves split the OUTPUT CHANNELS of each product
+// (16-channel blocks: 2 + 1 + 3 per wave) and every wave multiplies all NRB row blocks, so
+//   * a weight is read ONCE per workgroup, straight from L2 into registers: the matrices are kept a second time in FRAGMENT order
+//     ([channel block][pair of k-steps][lane][2] doubles - launch_frag64), a wave's load instruction is one contiguous KB, and no
+//     weight passes through LDS (1.18 MB per workgroup and layer; the L2s deliver it at a fifth of their rate at batch 64);
+//   * the activations every wave needs - the input tile [x ; msg], then the hidden layer, then the new x - take turns in ONE LDS
+//     buffer of TM x 258 doubles (66 KB at TM = 32: two workgroups per CU): the tile is dead when the hidden layer is complete, the
+//     hidden layer when the new x is; five barriers per workgroup, none inside a product loop;
+//   * v_mfma_f64_16x16x4_f64 with the roles of gemm_f64_kernel (A = activations, B = weights), every accumulator walked through k
+//     in the same order from zero, bias / ReLU / residual applied in the same order: the results are BIT-IDENTICAL to the
+//     three-launch form (tests/test_gpu_f64.py::test_f64_fused_layer_tail_equals_three_launches), which stays for shapes the
+//     kernel does not cover and as the reference of that test (mdgat_set_f64_layer_fusion).
+#include "common.hpp"
+#include "f64.hpp"
+#include "f64_dev.hpp"
+
+namespace {
+
+constexpr int LF_LD = 258;          // row pitch of the LDS tile, doubles: 516 dwords = 4 mod 64 - the 32 lanes of a half-wave fragment read
+                                    // (rows l15, k-slots g = 0, 1) fall on 32 distinct bank pairs
+constexpr int LF_WAVES = 8;
+
+// one product: acc[rb][c] += A[rows of block rb][k] W[channel block cb0 + c][k] over K = 8 JP, W in fragment order from L2, A in LDS.
+// PF: pairs of k-steps the weight loads run ahead (the loads of pair jp + PF are issued into the registers pair jp has just been
+// multiplied from).
+template <int NRB, int NCB, int JP, int PF>
+__device__ __forceinline__ void lf_product(const double* As, const double* wf, int lane, f64x4 (&acc)[NRB][NCB]) {
+    static_assert(JP % PF == 0, "prefetch depth");
+    const int l15 = lane & 15, g = lane >> 4;
+    const double* ap = As + l15 * LF_LD + g;
+    const f64x2* wp = reinterpret_cast<const f64x2*>(wf) + lane;          // channel block c, pair jp: wp[(c * JP + jp) * 64]
+    f64x2 wb[PF][NCB];
+#pragma unroll
+    for (int p = 0; p < PF; ++p)
+#pragma unroll
+        for (int c = 0; c < NCB; ++c) wb[p][c] = wp[(size_t)(c * JP + p) * 64];
+    double a[2][NRB][2];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb) { a[0][rb][0] = ap[rb * 16 * LF_LD]; a[0][rb][1] = ap[rb * 16 * LF_LD + 4]; }
+#pragma unroll 1
+    for (int jp0 = 0; jp0 < JP; jp0 += PF) {
+#pragma unroll
+        for (int p = 0; p < PF; ++p) {
+            const int jp = jp0 + p;
+            // the activations of the next pair of k-steps travel from LDS under this pair's products
+            if (jp + 1 < JP) {
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb) {
+                    a[(p + 1) & 1][rb][0] = ap[rb * 16 * LF_LD + 8 * (jp + 1)];
+                    a[(p + 1) & 1][rb][1] = ap[rb * 16 * LF_LD + 8 * (jp + 1) + 4];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                    for (int c = 0; c < NCB; ++c) acc[rb][c] = mfma64(a[p & 1][rb][t], wb[p][c][t], acc[rb][c]);
+            if (jp + PF < JP) {
+#pragma unroll
+                for (int c = 0; c < NCB; ++c) wb[p][c] = wp[(size_t)(c * JP + jp + PF) * 64];
+            }
+        }
+    }
+}
+
+template <int NRB>
+__global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64Args a) {
+    constexpr int TM = 16 * NRB;
+    extern __shared__ __attribute__((aligned(16))) double lfs[];      // [TM][LF_LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * TM;
+    bool bad = false;
+
+    // ---- input tile [x ; msg] -> LDS (rows beyond R: the last row again; their results are never written) ----
+    for (int e = tid; e < TM * 128; e += 64 * LF_WAVES) {
+        const int r = e >> 7, c = (e & 127) * 2;
+        const int row = min(row0 + r, a.R - 1);
+        const double* src = c < 128 ? a.x + (size_t)row * 128 + c : a.msg + (size_t)row * 128 + (c - 128);
+        *reinterpret_cast<f64x2*>(lfs + r * LF_LD + c) = *reinterpret_cast<const f64x2*>(src);
+    }
+    __syncthreads();
+
+    // ---- hid = ReLU(W1 [x ; msg] + b1): 16 channel blocks, two per wave ----
+    {
+        f64x4 acc[NRB][2];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) { acc[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[rb][1] = acc[rb][0]; }
+        lf_product<NRB, 2, 32, 4>(lfs, a.w1f + (size_t)(2 * wave) * 32 * 128, lane, acc);
+        __syncthreads();                        // every wave has read the tile: the hidden layer takes its place
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            const int n = (2 * wave + c) * 16 + l15;
+            const double bias = a.b1[n];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    double v = acc[rb][c][i] + bias;
+                    bad |= f64_out_of_range(v);
+                    v = v > 0.0 ? v : 0.0;
+                    lfs[(rb * 16 + g + 4 * i) * LF_LD + n] = v;
+                }
+        }
+    }
+    __syncthreads();
+
+    // ---- x += W2 hid + b2: 8 channel blocks, one per wave ----
+    {
+        f64x4 acc[NRB][1];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0};
+        // (the residual rows travel under the product)
+        const int n = wave * 16 + l15;
+        double res[NRB][4];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[rb][i] = a.x[(size_t)min(row0 + rb * 16 + g + 4 * i, a.R - 1) * 128 + n];
+        lf_product<NRB, 1, 32, 4>(lfs, a.w2f + (size_t)wave * 32 * 128, lane, acc);
+        __syncthreads();                        // every wave has read the hidden layer: the new x takes its place
+        const double bias = a.b2[n];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb * 16 + g + 4 * i;
+                double v = acc[rb][0][i] + bias;
+                bad |= f64_out_of_range(v);
+                v += res[rb][i];
+                bad |= f64_out_of_range(v);
+                lfs[r * LF_LD + n] = v;
+                if (row0 + r < a.R) {
+                    a.x[(size_t)(row0 + r) * 128 + n] = v;
+                    if (a.x32) a.x32[(size_t)(row0 + r) * 128 + n] = (float)v;      // the hand-over to the fp32-class layers
+                }
+            }
+    }
+    if (a.w3f) {
+        __syncthreads();
+        // ---- q | k | v of the next layer = W3 x + b3: 24 channel blocks, three per wave ----
+        f64x4 acc[NRB][3];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[rb][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        lf_product<NRB, 3, 16, NRB >= 4 ? 2 : 4>(lfs, a.w3f + (size_t)(3 * wave) * 16 * 128, lane, acc);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int n = (3 * wave + c) * 16 + l15;
+            const double bias = a.b3[n];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + rb * 16 + g + 4 * i;
+                    const double v = acc[rb][c][i] + bias;
+                    bad |= f64_out_of_range(v);
+                    if (row < a.R) a.qkv[(size_t)row * 384 + n] = v;
+                }
+        }
+    }
+    if (bad) f64_raise(a.guard);
+}
+
+// W [N][K] row-major -> fragment order [N / 16][K / 8][64 lanes][2]: lane (l15 = lane & 15, g = lane >> 4) of channel block cb and
+// k-step pair jp holds W[16 cb + l15][8 jp + 4 t + g], t = 0, 1 - the B operand of two consecutive v_mfma_f64_16x16x4_f64
+__global__ __launch_bounds__(256) void frag64_kernel(const double* W, double* out, int N, int K) {
+    const size_t total = (size_t)N * K;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const int t = (int)(e & 1), lane = (int)((e >> 1) & 63);
+        const size_t blk = e >> 7;
+        const int JP = K / 8;
+        const int jp = (int)(blk % JP), cb = (int)(blk / JP);
+        out[e] = W[(size_t)(cb * 16 + (lane & 15)) * K + 8 * jp + 4 * t + (lane >> 4)];
+    }
+}
+
+}  // namespace
+
+size_t layer_f64_frag_doubles() { return (size_t)256 * 256 + 128 * 256 + 384 * 128; }
+
+int launch_frag64(const double* W, double* out, int N, int K, hipStream_t s) {
+    if (N % 16 || K % 8) { mdgat_set_error("launch_frag64: %d x %d is not whole fragments", N, K); return MDGAT_ERR_BAD_ARG; }
+    hipLaunchKernelGGL(frag64_kernel, dim3((N * K + 255) / 256 < 1024 ? (N * K + 255) / 256 : 1024), dim3(256), 0, s, W, out, N, K);
+    return mdgat_check_hip(hipGetLastError(), "frag64 launch");
+}
+
+// 0: three launches per layer tail (gemm_f64_kernel); 1: the fused kernel, rows per workgroup chosen by the launch (default);
+// 16 / 32 / 64: the fused kernel with that many rows per workgroup (tests, measurements).  MDGAT_F64_LAYER_FUSION in the environment.
+static std::atomic<int> g_fusion{-1};
+static int fusion_default() {
+    static const int v = [] { const char* e = getenv("MDGAT_F64_LAYER_FUSION"); const int m = e ? atoi(e) : 1; return (m == 16 || m == 32 || m == 64) ? m : (m != 0); }();
+    return v;
+}
+static int fusion_mode() { const int v = g_fusion.load(std::memory_order_relaxed); return v < 0 ? fusion_default() : v; }
+bool layer_f64_fused() { return fusion_mode() != 0; }
+extern "C" int mdgat_set_f64_layer_fusion(int mode) {
+    const int m = mode < 0 ? -1 : (mode == 16 || mode == 32 || mode == 64) ? mode : (mode != 0);
+    const int prev = g_fusion.exchange(m, std::memory_order_relaxed);
+    return prev < 0 ? fusion_default() : prev;
+}
+
+static int lf_cu_count() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    static std::atomic<int> cached[16];
+    if (dev >= 0 && dev < 16 && (n = cached[dev].load(std::memory_order_relaxed)) > 0) return n;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    if (dev >= 0 && dev < 16) cached[dev].store(n, std::memory_order_relaxed);
+    return n;
+}
+
+int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s) {
+    if (a.R <= 0) return MDGAT_OK;
+    // Rows per workgroup.  32 (two workgroups per CU, four waves per SIMD) from a round of the device on; 16 below - one pair of 512
+    // keypoints is 64 workgroups instead of 32, and a workgroup's chain of products half as long (mdgat_set_f64_layer_fusion(16 | 32 |
+    // 64) forces one).
+    int tm = (long)((a.R + 31) / 32) >= 2L * lf_cu_count() ? 32 : 16;
+    if (fusion_mode() > 1) tm = fusion_mode();
+    const size_t lds = (size_t)tm * LF_LD * sizeof(double);
+    const dim3 grid((a.R + tm - 1) / tm);
+    auto go = [&](auto kern, auto tag) -> int {
+        (void)tag;
+        static std::atomic<unsigned long long> done{0};
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), lds, done, "layer_tail_f64 LDS")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * LF_WAVES), lds, s, a);
+        return mdgat_check_hip(hipGetLastError(), "layer_tail_f64 launch");
+    };
+    if (tm == 16) return go(layer_tail_f64_kernel<1>, std::integral_constant<int, 1>());
+    if (tm == 32) return go(layer_tail_f64_kernel<2>, std::integral_constant<int, 2>());
+    return go(layer_tail_f64_kernel<4>, std::integral_constant<int, 4>());
+}

@@ -265,6 +265,44 @@ def test_literal_bar_on_the_reference_held_variants(golden_dir, name):
     assert checked >= 2
 
 
+@pytest.mark.parametrize('B,n,m,L,k', [(1, 512, 512, 3, [128, None, 64, None]), (3, 100, 77, 2, [16, None, 8, None]), (20, 512, 512, 2, [64, None]),
+                                       (2, 1000, 1030, 2, [64, 32, None, 16]), (5, 33, 47, 4, [None, 8, 4, None])])
+def test_f64_fused_layer_tail_equals_three_launches(B, n, m, L, k):
+    """csrc/layer_f64.hip (mlp.0 -> ReLU -> mlp.3 -> + x -> next q | k | v in one launch, the hidden activation in LDS, the weights in
+    fragment order straight from L2) against the three gemm_f64_kernel launches it replaces: every accumulator walks k in the same
+    order, so EVERY output bit is the same - matches, scores, Z, and the fp32 taps of every layer's descriptors - for each tile height
+    (16 / 32 / 64 keypoints per workgroup), ragged keypoint counts, one pair and a batch large enough to run in slices."""
+    from mdgat_matcher_amd import _lib
+    lib = _lib.load()
+    cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=10)
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=L, seed=21))
+    net = net.eval().to(DEV)
+    assert net.exact()
+    d = synth.make_batch(B, n, m, device=DEV, first_pair=40)
+    P = n + m
+
+    def run(mode, taps):
+        prev = lib.mdgat_set_f64_layer_fusion(mode)
+        try:
+            t = {'x_layers': torch.zeros(2 * L, B, P, 128, device=DEV)} if taps else None
+            out = net._run(d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'], want_Z=True, taps=t)
+            torch.cuda.synchronize()
+            net.check(DEV)
+            return out, t
+        finally:
+            lib.mdgat_set_f64_layer_fusion(-1)
+            assert prev in (0, 1, 16, 32, 64)
+    for taps in (False, True):          # (taps run the whole batch unsliced)
+        ref, rt = run(0, taps)
+        for mode in (1, 16, 32, 64):
+            out, ot = run(mode, taps)
+            for a, b, what in zip(ref, out, ('matches0', 'matches1', 'mscores0', 'mscores1', 'Z')):
+                assert torch.equal(a, b), (mode, taps, what)
+            if taps:
+                assert torch.equal(rt['x_layers'], ot['x_layers']), mode
+
+
 def test_f64_dict_api_slices_and_errors():
     """forward(dict) in the exact mode: a batch large enough to run in slices on two lanes equals the pairs run alone; fp32
     entry points refuse an fp64 handle."""

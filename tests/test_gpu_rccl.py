@@ -26,7 +26,7 @@ rank, world, local = shard.init_distributed(1)
 assert dist.is_initialized() and dist.get_backend() == 'nccl' and world == 1, (dist.is_initialized(), world)
 dev = torch.device('cuda', local)
 L = 3
-cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=30)
+cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=30, arithmetic='fp32')      # the throughput path of a sharded job (bench.py)
 sd = synth.make_state_dict(L=L, seed=7)
 src = MDGAT(cfg); src.load_state_dict(sd); src = src.eval().to(dev)
 d = synth.make_batch(3, 200, 256, device=dev, dtype=torch.float32)
@@ -45,6 +45,24 @@ net = net.double().eval()                           # test.py:193 - the installe
 out = net.match(*args, return_scores=True)
 for a, b in zip(ref, out):
     assert torch.equal(a, b)
+# a module whose arithmetic follows its dtype (no 'arithmetic' key, like the reference's callers): BOTH blobs travel, and the cast of
+# test.py:193 after the broadcast switches the rank to the reference-exact mode on rank 0's weights
+cfg_auto = {k: v for k, v in cfg.items() if k != 'arithmetic'}
+src64 = MDGAT(cfg_auto).double(); src64.load_state_dict(sd); src64 = src64.eval().to(dev)
+assert src64.exact()
+ref64 = src64.match(*args, return_scores=True)
+net2 = MDGAT(cfg_auto).eval().to(dev)               # random init, float32
+if rank == 0:
+    net2 = net2.double(); net2.load_state_dict(sd)
+got64 = []
+shard.broadcast_weights(net2, dev, rank, world, out64=got64)
+assert len(got64) == 1 and got64[0].dtype == torch.float64 and got64[0].is_cuda
+net2 = net2.double().eval()
+assert net2.exact()
+out64 = net2.match(*args, return_scores=True)
+for a, b in zip(ref64, out64):
+    assert torch.equal(a, b)
+net2.check(dev)
 shard.barrier(world)
 t = shard.max_over_ranks(1.25, dev, world)          # all-reduce(MAX) on a device tensor
 assert t == 1.25
