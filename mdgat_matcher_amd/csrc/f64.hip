@@ -32,6 +32,7 @@
 #include "f64.hpp"
 #include "f64_dev.hpp"
 #include "row_search.hpp"
+#include "exp2_tab256.hpp"
 
 namespace {
 
@@ -171,37 +172,43 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int m) {
 __device__ __forceinline__ double quad_max(double v) { v = fmax(v, shfl_xor_f64(v, 16)); return fmax(v, shfl_xor_f64(v, 32)); }
 __device__ __forceinline__ double quad_sum(double v) { v += shfl_xor_f64(v, 16); return v + shfl_xor_f64(v, 32); }
 
-// exp(x) for x <= 0 (or -inf): the softmax numerators.  n = rint(x / ln 2), exp(x - n ln 2) by its Taylor polynomial of degree 12
-// on |r| <= 0.347 (truncation 1.7e-16 relative), scaled by v_ldexp_f64 - 19 fp64-rate instructions, a third of the library
-// routine's, which also serves arguments these kernels never have.  -inf (masked keys) and everything below -745 give 0.
-// p r + c with the coefficient c in a SCALAR register pair, as ONE VOP3 instruction.  Written through the compiler, the ten
-// coefficients sit in twenty vector registers and, in the rescaling branch of the online softmax, each is copied before a
-// two-address v_fmac (18 v_mov_b64 per loop iteration of the full-attention kernel).
-__device__ __forceinline__ double fma_sc(double p, double r, double c) {
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(r), "s"(c));
-    return d;
+// exp(x) for the softmax numerators: x <= TAU_LAZY (x <= 0 except under the lazy reference of the full-attention loop), -inf for
+// masked keys.  Table-driven: x = (256 q + j) ln2 / 256 + r, |r| <= ln2 / 512 = 1.35e-3,
+//     exp(x) = 2^q T[j] (1 + r + r^2 / 2 + r^3 / 6 + r^4 / 24),      T[j] = 2^(j / 256) correctly rounded, 2 KB of LDS (exp2_tab256.hpp)
+// (truncation r^5 / 120 = 3.8e-17).  n = 256 q + j falls out of the low word of x (256 / ln 2) + 1.5 2^52, the reduction is ONE fma
+// against the correctly rounded ln2 / 256 (its rounding error acts like a relative perturbation of x by 2^-53: an ulp of the logit
+// itself), the polynomial is a product and three fmas with at most one scalar operand each, the table entry gets 2^q by an integer
+// add to its exponent field (safe: x is clamped to -700, so q >= -1010) and one last fma scales.  Nine fp64 and four integer
+// instructions and a ds_read_b64; the degree-12 polynomial + v_ldexp form this replaces ran 19 (+ a v_mov_b64 the compiler
+// rematerialised for the leading coefficient) - on this part an fp64 vector instruction issues in the slot of a sixteenth of a
+// v_mfma_f64_16x16x4 and the two share the pipe (profiles/NOTES_r5.md section 1), so the attention loops are their vector
+// instruction count.  Keys masked with -inf get exp(-700) = 1e-304 instead of 0: nothing against a row's largest term, which is 1.
+typedef __attribute__((address_space(3))) const double lds_cdouble;
+struct ExpConst { double magic; };        // 1.5 2^52 held in a vector register pair for the whole kernel (the fma that uses it has its one
+                                          // scalar slot taken by 256 / ln 2; left to the compiler the constant is rematerialised per call)
+__device__ __forceinline__ ExpConst exp_const() {
+    double m = 0x1.8p+52;
+    asm volatile("" : "+v"(m));
+    return ExpConst{m};
 }
-
-__device__ __forceinline__ double exp_neg(double x) {
-    x = fmax(x, -745.5);
-    const double n = __builtin_rint(x * 1.4426950408889634);
-    double r = __builtin_fma(n, -0.6931471805599453, x);
-    r = __builtin_fma(n, -2.3190468138462996e-17, r);
-    double p = fma_sc(2.08767569878681e-09, r, 2.505210838544172e-08);     // 1 / 12!, 1 / 11!
-    p = fma_sc(p, r, 2.755731922398589e-07);     // 1 / 10!
-    p = fma_sc(p, r, 2.7557319223985893e-06);    // 1 / 9!
-    p = fma_sc(p, r, 2.48015873015873e-05);      // 1 / 8!
-    p = fma_sc(p, r, 0.0001984126984126984);     // 1 / 7!
-    p = fma_sc(p, r, 0.001388888888888889);      // 1 / 6!
-    p = fma_sc(p, r, 0.008333333333333333);      // 1 / 5!
-    p = fma_sc(p, r, 0.041666666666666664);      // 1 / 4!
-    p = fma_sc(p, r, 0.16666666666666666);       // 1 / 3!
-    p = __builtin_fma(p, r, 0.5);
-    p = __builtin_fma(p, r, 1.0);
-    p = __builtin_fma(p, r, 1.0);
-    return ldexp(p, (int)n);
+__device__ __forceinline__ double exp_fast(double x, const double* tab_, const ExpConst& ec) {
+    lds_cdouble* tab = (lds_cdouble*)tab_;
+    x = fmax(x, -700.0);
+    double tm, r, a, b, s;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(tm) : "v"(x), "s"(0x1.71547652b82fep+8), "v"(ec.magic));       // x 256 / ln 2 + 1.5 2^52
+    const int n = (int)(unsigned)__builtin_bit_cast(unsigned long long, tm);
+    const double nd = tm - ec.magic;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(nd), "s"(-0x1.62e42fefa39efp-9), "v"(x));              // x - n ln2 / 256
+    const double r2 = r * r;
+    asm("v_fma_f64 %0, %1, %2, 0.5" : "=v"(a) : "v"(r), "s"(0x1.5555555555555p-3));                        // 1/2 + r / 6
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(b) : "v"(r2), "s"(0x1.5555555555555p-5), "v"(a));               // ... + r^2 / 24
+    s = __builtin_fma(r2, b, r);                                                                          // exp(r) - 1
+    const unsigned long long tb = __builtin_bit_cast(unsigned long long, tab[n & 255]);
+    const unsigned hi = (unsigned)(tb >> 32) + (((unsigned)n & 0xffffff00u) << 12);                       // exponent + (n >> 8)
+    const double T = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)tb);
+    return __builtin_fma(T, s, T);
 }
+constexpr double TAU_LAZY = 8.0;          // full attention: the running reference of a row moves only when a logit exceeds it by this much
 
 constexpr int A_LIST = 32;        // logits tied (as fp32 roundings) at the k-th place that are ranked by their fp64 values; more: key order
 struct RowSel { float thr; int mode; int aux; int pad; };
@@ -221,6 +228,7 @@ __device__ RowSel f64_row_select(const float* row, int nk, int k, float zq, int 
 // LDS carve of the attention kernel.  The rounding images (dynamic layers) are dead once the rows have been searched - pass B
 // recomputes the logits - so the output partials of the final combine share their space.
 struct AttnLds {
+    double* tab;         // [256] 2^(j / 256) (exp_fast)
     double* obuf;        // [4 waves][QT][32]
     double* mw;          // [4][QT] row maxima per wave
     double* lw;          // [4][QT] row sums per wave
@@ -231,8 +239,9 @@ struct AttnLds {
     int* hist;           // [4 waves][RS_HIST_INTS] radix-select histograms (row_search.hpp)
     float* img;          // [QT][imgld]  (aliases obuf)
 };
-__device__ __forceinline__ AttnLds attn_lds(double* base, int QT, bool topk) {
+__device__ __forceinline__ AttnLds attn_lds(double* base, int QT, bool topk, int hist_ints) {
     AttnLds s;
+    s.tab = base; base += 256;
     s.mw = base; base += 4 * QT;
     s.lw = base; base += 4 * QT;
     if (!topk) {         // full attention: the row statistics and the output partials only (34 KB at 32 queries: four workgroups per CU)
@@ -245,14 +254,21 @@ __device__ __forceinline__ AttnLds attn_lds(double* base, int QT, bool topk) {
     s.lcount = s.lkey + QT * A_LIST;
     s.sel = reinterpret_cast<RowSel*>(s.lcount + QT);
     s.hist = reinterpret_cast<int*>(s.sel + QT);
-    s.obuf = reinterpret_cast<double*>(s.hist + 4 * RS_HIST_INTS);
+    s.obuf = reinterpret_cast<double*>(s.hist + hist_ints);
     s.img = reinterpret_cast<float*>(s.obuf);
     return s;
 }
-size_t attn_lds_bytes(int QT, int nk_max, bool topk) {
+// Histograms of the row select.  One row per wave (more than 512 keys): RS_HIST_INTS per wave.  Four rows per wave (topk_quad_search,
+// at most 512 keys): a row's histogram lives in the row's own rounding image (every value is in registers before the first clear)
+// whenever the image row is long enough - more than 256 keys; launches with a frame of at most 256 keys get a region of their own.
+int attn_hist_ints(int nk_min, int nk_max) {
+    if (nk_max > 512) return 4 * RS_HIST_INTS;
+    return ((nk_min + 63) & ~63) + 4 >= RQ_HIST_INTS ? 16 : 16 * RQ_HIST_INTS;
+}
+size_t attn_lds_bytes(int QT, int nk_max, bool topk, int hist_ints) {
     const size_t ob = (size_t)4 * QT * 32 * 8;
-    if (!topk) return (size_t)8 * QT * 8 + ob;
-    const size_t fixed = ((size_t)8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel) + 4 * RS_HIST_INTS * 4;
+    if (!topk) return (size_t)(256 + 8 * QT) * 8 + ob;
+    const size_t fixed = ((size_t)256 + 8 * QT + (size_t)QT * A_LIST) * 8 + ((size_t)QT * A_LIST + QT) * 4 + (size_t)QT * sizeof(RowSel) + (size_t)hist_ints * 4;
     const size_t im = topk ? (size_t)QT * (((nk_max + 63) & ~63) + 4) * 4 : 0;
     return fixed + (ob > im ? ob : im);
 }
@@ -266,7 +282,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
     static_assert(!KEEP || (TOPK && QB == 1), "KEEP: dynamic attention, one query block");
     constexpr int QT = 16 * QB;
     extern __shared__ __attribute__((aligned(16))) double asmem[];
-    const AttnLds sm = attn_lds(asmem, QT, TOPK);
+    const AttnLds sm = attn_lds(asmem, QT, TOPK, a.hist_ints);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, g = lane >> 4;
@@ -282,6 +298,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
     const int nk = src ? a.M : a.N, k_off = src ? a.N : 0;
     const int q0 = tile * QT;
     if (q0 >= nq) return;
+    sm.tab[tid] = MDGAT_EXP2_TAB256[tid];        // (256 threads)
+    if (!TOPK) __syncthreads();                  // (the dynamic kernels pass two barriers before their first exponential)
+    const ExpConst ec = exp_const();
     const int imgld = ((nk + 63) & ~63) + 4;
     const double* kbase = a.qkv + ((size_t)b * P + k_off) * 384 + 128 + head * 32;
     const double* vbase = kbase + 128;
@@ -321,7 +340,8 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = mfma64(kf[j], qf[qb][j], acc);
-        if (jb * 16 + 16 > nk) {
+        if (jb * 16 + 16 > nk) {          // (the last block of a ragged frame only: a scalar branch - the asm keeps the compiler from turning it
+            asm volatile("");             // into eight selects in every trip)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
                 if (jb * 16 + g + 4 * r >= nk) acc[r] = -__builtin_inf();
@@ -331,12 +351,17 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
     f64x4 O[QB][2];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) { O[qb][0] = f64x4{0.0, 0.0, 0.0, 0.0}; O[qb][1] = O[qb][0]; }
-    double lsum[QB], mrun[QB];
+    double lsum[QB], mrun[QB], mthr[QB];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) { lsum[qb] = 0.0; mrun[qb] = -__builtin_inf(); }
+    for (int qb = 0; qb < QB; ++qb) { lsum[qb] = 0.0; mrun[qb] = -__builtin_inf(); mthr[qb] = -__builtin_inf(); }
 
     if (!TOPK) {
         // ---- full attention: online softmax over this wave's blocks ----
+        // LAZY reference.  The exponentials of a row are taken against a reference mrun that only moves when a logit exceeds it by
+        // more than TAU_LAZY (numerators up to e^8 instead of 1: harmless in fp64, and o / l does not depend on the reference).  The
+        // test is lane-local - this lane's four logits against mrun + TAU_LAZY, one wave-uniform branch - so the common trip has
+        // no cross-lane row maximum (two 64-bit shuffles through the LDS crossbar per query block, each waited for) and no
+        // rescaling (an exponential and nine products per query block); after the first few blocks of a wave it is rarely taken.
         // (the next block's K fragments are requested into the SAME registers as soon as this block's Q K^T products are issued and
         // travel under the softmax and P V: a second register set copied at the top of the trip cost sixteen v_mov_b64 per block)
         double kf[8];
@@ -351,20 +376,21 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const f64x4 S = Sq[qb];
-                const double mb = quad_max(fmax(fmax(S[0], S[1]), fmax(S[2], S[3])));
-                const double mnew = fmax(mrun[qb], mb);
-                if (__any(mnew != mrun[qb])) {                    // (after the first blocks the running maximum rarely moves)
-                    const double sc = exp_neg(mrun[qb] - mnew);   // (first block: exp(-inf) = 0)
+                const double lm = fmax(fmax(S[0], S[1]), fmax(S[2], S[3]));
+                if (__any(lm > mthr[qb])) {
+                    const double mnew = fmax(mrun[qb], quad_max(lm));
+                    const double sc = exp_fast(mrun[qb] - mnew, sm.tab, ec);   // (rows that stay: exp(0) = 1 exactly; first block: 1e-304 x 0)
                     lsum[qb] *= sc;
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) O[qb][t][r] *= sc;
+                    mrun[qb] = mnew;
+                    mthr[qb] = mnew + TAU_LAZY;
                 }
-                mrun[qb] = mnew;
                 f64x4 p;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) p[r] = exp_neg(S[r] - mnew);
+                for (int r = 0; r < 4; ++r) p[r] = exp_fast(S[r] - mrun[qb], sm.tab, ec);
                 lsum[qb] += (p[0] + p[1]) + (p[2] + p[3]);
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
@@ -418,7 +444,26 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             if (tid < QT) sm.lcount[tid] = 0;
         }
         __syncthreads();
-        // ---- the exact k-th largest rounding of every row: one wave per row ----
+        // ---- the exact k-th largest rounding of every row ----
+        if (KEEP) {
+            // at most 512 keys: the wave's four rows (4 wave .. 4 wave + 3) side by side, sixteen lanes each (row_search.hpp)
+#ifndef F64_KO_SEARCH
+            const float* rows = sm.img + 4 * wave * imgld;
+            const bool own_space = imgld >= RQ_HIST_INTS;
+            int* hb = own_space ? reinterpret_cast<int*>(sm.img + 4 * wave * imgld) : sm.hist + wave * 4 * RQ_HIST_INTS;
+            const int hp = own_space ? imgld : RQ_HIST_INTS;
+            const RowSearch r = nk <= 128 ? topk_quad_search<8>(rows, imgld, nk, a.topk, a.zq, lane, A_LIST, hb, hp)
+                              : nk <= 256 ? topk_quad_search<16>(rows, imgld, nk, a.topk, a.zq, lane, A_LIST, hb, hp)
+                                          : topk_quad_search<32>(rows, imgld, nk, a.topk, a.zq, lane, A_LIST, hb, hp);
+            RowSel rs;
+            if (a.topk >= nk || r.c_ge == a.topk) rs = RowSel{r.thr, 0, 0, 0};
+            else if (r.c_ge - r.c_gt <= A_LIST) rs = RowSel{r.thr, 2, a.topk - r.c_gt, 0};
+            else rs = RowSel{r.thr, 1, r.keylim, 0};
+            if ((lane & 15) == 0) sm.sel[4 * wave + (lane >> 4)] = rs;
+#else
+            if (lane < 4) sm.sel[4 * wave + lane] = RowSel{0.f, 0, 0, 0};
+#endif
+        } else
         for (int q = wave; q < QT; q += 4) {
             const float* row = sm.img + q * imgld;
             int* hist = sm.hist + wave * RS_HIST_INTS;
@@ -460,7 +505,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                     }
                 }
                 keep = keep && key < nk;
-                p[r] = keep ? exp_neg(S[r] - mrun[qb]) : 0.0;
+                p[r] = keep ? exp_fast(S[r] - mrun[qb], sm.tab, ec) : 0.0;
                 bits |= (unsigned)keep << (4 * r);        // keys 16 jb + g + 4 r
             }
             if (TAP && bits && q0 + qb * 16 + l15 < nq) atomicOr(tap[qb] + (jb >> 1), bits << (16 * (jb & 1) + g));
@@ -543,7 +588,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
 #pragma unroll
         for (int w = 0; w < 4; ++w) {
             const double mwv = sm.mw[w * QT + q];
-            const double f = TOPK ? 1.0 : (mwv == -__builtin_inf() ? 0.0 : exp_neg(mwv - m));
+            const double f = TOPK ? 1.0 : (mwv == -__builtin_inf() ? 0.0 : exp_fast(mwv - m, sm.tab, ec));
             l += f * sm.lw[w * QT + q];
             o0 += f * sm.obuf[((size_t)w * QT + q) * 32 + d];
             o1 += f * sm.obuf[((size_t)w * QT + q) * 32 + d + 1];
@@ -553,7 +598,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             for (int j = 0; j < n; ++j) {
                 const int kj = sm.lkey[q * A_LIST + j];
                 if (kj >= 0) continue;
-                const double p = exp_neg(sm.lS[q * A_LIST + j] - m);
+                const double p = exp_fast(sm.lS[q * A_LIST + j] - m, sm.tab, ec);
                 const f64x2 v = *reinterpret_cast<const f64x2*>(vbase + (size_t)(kj & 0x7fffffff) * 384 + d);
                 l += p; o0 += p * v[0]; o1 += p * v[1];
             }
@@ -794,8 +839,9 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
     auto go = [&](auto kern, int QT, bool tk, int cap, auto tag) -> int {
         (void)tag;
         static std::atomic<unsigned long long> done{0};
-        const size_t lds = attn_lds_bytes(QT, nk_max, tk);
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), attn_lds_bytes(QT, cap, tk), done, "attention_f64 LDS")) return rc;
+        a.hist_ints = tk ? attn_hist_ints(nk_min, nk_max) : 0;
+        const size_t lds = attn_lds_bytes(QT, nk_max, tk, a.hist_ints);
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), attn_lds_bytes(QT, cap, tk, tk ? (cap > 512 ? 4 * RS_HIST_INTS : 16 * RQ_HIST_INTS) : 0), done, "attention_f64 LDS")) return rc;
         a.tiles = (nk_max + QT - 1) / QT;
         hipLaunchKernelGGL(kern, dim3(8 * a.tiles * ugroups), dim3(256), lds, s, a);
         return mdgat_check_hip(hipGetLastError(), "attention_f64 launch");

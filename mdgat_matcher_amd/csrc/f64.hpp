@@ -28,6 +28,7 @@ struct AttnF64Args {
     uint32_t* sel;         // parity tap (mdgat_taps.topk_sel layout) or nullptr
     int selW;
     int units, tiles;      // B * 2 * 4 (pair, frame, head) units; query tiles per unit
+    int hist_ints;         // dynamic attention: ints of LDS for the radix-select histograms (attn_hist_ints in f64.hip)
     unsigned* guard;       // as GemmF64Args::guard, for the message rows
 };
 // attention (topk == 0) / dynamic_attention (mdgat.py:190-210) on fp64 q / k / v; sel: optional tap of the kept keys

@@ -164,3 +164,136 @@ __device__ RowSearch topk_row_search(const float* row_, int nk, int k, float zq,
     out.keylim = keylim;
     return out;
 }
+
+// ---- four rows per wave at once (rows of at most 512 values) ------------------------------------------------------------------
+// The same radix select with a row on SIXTEEN lanes (a DPP row) and the four rows of a wave side by side in one instruction
+// stream.  One row per wave (above) is a chain of latencies - four DPP reductions, then per level LDS clear -> atomics -> wait ->
+// read -> scan -> three readlanes - paid four times over, one row after the other, between the two barriers of a tile
+// (profiles/NOTES_r5.md section 10: the select is 31 % of the 512-key dynamic kernel and it is latency, not issue).  Here every step
+// serves four rows: the reductions are rotations inside the DPP row (every lane ends up with the row's value: no readlane), a
+// level is ONE round trip for the four histograms, and rows that need another level or restart from their minimum simply stay
+// active (per-lane control flow; each row's histogram is its own LDS region, so rows never meet).
+// Lane s of a row holds the values s, s + 16, s + 32, ...: NV per lane, nk <= 16 NV.
+template <typename Op>
+__device__ __forceinline__ int rq_allreduce(int v, Op op) {      // over the 16 lanes of a DPP row, by rotations: every lane gets the result
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x128, 0xf, 0xf, false));      // row_ror:8
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x124, 0xf, 0xf, false));      // row_ror:4
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x122, 0xf, 0xf, false));      // row_ror:2
+    v = op(v, __builtin_amdgcn_update_dpp(v, v, 0x121, 0xf, 0xf, false));      // row_ror:1
+    return v;
+}
+__device__ __forceinline__ int rq_sum(int v) { return rq_allreduce(v, [](int a, int b) { return a + b; }); }
+__device__ __forceinline__ unsigned rq_max_u(unsigned v) { return (unsigned)rq_allreduce((int)v, [](int a, int b) { return (int)max((unsigned)a, (unsigned)b); }); }
+__device__ __forceinline__ unsigned rq_min_u(unsigned v) { return (unsigned)rq_allreduce((int)v, [](int a, int b) { return (int)min((unsigned)a, (unsigned)b); }); }
+__device__ __forceinline__ float rq_sum_f(float v) {
+    auto f = [](int x) { return __builtin_bit_cast(float, x); };
+    return f(rq_allreduce(__builtin_bit_cast(int, v), [&](int a, int b) { return __builtin_bit_cast(int, f(a) + f(b)); }));
+}
+// inclusive suffix sum over the row: lane s gets the sum over lanes s .. 15 (row_shl:n reads lane s + n; beyond the row: 0)
+__device__ __forceinline__ int rq_suffix_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x102, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x108, 0xf, 0xf, false);
+    return v;
+}
+// this row's 16 bits of a wave ballot
+__device__ __forceinline__ unsigned rq_row_bits(unsigned long long ballot, int lane) { return (unsigned)(ballot >> (lane & 48)) & 0xffffu; }
+
+constexpr int RQ_HIST_INTS = 272;       // per row: 256 bins + one waste bin per lane
+// rows: the wave's four rows in LDS, `pitch` floats apart (row r of the wave = lanes 16 r .. 16 r + 15); hist: 4 x RQ_HIST_INTS ints of LDS
+// owned by this wave (it may be the rows' own storage: every value is in registers before the first histogram is cleared, and the
+// LDS serves a wave's accesses in order).  Every lane returns its row's answer.
+template <int NV>
+__device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int k, float zq, int lane, int list_cap, int* hist_, int hist_pitch) {
+    const int s = lane & 15, rw = lane >> 4;
+    rs_lds_cfloat* row = (rs_lds_cfloat*)rows_ + rw * pitch;
+    unsigned o[NV];                      // pads: 0, below the image of every float
+    unsigned omn = ~0u, omx = 0u;
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int idx = s + 16 * i;
+        const float f = idx < nk ? row[idx] + 0.f : 0.f;
+        o[i] = idx < nk ? f2ord(f) : 0u;
+        omn = min(omn, idx < nk ? o[i] : ~0u); omx = max(omx, o[i]);
+        if (i % 4 == 0) { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+    }
+    omn = rq_min_u(omn); omx = rq_max_u(omx);
+    RowSearch out{-__builtin_inff(), nk, 0, ord2f(omx), 1 << 30};
+    if (k >= nk) return out;             // (the same for every row of the launch)
+    rs_lds_int* hist = (rs_lds_int*)hist_ + rw * hist_pitch;
+    unsigned base = omn;
+    {
+        s1 = rq_sum_f(s1); s2 = rq_sum_f(s2);
+        const float inv_n = 4.0f / (float)nk;
+        const float mu = s1 * inv_n;
+        const float sd = sqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f));
+        const unsigned cand = f2ord(mu + (zq - 1.0f) * sd);
+        if (cand > omn && cand < omx) base = cand;
+    }
+    int sh = 24 - __builtin_clz((omx - base) | 0xffu);
+    int above = 0, ceq = 0;
+    unsigned width = 256u;
+    for (;;) {
+        typedef int rq_i4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) rq_i4 rq_lds_int4;
+        rq_lds_int4* h4 = (rq_lds_int4*)hist;
+        h4[4 * s] = rq_i4{0, 0, 0, 0}; h4[4 * s + 1] = rq_i4{0, 0, 0, 0}; h4[4 * s + 2] = rq_i4{0, 0, 0, 0}; h4[4 * s + 3] = rq_i4{0, 0, 0, 0};
+        hist[256 + s] = 0;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const unsigned d = (o[i] - base) >> sh;
+            __atomic_fetch_add(hist + ((o[i] >= base && d < width) ? (int)d : 256 + s), 1, __ATOMIC_RELAXED);
+        }
+        // stage 1: this lane's sixteen bins (16 s .. 16 s + 15) as one count; the lane whose bins hold the k-th largest
+        const rq_i4 ha = h4[4 * s], hb = h4[4 * s + 1], hc = h4[4 * s + 2], hd = h4[4 * s + 3];
+        const int t = (ha.x + ha.y + ha.z + ha.w) + (hb.x + hb.y + hb.z + hb.w) + (hc.x + hc.y + hc.z + hc.w) + (hd.x + hd.y + hd.z + hd.w);
+        const int suf = rq_suffix_sum(t);
+        const int tot = rq_sum(t);
+        if (above + tot < k) {           // (first level only: fewer than k values above the start - not a bell-shaped row)
+            base = omn;
+            sh = 24 - __builtin_clz((omx - omn) | 0xffu);
+            continue;
+        }
+        const int al = above + suf - t;                              // values in play above this lane's bins
+        const bool own = al < k && k <= al + t;                      // exactly one lane of the row
+        const int ls = __builtin_ctz(rq_row_bits(__ballot(own), lane) | 0x10000u);
+        const int as = rq_sum(own ? al : 0);
+        // stage 2: that lane's sixteen bins, one per lane
+        const int h1 = hist[16 * ls + s];
+        const int a1 = as + rq_suffix_sum(h1) - h1;
+        const bool own1 = a1 < k && k <= a1 + h1;
+        const int bin = 16 * ls + __builtin_ctz(rq_row_bits(__ballot(own1), lane) | 0x10000u);
+        above = rq_sum(own1 ? a1 : 0);
+        ceq = rq_sum(own1 ? h1 : 0);
+        base += (unsigned)bin << sh;
+        if (sh == 0) break;                                          // the bin is one value: `ceq` values equal it
+        if (ceq == 1) {                                              // one value left in play: it is the k-th largest
+            unsigned m = 0u;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) m = max(m, (o[i] >= base && ((o[i] - base) >> sh) == 0u) ? o[i] : 0u);
+            base = rq_max_u(m);
+            break;
+        }
+        width = sh >= 8 ? 256u : 1u << sh;
+        sh = sh > 8 ? sh - 8 : 0;
+    }
+    out.thr = ord2f(base); out.c_gt = above; out.c_ge = above + ceq;
+    if (out.c_ge == k || ceq <= list_cap) return out;
+    // more than list_cap values share the k-th place: the first k - c_gt of them in key order stay (key = s + 16 i)
+    const int need = k - above;
+    int seen = 0, keylim = nk;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        unsigned mask = rq_row_bits(__ballot(o[i] == base), lane);
+        const int c = __popc(mask);
+        if (keylim == nk && seen + c >= need) {
+            for (int n = need - seen; n > 1; --n) mask &= mask - 1;
+            keylim = 16 * i + __builtin_ctz(mask);
+        }
+        seen += c;
+    }
+    out.keylim = keylim;
+    return out;
+}
