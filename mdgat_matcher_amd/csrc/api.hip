@@ -140,8 +140,9 @@ extern "C" int mdgat_create(const mdgat_config* cfg, int device, mdgat_handle** 
     int rc = mdgat_check_hip(hipSetDevice(device), "hipSetDevice");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->weights, h->bl.total * sizeof(float)), "hipMalloc(weights)");
     if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64) rc = mdgat_check_hip(hipMalloc(&h->weights64, h->bl.total * sizeof(double)), "hipMalloc(fp64 weights)");
-    if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64 && cfg->L > 0)
-        rc = mdgat_check_hip(hipMalloc(&h->wfrag64, layer_f64_frag_doubles() * (size_t)(2 * cfg->L) * sizeof(double)), "hipMalloc(fp64 weight fragments)");
+    if (!rc && cfg->arithmetic == MDGAT_ARITH_FP64)
+        rc = mdgat_check_hip(hipMalloc(&h->wfrag64, (layer_f64_frag_doubles() * (size_t)(2 * cfg->L) + encoder_f64_frag_doubles()) * sizeof(double)),
+                             "hipMalloc(fp64 weight fragments)");
     if (!rc) rc = mdgat_check_hip(hipMalloc(&h->wsplit, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMalloc(split weights)");
     if (!rc) rc = mdgat_check_hip(hipMemset(h->wsplit, 0, (wsplit_halves(cfg->L) + wfrag_halves(cfg->L)) * sizeof(_Float16)), "hipMemset(split weights)");
     if (!rc) rc = mdgat_check_hip(hipHostMalloc(reinterpret_cast<void**>(&h->host_error), MDGAT_STATUS_WORDS * sizeof(unsigned), hipHostMallocMapped), "hipHostMalloc(status words)");
@@ -260,6 +261,17 @@ extern "C" int mdgat_load_weights_f64(mdgat_handle* h, const double* blob, size_
         rc = launch_frag64(lw + bl.mlp1_w, lf + WF64_W1, 256, 256, nullptr);
         if (!rc) rc = launch_frag64(lw + bl.mlp2_w, lf + WF64_W2, 128, 256, nullptr);
         if (!rc) rc = launch_frag64(lw + bl.qkv_w, lf + WF64_QKV, 384, 128, nullptr);
+    }
+    {
+        // the encoder matrices behind the layers': kenc.0 | denc.0 | kenc.3 | kenc.6 | denc.3 | last layers summed (EncFrag below)
+        double* ef = h->wfrag64 + layer_f64_frag_doubles() * (size_t)(2 * h->cfg.L);
+        const double* w = h->weights64;
+        const struct { size_t src; int n, k; } enc[6] = {{bl.kenc0_w, 32, 4}, {bl.denc0_w, 64, 33}, {bl.kenc1_w, 64, 32}, {bl.kenc2_w, 128, 64},
+                                                         {bl.denc1_w, 128, 64}, {bl.encl_w, 128, 256}};
+        for (int j = 0; j < 6 && !rc; ++j) {
+            rc = launch_frag64(w + enc[j].src, ef, enc[j].n, enc[j].k, nullptr);
+            ef += frag64_doubles(enc[j].n, enc[j].k);
+        }
     }
     if (!rc) rc = mdgat_check_hip(hipDeviceSynchronize(), "fp64 weight fragments");
     (void)hipSetDevice(prev);
@@ -450,10 +462,12 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
             GemmF64Args g{A0, lda0, K0, A1, lda1, w64 + wofs, K, w64 + bofs, Rs, ldc, C, ldc, R, cout, K, relu, status_dev + MDGAT_STATUS_RANGE};
             return launch_gemm_f64(g, s);
         };
-        // encoder stages in the (contiguous) q|k|v + hidden area: 4 + 33 + 32 + 64 + 128 + 64 + 128 = 453 of 640 doubles per point
-        double* in4 = ws.qkv64;
+        // the assembled inputs at the END of the hidden area (the fused encoder writes layer 0's q | k | v while other workgroups still
+        // read their inputs); the stages of the one-product-per-launch form in the (contiguous) q|k|v + hidden area in front of them:
+        // 32 + 64 + 128 + 64 + 128 = 416 of the 603 doubles per point there
+        double* in4 = ws.hid64 + Rz * (256 - 37);
         double* in33 = in4 + Rz * 4;
-        double* hk1 = in33 + Rz * 33;
+        double* hk1 = ws.qkv64;
         double* hk2 = hk1 + Rz * 32;
         double* hk3 = hk2 + Rz * 64;
         double* hd1 = hk3 + Rz * 128;
@@ -462,26 +476,44 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         else rc = launch_assemble_f64(B, N, M, in.dk0, in.ds0, in.df0, in.dk1, in.ds1, in.df1, in4, in33, status_dev + MDGAT_STATUS_RANGE, s);
         if (rc) return rc;
         mark(MDGAT_PROF_F64_OTHER);
+        first = f64_layer_count(h->cfg);
+        // The tail of a layer - mlp.0 + ReLU, mlp.3 + residual (mdgat.py:246-248, 274) - and the NEXT layer's q | k | v projection
+        // (227-232) run as one launch (layer_f64.hip), the hidden activation never leaving the chip, and so do the two encoders with
+        // layer 0's projection; the last fp64 launch also writes the fp32 rounding of x, the hand-over.  mdgat_set_f64_layer_fusion(0)
+        // keeps the one-product-per-launch form (bit-identical).
+        const bool fused = layer_f64_fused() && h->wfrag64;
+        bool handed_over = false;
         // KeypointEncoder (mdgat.py:184-188), DescriptorEncoder (152-155), their sum (392-393) as one product over [hd ; hk]
-        if ((rc = gemm(in4, 4, 4, nullptr, 0, bl.kenc0_w, bl.kenc0_b, 1, nullptr, hk1, 32, 32, 4))) return rc;
-        if ((rc = gemm(hk1, 32, 32, nullptr, 0, bl.kenc1_w, bl.kenc1_b, 1, nullptr, hk2, 64, 64, 32))) return rc;
-        if ((rc = gemm(hk2, 64, 64, nullptr, 0, bl.kenc2_w, bl.kenc2_b, 1, nullptr, hk3, 128, 128, 64))) return rc;
-        if ((rc = gemm(in33, 33, 33, nullptr, 0, bl.denc0_w, bl.denc0_b, 1, nullptr, hd1, 64, 64, 33))) return rc;
-        if ((rc = gemm(hd1, 64, 64, nullptr, 0, bl.denc1_w, bl.denc1_b, 1, nullptr, hd2, 128, 128, 64))) return rc;
-        if ((rc = gemm(hd2, 128, 128, hk3, 128, bl.encl_w, bl.encl_b, 0, nullptr, ws.x64, 128, 128, 256))) return rc;
+        if (fused) {
+            const double* ef = h->wfrag64 + layer_f64_frag_doubles() * (size_t)L2;
+            const double* f_k0 = ef;
+            const double* f_d0 = f_k0 + frag64_doubles(32, 4);
+            const double* f_k1 = f_d0 + frag64_doubles(64, 33);
+            const double* f_k2 = f_k1 + frag64_doubles(64, 32);
+            const double* f_d1 = f_k2 + frag64_doubles(128, 64);
+            const double* f_l = f_d1 + frag64_doubles(128, 64);
+            const EncoderF64Args e{in4, in33, f_k0, w64 + bl.kenc0_b, f_d0, w64 + bl.denc0_b, f_k1, w64 + bl.kenc1_b, f_k2, w64 + bl.kenc2_b,
+                                   f_d1, w64 + bl.denc1_b, f_l, w64 + bl.encl_b,
+                                   first > 0 ? h->wfrag64 + WF64_QKV : nullptr, first > 0 ? w64 + bl.layer0 + bl.qkv_b : nullptr,
+                                   ws.x64, ws.qkv64,
+                                   first == 0 ? ws.x : nullptr, R, status_dev + MDGAT_STATUS_RANGE};
+            if ((rc = launch_encoder_f64(e, s))) return rc;
+            handed_over = first == 0;
+        } else {
+            if ((rc = gemm(in4, 4, 4, nullptr, 0, bl.kenc0_w, bl.kenc0_b, 1, nullptr, hk1, 32, 32, 4))) return rc;
+            if ((rc = gemm(hk1, 32, 32, nullptr, 0, bl.kenc1_w, bl.kenc1_b, 1, nullptr, hk2, 64, 64, 32))) return rc;
+            if ((rc = gemm(hk2, 64, 64, nullptr, 0, bl.kenc2_w, bl.kenc2_b, 1, nullptr, hk3, 128, 128, 64))) return rc;
+            if ((rc = gemm(in33, 33, 33, nullptr, 0, bl.denc0_w, bl.denc0_b, 1, nullptr, hd1, 64, 64, 33))) return rc;
+            if ((rc = gemm(hd1, 64, 64, nullptr, 0, bl.denc1_w, bl.denc1_b, 1, nullptr, hd2, 128, 128, 64))) return rc;
+            if ((rc = gemm(hd2, 128, 128, hk3, 128, bl.encl_w, bl.encl_b, 0, nullptr, ws.x64, 128, 128, 256))) return rc;
+        }
         mark(MDGAT_PROF_F64_GEMM);
         if (taps && taps->x_enc)
             if ((rc = launch_f64_to_f32(ws.x64, taps->x_enc, Rz * 128, nullptr, s))) return rc;
-        first = f64_layer_count(h->cfg);
-        // The tail of a layer - mlp.0 + ReLU, mlp.3 + residual (mdgat.py:246-248, 274) - and the NEXT layer's q | k | v projection
-        // (227-232) run as one launch (layer_f64.hip), the hidden activation never leaving the chip; the last fp64 layer's launch
-        // also writes the fp32 rounding of x, the hand-over.  mdgat_set_f64_layer_fusion(0) keeps the three-launch form (bit-identical).
-        const bool fused = layer_f64_fused() && h->wfrag64;
-        bool handed_over = false;
         for (int i = 0; i < first; ++i) {
             const size_t lo = bl.layer0 + (size_t)i * bl.layer_stride;
             // MultiHeadedAttention (mdgat.py:223-237; merge is folded into mlp.0 by pack.py), attention / dynamic_attention (190-210)
-            if (i == 0 || !fused) {
+            if (!fused) {
                 if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, lo + bl.qkv_w, lo + bl.qkv_b, 0, nullptr, ws.qkv64, 384, 384, 128))) return rc;
                 mark(MDGAT_PROF_F64_GEMM);
             }

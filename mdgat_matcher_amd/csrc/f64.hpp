@@ -55,7 +55,23 @@ struct LayerF64Args {
     unsigned* guard;           // as GemmF64Args::guard
 };
 int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s);
-// W [N][K] row-major -> the fragment order layer_tail_f64_kernel loads ([N / 16][K / 8][64 lanes][2]); N % 16 == 0, K % 8 == 0
+// both encoders, their sum and layer 0's q | k | v as one launch (mdgat.py:184-188, 152-155, 392-393, 227-232); weights in fragment order
+struct EncoderF64Args {
+    const double *in4, *in33;                  // [R][4] x y z saliency, [R][33] FPFH (launch_assemble_f64)
+    const double *wk0, *bk0, *wd0, *bd0;       // kenc.0 [32][4], denc.0 [64][33] (BN folded)
+    const double *wk1, *bk1, *wk2, *bk2;       // kenc.3 [64][32], kenc.6 [128][64]
+    const double *wd1, *bd1;                   // denc.3 [128][64]
+    const double *wl, *bl;                     // the encoders' last layers as one product over [hd2 ; hk3]: [128][256]
+    const double *wq, *bq;                     // layer 0's q | k | v [384][128], or nullptr (no fp64 layer follows)
+    double* x; double* qkv;                    // [R][128], [R][384]
+    float* x32;                                // optional fp32 rounding of x (the hand-over when no fp64 layer follows)
+    int R;
+    unsigned* guard;
+};
+int launch_encoder_f64(const EncoderF64Args& a, hipStream_t s);
+size_t encoder_f64_frag_doubles();
+size_t frag64_doubles(int N, int K);
+// W [N][K] row-major -> the fragment order the kernels of layer_f64.hip load ([N / 16][ceil(K / 8)][64 lanes][2], zero beyond K); N % 16 == 0
 int launch_frag64(const double* W, double* out, int N, int K, hipStream_t s);
 size_t layer_f64_frag_doubles();      // per layer: mlp.0 | mlp.3 | q|k|v
 bool layer_f64_fused();               // mdgat_set_f64_layer_fusion / MDGAT_F64_LAYER_FUSION

@@ -73,6 +73,138 @@ __device__ __forceinline__ void lf_product(const double* As, const double* wf, i
     }
 }
 
+// a short product, one channel block per wave, fully unrolled: K = 4 KSTEPS (the last k-step may be zero padded, the last PAIR of the
+// fragment layout half empty - its second k-step is then simply not multiplied, as gemm_f64_kernel does not either)
+template <int NRB, int KSTEPS>
+__device__ __forceinline__ void lf_product_u(const double* As, const double* wf, int lane, f64x4 (&acc)[NRB]) {
+    constexpr int JP = (KSTEPS + 1) / 2;
+    const int l15 = lane & 15, g = lane >> 4;
+    const f64x2* wp = reinterpret_cast<const f64x2*>(wf) + lane;
+    f64x2 wb[JP];
+#pragma unroll
+    for (int jp = 0; jp < JP; ++jp) wb[jp] = wp[(size_t)jp * 64];
+    const double* ap = As + l15 * LF_LD + g;
+#pragma unroll
+    for (int j = 0; j < KSTEPS; ++j)
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) acc[rb] = mfma64(ap[rb * 16 * LF_LD + 4 * j], wb[j >> 1][j & 1], acc[rb]);
+}
+
+// epilogue of an encoder stage: ReLU(acc + bias) of channel block cb -> tile columns col0 + 16 cb ..
+template <int NRB>
+__device__ __forceinline__ void lf_store_relu(double* tile, int col0, int cb, const double* bias, int lane, const f64x4 (&acc)[NRB], bool& bad) {
+    const int l15 = lane & 15, g = lane >> 4;
+    const double b = bias[cb * 16 + l15];
+#pragma unroll
+    for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = acc[rb][i] + b;
+            bad |= f64_out_of_range(v);
+            v = v > 0.0 ? v : 0.0;
+            tile[(rb * 16 + g + 4 * i) * LF_LD + col0 + cb * 16 + l15] = v;
+        }
+}
+
+// Both encoders, their sum and the first layer's q | k | v projection as ONE launch (mdgat.py:184-188, 152-155, 392-393, 227-232):
+// seven products whose operands never leave the workgroup's LDS tile - the three-launch-per-layer form's counterpart here is seven
+// gemm_f64_kernel launches of K = 4 ... 256, each a few dozen workgroups at one pair per call.  The keypoint chain lives in tile
+// columns 128 .., the descriptor chain in columns 0 ..; a stage reads, the workgroup meets at a barrier, the stage's output takes
+// its input's place, a second barrier: [hd2 ; hk3] then stand side by side as the 256 input columns of the last encoder layer.
+template <int NRB>
+__global__ __launch_bounds__(64 * LF_WAVES) void encoder_f64_kernel(EncoderF64Args a) {
+    constexpr int TM = 16 * NRB;
+    extern __shared__ __attribute__((aligned(16))) double lfs[];      // [TM][LF_LD]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    const int row0 = blockIdx.x * TM;
+    bool bad = false;
+    // ---- inputs: FPFH (33) -> columns 0 .. 32 (33 .. 35: the zero padding of the ninth k-step), x y z saliency -> columns 128 .. 131 ----
+    for (int e = tid; e < TM * 40; e += 64 * LF_WAVES) {
+        const int r = e / 40, c = e - r * 40;
+        const int row = min(row0 + r, a.R - 1);
+        if (c < 36) lfs[r * LF_LD + c] = c < 33 ? a.in33[(size_t)row * 33 + c] : 0.0;
+        else lfs[r * LF_LD + 128 + (c - 36)] = a.in4[(size_t)row * 4 + (c - 36)];
+    }
+    __syncthreads();
+    f64x4 acc[NRB], acc2[NRB];
+    auto zero = [&](f64x4 (&v)[NRB]) {
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) v[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    };
+    // ---- stage 1: hk1 = ReLU(kenc.0 [4 -> 32]) on waves 0, 1; hd1 = ReLU(denc.0 [33 -> 64]) on waves 2 .. 5 ----
+    zero(acc);
+    if (wave < 2) lf_product_u<NRB, 1>(lfs + 128, a.wk0 + (size_t)wave * 1 * 128, lane, acc);
+    else if (wave < 6) lf_product_u<NRB, 9>(lfs, a.wd0 + (size_t)(wave - 2) * 5 * 128, lane, acc);
+    __syncthreads();
+    if (wave < 2) lf_store_relu<NRB>(lfs, 128, wave, a.bk0, lane, acc, bad);
+    else if (wave < 6) lf_store_relu<NRB>(lfs, 0, wave - 2, a.bd0, lane, acc, bad);
+    __syncthreads();
+    // ---- stage 2: hk2 = ReLU(kenc.3 [32 -> 64]) on waves 0 .. 3; hd2 = ReLU(denc.3 [64 -> 128]) on all eight ----
+    zero(acc); zero(acc2);
+    if (wave < 4) lf_product_u<NRB, 8>(lfs + 128, a.wk1 + (size_t)wave * 4 * 128, lane, acc);
+    lf_product_u<NRB, 16>(lfs, a.wd1 + (size_t)wave * 8 * 128, lane, acc2);
+    __syncthreads();
+    if (wave < 4) lf_store_relu<NRB>(lfs, 128, wave, a.bk1, lane, acc, bad);
+    lf_store_relu<NRB>(lfs, 0, wave, a.bd1, lane, acc2, bad);
+    __syncthreads();
+    // ---- stage 3: hk3 = ReLU(kenc.6 [64 -> 128]) ----
+    zero(acc);
+    lf_product_u<NRB, 16>(lfs + 128, a.wk2 + (size_t)wave * 8 * 128, lane, acc);
+    __syncthreads();
+    lf_store_relu<NRB>(lfs, 128, wave, a.bk2, lane, acc, bad);
+    __syncthreads();
+    // ---- stage 4: x = last encoder layers summed: one product over [hd2 ; hk3] (mdgat.py:392-393) ----
+    {
+        f64x4 ax[NRB][1];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb) ax[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0};
+        lf_product<NRB, 1, 32, 4>(lfs, a.wl + (size_t)wave * 32 * 128, lane, ax);
+        __syncthreads();
+        const int n = wave * 16 + l15;
+        const double b = a.bl[n];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = rb * 16 + g + 4 * i;
+                const double v = ax[rb][0][i] + b;
+                bad |= f64_out_of_range(v);
+                lfs[r * LF_LD + n] = v;
+                if (row0 + r < a.R) {
+                    a.x[(size_t)(row0 + r) * 128 + n] = v;
+                    if (a.x32) a.x32[(size_t)(row0 + r) * 128 + n] = (float)v;
+                }
+            }
+    }
+    if (a.wq) {
+        __syncthreads();
+        // ---- stage 5: q | k | v of layer 0 ----
+        f64x4 aq[NRB][3];
+#pragma unroll
+        for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) aq[rb][c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        lf_product<NRB, 3, 16, NRB >= 4 ? 2 : 4>(lfs, a.wq + (size_t)(3 * wave) * 16 * 128, lane, aq);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int n = (3 * wave + c) * 16 + l15;
+            const double b = a.bq[n];
+#pragma unroll
+            for (int rb = 0; rb < NRB; ++rb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int row = row0 + rb * 16 + g + 4 * i;
+                    const double v = aq[rb][c][i] + b;
+                    bad |= f64_out_of_range(v);
+                    if (row < a.R) a.qkv[(size_t)row * 384 + n] = v;
+                }
+        }
+    }
+    if (bad) f64_raise(a.guard);
+}
+
 template <int NRB>
 __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64Args a) {
     constexpr int TM = 16 * NRB;
@@ -174,16 +306,18 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
     if (bad) f64_raise(a.guard);
 }
 
-// W [N][K] row-major -> fragment order [N / 16][K / 8][64 lanes][2]: lane (l15 = lane & 15, g = lane >> 4) of channel block cb and
-// k-step pair jp holds W[16 cb + l15][8 jp + 4 t + g], t = 0, 1 - the B operand of two consecutive v_mfma_f64_16x16x4_f64
+// W [N][K] row-major -> fragment order [N / 16][ceil(K / 8)][64 lanes][2]: lane (l15 = lane & 15, g = lane >> 4) of channel block cb
+// and k-step pair jp holds W[16 cb + l15][8 jp + 4 t + g], t = 0, 1 - the B operand of two consecutive v_mfma_f64_16x16x4_f64;
+// zero beyond K (the encoders' K = 4 and K = 33)
 __global__ __launch_bounds__(256) void frag64_kernel(const double* W, double* out, int N, int K) {
-    const size_t total = (size_t)N * K;
+    const int JP = (K + 7) / 8;
+    const size_t total = (size_t)N * JP * 8;
     for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
         const int t = (int)(e & 1), lane = (int)((e >> 1) & 63);
         const size_t blk = e >> 7;
-        const int JP = K / 8;
         const int jp = (int)(blk % JP), cb = (int)(blk / JP);
-        out[e] = W[(size_t)(cb * 16 + (lane & 15)) * K + 8 * jp + 4 * t + (lane >> 4)];
+        const int k = 8 * jp + 4 * t + (lane >> 4);
+        out[e] = k < K ? W[(size_t)(cb * 16 + (lane & 15)) * K + k] : 0.0;
     }
 }
 
@@ -191,9 +325,16 @@ __global__ __launch_bounds__(256) void frag64_kernel(const double* W, double* ou
 
 size_t layer_f64_frag_doubles() { return (size_t)256 * 256 + 128 * 256 + 384 * 128; }
 
+size_t frag64_doubles(int N, int K) { return (size_t)N * ((K + 7) / 8) * 8; }
+// the six encoder matrices: kenc.0 | denc.0 | kenc.3 | kenc.6 | denc.3 | last layers summed
+size_t encoder_f64_frag_doubles() {
+    return frag64_doubles(32, 4) + frag64_doubles(64, 33) + frag64_doubles(64, 32) + frag64_doubles(128, 64) + frag64_doubles(128, 64) + frag64_doubles(128, 256);
+}
+
 int launch_frag64(const double* W, double* out, int N, int K, hipStream_t s) {
-    if (N % 16 || K % 8) { mdgat_set_error("launch_frag64: %d x %d is not whole fragments", N, K); return MDGAT_ERR_BAD_ARG; }
-    hipLaunchKernelGGL(frag64_kernel, dim3((N * K + 255) / 256 < 1024 ? (N * K + 255) / 256 : 1024), dim3(256), 0, s, W, out, N, K);
+    if (N % 16) { mdgat_set_error("launch_frag64: %d output channels are not whole fragments", N); return MDGAT_ERR_BAD_ARG; }
+    const size_t total = frag64_doubles(N, K);
+    hipLaunchKernelGGL(frag64_kernel, dim3((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), dim3(256), 0, s, W, out, N, K);
     return mdgat_check_hip(hipGetLastError(), "frag64 launch");
 }
 
@@ -241,4 +382,21 @@ int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s) {
     if (tm == 16) return go(layer_tail_f64_kernel<1>, std::integral_constant<int, 1>());
     if (tm == 32) return go(layer_tail_f64_kernel<2>, std::integral_constant<int, 2>());
     return go(layer_tail_f64_kernel<4>, std::integral_constant<int, 4>());
+}
+
+int launch_encoder_f64(const EncoderF64Args& a, hipStream_t s) {
+    if (a.R <= 0) return MDGAT_OK;
+    int tm = (long)((a.R + 31) / 32) >= 2L * lf_cu_count() ? 32 : 16;
+    if (fusion_mode() == 16 || fusion_mode() == 32) tm = fusion_mode();
+    const size_t lds = (size_t)tm * LF_LD * sizeof(double);
+    const dim3 grid((a.R + tm - 1) / tm);
+    auto go = [&](auto kern, auto tag) -> int {
+        (void)tag;
+        static std::atomic<unsigned long long> done{0};
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), lds, done, "encoder_f64 LDS")) return rc;
+        hipLaunchKernelGGL(kern, grid, dim3(64 * LF_WAVES), lds, s, a);
+        return mdgat_check_hip(hipGetLastError(), "encoder_f64 launch");
+    };
+    if (tm == 16) return go(encoder_f64_kernel<1>, std::integral_constant<int, 1>());
+    return go(encoder_f64_kernel<2>, std::integral_constant<int, 2>());
 }

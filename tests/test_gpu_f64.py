@@ -266,12 +266,14 @@ def test_literal_bar_on_the_reference_held_variants(golden_dir, name):
 
 
 @pytest.mark.parametrize('B,n,m,L,k', [(1, 512, 512, 3, [128, None, 64, None]), (3, 100, 77, 2, [16, None, 8, None]), (20, 512, 512, 2, [64, None]),
-                                       (2, 1000, 1030, 2, [64, 32, None, 16]), (5, 33, 47, 4, [None, 8, 4, None])])
+                                       (2, 1000, 1030, 2, [64, 32, None, 16]), (5, 33, 47, 4, [None, 8, 4, None]), (3, 70, 64, 1, [])])
 def test_f64_fused_layer_tail_equals_three_launches(B, n, m, L, k):
     """csrc/layer_f64.hip (mlp.0 -> ReLU -> mlp.3 -> + x -> next q | k | v in one launch, the hidden activation in LDS, the weights in
-    fragment order straight from L2) against the three gemm_f64_kernel launches it replaces: every accumulator walks k in the same
-    order, so EVERY output bit is the same - matches, scores, Z, and the fp32 taps of every layer's descriptors - for each tile height
-    (16 / 32 / 64 keypoints per workgroup), ragged keypoint counts, one pair and a batch large enough to run in slices."""
+    fragment order straight from L2) against the three gemm_f64_kernel launches it replaces - and the fused encoder launch (both
+    encoders, their sum, layer 0's q | k | v) against the seven it replaces: every accumulator walks k in the same order, so EVERY
+    output bit is the same - matches, scores, Z, and the fp32 taps of the encoder output and of every layer's descriptors - for each
+    tile height (16 / 32 / 64 keypoints per workgroup), ragged keypoint counts, one pair, a batch large enough to run in slices, and
+    a network without a dynamic layer (encoders only in fp64: the encoder launch hands over)."""
     from mdgat_matcher_amd import _lib
     lib = _lib.load()
     cfg = synth.default_config(L=L, k=k, sinkhorn_iterations=10)
@@ -285,7 +287,7 @@ def test_f64_fused_layer_tail_equals_three_launches(B, n, m, L, k):
     def run(mode, taps):
         prev = lib.mdgat_set_f64_layer_fusion(mode)
         try:
-            t = {'x_layers': torch.zeros(2 * L, B, P, 128, device=DEV)} if taps else None
+            t = {'x_layers': torch.zeros(2 * L, B, P, 128, device=DEV), 'x_enc': torch.zeros(B, P, 128, device=DEV)} if taps else None
             out = net._run(d['keypoints0'], d['scores0'], d['descriptors0'], d['keypoints1'], d['scores1'], d['descriptors1'], want_Z=True, taps=t)
             torch.cuda.synchronize()
             net.check(DEV)
@@ -300,7 +302,7 @@ def test_f64_fused_layer_tail_equals_three_launches(B, n, m, L, k):
             for a, b, what in zip(ref, out, ('matches0', 'matches1', 'mscores0', 'mscores1', 'Z')):
                 assert torch.equal(a, b), (mode, taps, what)
             if taps:
-                assert torch.equal(rt['x_layers'], ot['x_layers']), mode
+                assert torch.equal(rt['x_layers'], ot['x_layers']) and torch.equal(rt['x_enc'], ot['x_enc']), mode
 
 
 def test_f64_dict_api_slices_and_errors():
