@@ -34,6 +34,17 @@
 #include "row_search.hpp"
 #include "exp2_tab256.hpp"
 
+#ifdef F64_TRACE
+// measurement build only (tools/ab_build.sh f64 trace -DF64_TRACE; tools/f64_trace.py): s_memtime at the phase boundaries of the
+// dynamic kernel, waves 0 and 3 of one workgroup in the middle of the grid
+__device__ long long g_f64_trace[2 * 16];
+extern "C" int mdgat_f64_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f64_trace), n * sizeof(long long)); }
+#define FT(k) do { if (blockIdx.x == gridDim.x / 2 + 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
+    g_f64_trace[((threadIdx.x >> 6) == 3) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define FT(k) do {} while (0)
+#endif
+
 namespace {
 
 // ================================================================================================ GEMM
@@ -400,6 +411,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             }
         }
     } else {
+        FT(0);
         // ---- dynamic attention, pass A: fp32 roundings of the logits -> LDS, row maxima ----
         f64x4 Sk[KEEP ? 8 : 1];
         if (KEEP) {
@@ -443,7 +455,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             }
             if (tid < QT) sm.lcount[tid] = 0;
         }
+        FT(1);
         __syncthreads();
+        FT(2);
         // ---- the exact k-th largest rounding of every row ----
         if (KEEP) {
             // at most 512 keys: the wave's four rows (4 wave .. 4 wave + 3) side by side, sixteen lanes each (row_search.hpp)
@@ -475,7 +489,9 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                             : nk <= 1024 ? f64_row_select<16>(row, nk, a.topk, a.zq, lane, hist) : f64_row_select<32>(row, nk, a.topk, a.zq, lane, hist);
             if (lane == 0) sm.sel[q] = rs;
         }
+        FT(3);
         __syncthreads();
+        FT(4);
         // ---- pass B: the fp64 logits again, masked softmax against the row maximum, P.V ----
         RowSel rs[QB];
         uint32_t* tap[QB];
@@ -495,7 +511,12 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 const int key = jb * 16 + g + 4 * r;
                 const float sf = (float)S[r];
                 bool keep = sf > rs[qb].thr;
+#ifdef F64_KO_TIES
+                keep = sf >= rs[qb].thr;
+                if (false) {
+#else
                 if (sf == rs[qb].thr) {
+#endif
                     if (rs[qb].mode == 0) keep = true;
                     else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
                     else if (key < nk) {
@@ -505,7 +526,11 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                     }
                 }
                 keep = keep && key < nk;
+#ifdef F64_KO_EXP
+                p[r] = keep ? S[r] - mrun[qb] : 0.0;
+#else
                 p[r] = keep ? exp_fast(S[r] - mrun[qb], sm.tab, ec) : 0.0;
+#endif
                 bits |= (unsigned)keep << (4 * r);        // keys 16 jb + g + 4 r
             }
             if (TAP && bits && q0 + qb * 16 + l15 < nq) atomicOr(tap[qb] + (jb >> 1), bits << (16 * (jb & 1) + g));
@@ -542,6 +567,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
         }
     }
 
+    if (TOPK) FT(5);
     // ---- combine the four waves: row statistics and output partials through LDS ----
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -603,6 +629,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 l += p; o0 += p * v[0]; o1 += p * v[1];
             }
         }
+        if (TOPK) FT(6);
         const double inv = 1.0 / l;
         o0 *= inv; o1 *= inv;
         if (f64_out_of_range(o0) || f64_out_of_range(o1)) f64_raise(a.guard);

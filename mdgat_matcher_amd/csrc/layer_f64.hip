@@ -32,17 +32,23 @@ constexpr int LF_WAVES = 8;
 // one product: acc[rb][c] += A[rows of block rb][k] W[channel block cb0 + c][k] over K = 8 JP, W in fragment order from L2, A in LDS.
 // PF: pairs of k-steps the weight loads run ahead (the loads of pair jp + PF are issued into the registers pair jp has just been
 // multiplied from).
-template <int NRB, int NCB, int JP, int PF>
-__device__ __forceinline__ void lf_product(const double* As, const double* wf, int lane, f64x4 (&acc)[NRB][NCB]) {
-    static_assert(JP % PF == 0, "prefetch depth");
-    const int l15 = lane & 15, g = lane >> 4;
-    const double* ap = As + l15 * LF_LD + g;
+// the first PF pairs of a product's weights.  They do not depend on the activations: a caller may request them BEFORE the barrier
+// that makes the activations visible (the one-pair tile height does: a workgroup alone on its CU has nothing else to cover that
+// round trip to L2 with).
+template <int NCB, int JP, int PF>
+__device__ __forceinline__ void lf_prefetch(const double* wf, int lane, f64x2 (&wb)[PF][NCB]) {
     const f64x2* wp = reinterpret_cast<const f64x2*>(wf) + lane;          // channel block c, pair jp: wp[(c * JP + jp) * 64]
-    f64x2 wb[PF][NCB];
 #pragma unroll
     for (int p = 0; p < PF; ++p)
 #pragma unroll
         for (int c = 0; c < NCB; ++c) wb[p][c] = wp[(size_t)(c * JP + p) * 64];
+}
+template <int NRB, int NCB, int JP, int PF>
+__device__ __forceinline__ void lf_product(const double* As, const double* wf, int lane, f64x4 (&acc)[NRB][NCB], f64x2 (&wb)[PF][NCB]) {
+    static_assert(JP % PF == 0, "prefetch depth");
+    const int l15 = lane & 15, g = lane >> 4;
+    const double* ap = As + l15 * LF_LD + g;
+    const f64x2* wp = reinterpret_cast<const f64x2*>(wf) + lane;
     double a[2][NRB][2];
 #pragma unroll
     for (int rb = 0; rb < NRB; ++rb) { a[0][rb][0] = ap[rb * 16 * LF_LD]; a[0][rb][1] = ap[rb * 16 * LF_LD + 4]; }
@@ -160,7 +166,9 @@ __global__ __launch_bounds__(64 * LF_WAVES) void encoder_f64_kernel(EncoderF64Ar
         f64x4 ax[NRB][1];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) ax[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0};
-        lf_product<NRB, 1, 32, 4>(lfs, a.wl + (size_t)wave * 32 * 128, lane, ax);
+        f64x2 wbx[4][1];
+        lf_prefetch<1, 32, 4>(a.wl + (size_t)wave * 32 * 128, lane, wbx);
+        lf_product<NRB, 1, 32, 4>(lfs, a.wl + (size_t)wave * 32 * 128, lane, ax, wbx);
         __syncthreads();
         const int n = wave * 16 + l15;
         const double b = a.bl[n];
@@ -186,7 +194,9 @@ __global__ __launch_bounds__(64 * LF_WAVES) void encoder_f64_kernel(EncoderF64Ar
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int c = 0; c < 3; ++c) aq[rb][c] = f64x4{0.0, 0.0, 0.0, 0.0};
-        lf_product<NRB, 3, 16, NRB >= 4 ? 2 : 4>(lfs, a.wq + (size_t)(3 * wave) * 16 * 128, lane, aq);
+        f64x2 wbq[4][3];
+        lf_prefetch<3, 16, 4>(a.wq + (size_t)(3 * wave) * 16 * 128, lane, wbq);
+        lf_product<NRB, 3, 16, 4>(lfs, a.wq + (size_t)(3 * wave) * 16 * 128, lane, aq, wbq);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int n = (3 * wave + c) * 16 + l15;
@@ -214,6 +224,10 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
     const int l15 = lane & 15, g = lane >> 4;
     const int row0 = blockIdx.x * TM;
     bool bad = false;
+    constexpr bool EARLY = NRB == 1;        // the first weights of a product requested before the barrier in front of it (registers: one-pair tiles only)
+    constexpr int PF3 = NRB >= 4 ? 2 : 4;
+    f64x2 wb1[4][2], wb2[4][1], wb3[PF3][3];
+    if (EARLY) lf_prefetch<2, 32, 4>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
 
     // ---- input tile [x ; msg] -> LDS (rows beyond R: the last row again; their results are never written) ----
     for (int e = tid; e < TM * 128; e += 64 * LF_WAVES) {
@@ -229,7 +243,9 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
         f64x4 acc[NRB][2];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { acc[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[rb][1] = acc[rb][0]; }
-        lf_product<NRB, 2, 32, 4>(lfs, a.w1f + (size_t)(2 * wave) * 32 * 128, lane, acc);
+        if (!EARLY) lf_prefetch<2, 32, 4>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
+        lf_product<NRB, 2, 32, 4>(lfs, a.w1f + (size_t)(2 * wave) * 32 * 128, lane, acc, wb1);
+        if (EARLY) lf_prefetch<1, 32, 4>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
         __syncthreads();                        // every wave has read the tile: the hidden layer takes its place
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -260,7 +276,9 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) res[rb][i] = a.x[(size_t)min(row0 + rb * 16 + g + 4 * i, a.R - 1) * 128 + n];
-        lf_product<NRB, 1, 32, 4>(lfs, a.w2f + (size_t)wave * 32 * 128, lane, acc);
+        if (!EARLY) lf_prefetch<1, 32, 4>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
+        lf_product<NRB, 1, 32, 4>(lfs, a.w2f + (size_t)wave * 32 * 128, lane, acc, wb2);
+        if (EARLY && a.w3f) lf_prefetch<3, 16, PF3>(a.w3f + (size_t)(3 * wave) * 16 * 128, lane, wb3);
         __syncthreads();                        // every wave has read the hidden layer: the new x takes its place
         const double bias = a.b2[n];
 #pragma unroll
@@ -287,7 +305,8 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int c = 0; c < 3; ++c) acc[rb][c] = f64x4{0.0, 0.0, 0.0, 0.0};
-        lf_product<NRB, 3, 16, NRB >= 4 ? 2 : 4>(lfs, a.w3f + (size_t)(3 * wave) * 16 * 128, lane, acc);
+        if (!EARLY) lf_prefetch<3, 16, PF3>(a.w3f + (size_t)(3 * wave) * 16 * 128, lane, wb3);
+        lf_product<NRB, 3, 16, PF3>(lfs, a.w3f + (size_t)(3 * wave) * 16 * 128, lane, acc, wb3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             const int n = (3 * wave + c) * 16 + l15;

@@ -201,9 +201,16 @@ __device__ __forceinline__ int rq_suffix_sum(int v) {
 __device__ __forceinline__ unsigned rq_row_bits(unsigned long long ballot, int lane) { return (unsigned)(ballot >> (lane & 48)) & 0xffffu; }
 
 constexpr int RQ_HIST_INTS = 272;       // per row: 256 bins + one waste bin per lane
+#ifndef RQ_START_BELOW
+#define RQ_START_BELOW 0.25f
+#endif
 // rows: the wave's four rows in LDS, `pitch` floats apart (row r of the wave = lanes 16 r .. 16 r + 15); hist: 4 x RQ_HIST_INTS ints of LDS
 // owned by this wave (it may be the rows' own storage: every value is in registers before the first histogram is cleared, and the
 // LDS serves a wave's accesses in order).  Every lane returns its row's answer.
+// Instruction count matters here as much as latency (PMC, 512 keys: the select was 1 550 of the dynamic kernel's 2 500 vector
+// instructions per wave and tile in its first form): the row is loaded without per-value branches (whole rows without any guard),
+// and a level's base is ALIGNED to its digit position, so that a value's bin is (o >> sh) - (base >> sh) - two instructions, values
+// below the base wrap to huge bins - and one compare against the level's width sends everything out of play to the lane's waste bin.
 template <int NV>
 __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int k, float zq, int lane, int list_cap, int* hist_, int hist_pitch) {
     const int s = lane & 15, rw = lane >> 4;
@@ -211,28 +218,51 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
     unsigned o[NV];                      // pads: 0, below the image of every float
     unsigned omn = ~0u, omx = 0u;
     float s1 = 0.f, s2 = 0.f;
+    if (nk == 16 * NV) {                 // (a whole row: 512 / 256 / 128 keys)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const int idx = s + 16 * i;
-        const float f = idx < nk ? row[idx] + 0.f : 0.f;
-        o[i] = idx < nk ? f2ord(f) : 0u;
-        omn = min(omn, idx < nk ? o[i] : ~0u); omx = max(omx, o[i]);
-        if (i % 4 == 0) { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+        for (int i = 0; i < NV; ++i) {
+            const float f = row[s + 16 * i] + 0.f;
+            o[i] = f2ord(f);
+            omn = min(omn, o[i]); omx = max(omx, o[i]);
+            { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int idx = s + 16 * i;
+            const bool valid = idx < nk;
+            const float f = row[min(idx, nk - 1)] + 0.f;       // (an address inside the row either way: no branch around the load)
+            o[i] = valid ? f2ord(f) : 0u;
+            omn = min(omn, valid ? o[i] : ~0u); omx = max(omx, o[i]);
+            { const float g = (valid && f > -3.0e38f) ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+        }
     }
     omn = rq_min_u(omn); omx = rq_max_u(omx);
     RowSearch out{-__builtin_inff(), nk, 0, ord2f(omx), 1 << 30};
     if (k >= nk) return out;             // (the same for every row of the launch)
     rs_lds_int* hist = (rs_lds_int*)hist_ + rw * hist_pitch;
-    unsigned base = omn;
+    unsigned base;
+    int sh;
+    // digit position for the values lo .. omx, the base aligned to it (eight bits a level: ((omx - base) >> sh) < 256)
+    auto set_range = [&](unsigned lo) {
+        int h = 24 - __builtin_clz((omx - lo) | 0xffu);
+        unsigned b = lo & ~((1u << h) - 1u);
+        if (((omx - b) >> h) >= 256u) { ++h; b = lo & ~((1u << h) - 1u); }
+        base = b; sh = h;
+    };
     {
         s1 = rq_sum_f(s1); s2 = rq_sum_f(s2);
-        const float inv_n = 4.0f / (float)nk;
+        const float inv_n = 1.0f / (float)nk;
         const float mu = s1 * inv_n;
         const float sd = sqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f));
-        const unsigned cand = f2ord(mu + (zq - 1.0f) * sd);
-        if (cand > omn && cand < omx) base = cand;
+        // Where the select starts.  A level's cost is its values IN PLAY: their atomics meet in the banks of one histogram (the values
+        // out of play go to sixteen neighbouring waste bins and do not) - phase trace at 512 keys: 25 000 cycles of select for k = 128
+        // (63 % in play at mean + (zq - 1) sd), 17 000 for k = 64 (44 %).  The k-th largest of a bell-shaped row sits near mean + zq
+        // sd; with the moments taken over the whole row the start a quarter of a deviation below it still holds k values in all
+        // but a few rows in a thousand (a row that does not starts over from its minimum), and a third of the row is in play.
+        const unsigned cand = f2ord(mu + (zq - RQ_START_BELOW) * sd);
+        set_range((cand > omn && cand < omx) ? cand : omn);
     }
-    int sh = 24 - __builtin_clz((omx - base) | 0xffu);
     int above = 0, ceq = 0;
     unsigned width = 256u;
     for (;;) {
@@ -241,10 +271,13 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         rq_lds_int4* h4 = (rq_lds_int4*)hist;
         h4[4 * s] = rq_i4{0, 0, 0, 0}; h4[4 * s + 1] = rq_i4{0, 0, 0, 0}; h4[4 * s + 2] = rq_i4{0, 0, 0, 0}; h4[4 * s + 3] = rq_i4{0, 0, 0, 0};
         hist[256 + s] = 0;
+        const unsigned bq = base >> sh;
+        // (values out of play go to the lane's waste bin: an unconditional atomic.  Issued under the lane mask of the values in play
+        // instead - a branch per value - the select was slower: 680 -> 795 us per launch at batch 64)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const unsigned d = (o[i] - base) >> sh;
-            __atomic_fetch_add(hist + ((o[i] >= base && d < width) ? (int)d : 256 + s), 1, __ATOMIC_RELAXED);
+            const unsigned d = (o[i] >> sh) - bq;               // below the base: wraps far beyond the width
+            __atomic_fetch_add(hist + (d < width ? (int)d : 256 + s), 1, __ATOMIC_RELAXED);
         }
         // stage 1: this lane's sixteen bins (16 s .. 16 s + 15) as one count; the lane whose bins hold the k-th largest
         const rq_i4 ha = h4[4 * s], hb = h4[4 * s + 1], hc = h4[4 * s + 2], hd = h4[4 * s + 3];
@@ -252,8 +285,7 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         const int suf = rq_suffix_sum(t);
         const int tot = rq_sum(t);
         if (above + tot < k) {           // (first level only: fewer than k values above the start - not a bell-shaped row)
-            base = omn;
-            sh = 24 - __builtin_clz((omx - omn) | 0xffu);
+            set_range(omn);
             continue;
         }
         const int al = above + suf - t;                              // values in play above this lane's bins
@@ -270,13 +302,14 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         base += (unsigned)bin << sh;
         if (sh == 0) break;                                          // the bin is one value: `ceq` values equal it
         if (ceq == 1) {                                              // one value left in play: it is the k-th largest
+            const unsigned bb = base >> sh;
             unsigned m = 0u;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) m = max(m, (o[i] >= base && ((o[i] - base) >> sh) == 0u) ? o[i] : 0u);
+            for (int i = 0; i < NV; ++i) m = max(m, (o[i] >> sh) == bb ? o[i] : 0u);
             base = rq_max_u(m);
             break;
         }
-        width = sh >= 8 ? 256u : 1u << sh;
+        width = sh >= 8 ? 256u : 1u << sh;      // (the bin just chosen spans 2^sh values: the next level must not look beyond it)
         sh = sh > 8 ? sh - 8 : 0;
     }
     out.thr = ord2f(base); out.c_gt = above; out.c_ge = above + ceq;
