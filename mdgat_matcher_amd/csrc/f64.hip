@@ -188,9 +188,8 @@ __device__ __forceinline__ double quad_sum(double v) { v += shfl_xor_f64(v, 16);
 //     exp(x) = 2^q T[j] (1 + r + r^2 / 2 + r^3 / 6 + r^4 / 24),      T[j] = 2^(j / 256) correctly rounded, 2 KB of LDS (exp2_tab256.hpp)
 // (truncation r^5 / 120 = 3.8e-17).  n = 256 q + j falls out of the low word of x (256 / ln 2) + 1.5 2^52, the reduction is ONE fma
 // against the correctly rounded ln2 / 256 (its rounding error acts like a relative perturbation of x by 2^-53: an ulp of the logit
-// itself), the polynomial is a product and three fmas with at most one scalar operand each, the table entry gets 2^q by an integer
-// add to its exponent field (safe: x is clamped to -700, so q >= -1010) and one last fma scales.  Nine fp64 and four integer
-// instructions and a ds_read_b64; the degree-12 polynomial + v_ldexp form this replaces ran 19 (+ a v_mov_b64 the compiler
+// itself), the polynomial is a product and three fmas with at most one scalar operand each, one fma scales the table entry and
+// v_ldexp_f64 applies 2^q.  Ten fp64 and three integer instructions and a ds_read_b64; the degree-12 polynomial this replaces ran 19 (+ a v_mov_b64 the compiler
 // rematerialised for the leading coefficient) - on this part an fp64 vector instruction issues in the slot of a sixteenth of a
 // v_mfma_f64_16x16x4 and the two share the pipe (profiles/NOTES_r5.md section 1), so the attention loops are their vector
 // instruction count.  Keys masked with -inf get exp(-700) = 1e-304 instead of 0: nothing against a row's largest term, which is 1.
@@ -214,10 +213,8 @@ __device__ __forceinline__ double exp_fast(double x, const double* tab_, const E
     asm("v_fma_f64 %0, %1, %2, 0.5" : "=v"(a) : "v"(r), "s"(0x1.5555555555555p-3));                        // 1/2 + r / 6
     asm("v_fma_f64 %0, %1, %2, %3" : "=v"(b) : "v"(r2), "s"(0x1.5555555555555p-5), "v"(a));               // ... + r^2 / 24
     s = __builtin_fma(r2, b, r);                                                                          // exp(r) - 1
-    const unsigned long long tb = __builtin_bit_cast(unsigned long long, tab[n & 255]);
-    const unsigned hi = (unsigned)(tb >> 32) + (((unsigned)n & 0xffffff00u) << 12);                       // exponent + (n >> 8)
-    const double T = __builtin_bit_cast(double, ((unsigned long long)hi << 32) | (unsigned)tb);
-    return __builtin_fma(T, s, T);
+    const double T = tab[n & 255];
+    return ldexp(__builtin_fma(T, s, T), n >> 8);       // (v_ashrrev + v_ldexp_f64; shift, mask and a 64-bit add into T's exponent field: one more, same time)
 }
 constexpr double TAU_LAZY = 8.0;          // full attention: the running reference of a row moves only when a logit exceeds it by this much
 
