@@ -368,6 +368,7 @@ def main():
     ap.add_argument('--arithmetic', default='fp32', choices=['fp32', 'fp64'],
                     help="'fp64': time the reference-exact mode (MDGAT(arithmetic='fp64')) as the step; never the headline")
     ap.add_argument('--no-exact-mode', action='store_true', help='skip the exact_mode block (reference-exact fp64 mode on a bounded batch)')
+    ap.add_argument('--no-parity', action='store_true', help='skip the parity block (profiling runs: its 8-pair forwards would enter the per-kernel averages)')
     args = ap.parse_args()
     self_launch(args)
 
@@ -482,7 +483,7 @@ def main():
         }
         # where both modes stand against the literal bar, MEASURED here on the reference-held pairs of this shape (parity_block)
         try:
-            out['parity'] = parity_block(dev, n, L, S, stub=stub)
+            out['parity'] = {'skipped': '--no-parity'} if args.no_parity else parity_block(dev, n, L, S, stub=stub)
         except RuntimeError as e:
             print(f'[bench] parity: {e}', file=sys.stderr, flush=True)
             out['parity'] = {'error': str(e)}

@@ -14,7 +14,7 @@ CLASSES = (('layer_split_kernelILi0ELi1E', 'layer_first'), ('layer_split_kernelI
            ('attention_stream_kernel', 'attention_full'), ('attention_topk', 'attention_topk'), ('attention_kernelILb1E', 'attention_topk'),
            ('attention_kernelILb0E', 'attention_full'), ('sinkhorn_scaling_kernel', 'sinkhorn'), ('scores_kernel', 'scores'),
            ('encoder_kernel', 'encoder'), ('extract_kernel', 'extract'),
-           ('gemm_f64_kernel', 'f64_gemm'), ('attention_f64_kernelILb0E', 'f64_attention_full'), ('attention_f64_kernelILb1E', 'f64_attention_topk'))
+           ('layer_tail_f64_kernel', 'f64_gemm'), ('encoder_f64_kernel', 'f64_gemm'), ('gemm_f64_kernel', 'f64_gemm'), ('attention_f64_kernelILb0E', 'f64_attention_full'), ('attention_f64_kernelILb1E', 'f64_attention_topk'))
 
 
 def read(path, counter):

@@ -6,7 +6,7 @@ BATCH=${2:-32}
 CONFIG=${CONFIG:-1}
 R=$PWD; O=$R/gpurun_out; mkdir -p $O
 python bench.py --config $CONFIG --arithmetic fp64 --batch $BATCH --steps 5 --warmup 2 --no-cpu-baseline --no-dict-api --no-latency 2>/dev/null | tail -1 > $O/${TAG}_f64_bench_line.json
-CMD="python $R/bench.py --config $CONFIG --arithmetic fp64 --batch $BATCH --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-dict-api --no-latency --no-exact-mode"
+CMD="python $R/bench.py --config $CONFIG --arithmetic fp64 --batch $BATCH --steps 3 --warmup 1 --windows 1 --no-cpu-baseline --no-dict-api --no-latency --no-exact-mode --no-parity"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pf_stats && rocprofv3 --kernel-trace --stats -d /tmp/pf_stats -o s -- $CMD > /dev/null 2>&1
 ( echo "# rocprofv3 --kernel-trace --stats -- ${CMD#python $R/}"; cd $R; python tools/rocpd_summary.py /tmp/pf_stats/s_results.db ) > $O/${TAG}_f64_kernel_stats.txt 2>&1
