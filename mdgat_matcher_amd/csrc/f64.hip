@@ -31,19 +31,19 @@
 #include "common.hpp"
 #include "f64.hpp"
 #include "f64_dev.hpp"
-#include "row_search.hpp"
-#include "exp2_tab256.hpp"
-
 #ifdef F64_TRACE
 // measurement build only (tools/ab_build.sh f64 trace -DF64_TRACE; tools/f64_trace.py): s_memtime at the phase boundaries of the
 // dynamic kernel, waves 0 and 3 of one workgroup in the middle of the grid
-__device__ long long g_f64_trace[2 * 16];
+__device__ long long g_f64_trace[2 * 32];
 extern "C" int mdgat_f64_trace_read(long long* out, int n) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_f64_trace), n * sizeof(long long)); }
 #define FT(k) do { if (blockIdx.x == gridDim.x / 2 + 3 && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == 3)) \
-    g_f64_trace[((threadIdx.x >> 6) == 3) * 16 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+    g_f64_trace[((threadIdx.x >> 6) == 3) * 32 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define FT(k) do {} while (0)
 #endif
+
+#include "row_search.hpp"
+#include "exp2_tab256.hpp"
 
 namespace {
 
@@ -285,8 +285,10 @@ size_t attn_lds_bytes(int QT, int nk_max, bool topk, int hist_ints) {
 // and pass B neither reads K nor multiplies again - a third of the matrix work of the recomputing form.
 // (32-query full attention: 146 registers, three waves per SIMD.  Held to 128 for a fourth - amdgpu_waves_per_eu(4), 16 spilled - it
 // loses: 239 -> 260 us at batch 32.)
+// (three waves per SIMD at least - 168 registers: the 512-key dynamic instance sits right at that line, and one register more costs it
+// a third of its occupancy: 666 -> 797 us per launch at batch 64)
 template <bool TOPK, int QB, bool TAP, bool KEEP = false>
-__global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attention_f64_kernel(AttnF64Args a) {
     static_assert(!KEEP || (TOPK && QB == 1), "KEEP: dynamic attention, one query block");
     constexpr int QT = 16 * QB;
     extern __shared__ __attribute__((aligned(16))) double asmem[];
@@ -500,19 +502,23 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
             tap[qb] = TAP ? a.sel + (((size_t)b * 4 + head) * P + q_off + min(q0 + q, nq - 1)) * a.selW : nullptr;
         }
         // one block of pass B for query block qb: classify, masked exponentials, P.V
-        auto pass_b = [&](int jb, const f64x4& S, const f64x2 (&vf)[4], int qb) {
+        // Roundings tied at the k-th place (modes 1, 2) are rare - about one row in 60 000 on real-valued logits - and their handling is a
+        // compare and a branch per logit: a wave none of whose rows has them (TIES = false: mode 0 everywhere, "keep every rounding
+        // >= thr") runs a pass without it.  Knock-out: the tie branches were 9 % of the launch.
+        auto pass_b = [&](int jb, const f64x4& S, const f64x2 (&vf)[4], int qb, auto ties) {
+            constexpr bool TIES = decltype(ties)::value;
             f64x4 p;
             unsigned bits = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int key = jb * 16 + g + 4 * r;
                 const float sf = (float)S[r];
-                bool keep = sf > rs[qb].thr;
+                bool keep = TIES ? sf > rs[qb].thr : sf >= rs[qb].thr;
 #ifdef F64_KO_TIES
                 keep = sf >= rs[qb].thr;
                 if (false) {
 #else
-                if (sf == rs[qb].thr) {
+                if (TIES && sf == rs[qb].thr) {
 #endif
                     if (rs[qb].mode == 0) keep = true;
                     else if (rs[qb].mode == 1) keep = key <= rs[qb].aux;
@@ -538,16 +544,23 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 O[qb][1] = mfma64(vf[s][1], p[s], O[qb][1]);
             }
         };
-        if (KEEP) {
+        bool any_ties = false;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int jb = wave + 4 * i;
-                if (jb < nblk) {
-                    f64x2 vf[4];
-                    vload(jb, vf);
-                    pass_b(jb, Sk[i], vf, 0);
+        for (int qb = 0; qb < QB; ++qb) any_ties |= rs[qb].mode != 0;
+        any_ties = __any(any_ties);
+        if (KEEP) {
+            auto run = [&](auto ties) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int jb = wave + 4 * i;
+                    if (jb < nblk) {
+                        f64x2 vf[4];
+                        vload(jb, vf);
+                        pass_b(jb, Sk[i], vf, 0, ties);
+                    }
                 }
-            }
+            };
+            if (any_ties) run(std::true_type()); else run(std::false_type());
         } else {
             double kf[8];
             f64x2 vf[4];
@@ -559,7 +572,7 @@ __global__ __launch_bounds__(256) void attention_f64_kernel(AttnF64Args a) {
                 for (int qb = 0; qb < QB; ++qb) Sq[qb] = logits(jb, kf, qb);
                 if (jb + 4 < nblk) kload(jb + 4, kf);
 #pragma unroll
-                for (int qb = 0; qb < QB; ++qb) pass_b(jb, Sq[qb], vf, qb);
+                for (int qb = 0; qb < QB; ++qb) { if (any_ties) pass_b(jb, Sq[qb], vf, qb, std::true_type()); else pass_b(jb, Sq[qb], vf, qb, std::false_type()); }
             }
         }
     }

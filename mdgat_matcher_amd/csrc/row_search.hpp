@@ -6,6 +6,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "common.hpp"
+#ifndef FT
+#define FT(k) do {} while (0)
+#endif
 
 // monotone image of a float in the unsigned integers (larger float <-> larger integer; -inf below every finite value)
 __device__ __forceinline__ unsigned f2ord(float f) {
@@ -216,15 +219,15 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
     const int s = lane & 15, rw = lane >> 4;
     rs_lds_cfloat* row = (rs_lds_cfloat*)rows_ + rw * pitch;
     unsigned o[NV];                      // pads: 0, below the image of every float
-    unsigned omn = ~0u, omx = 0u;
-    float s1 = 0.f, s2 = 0.f;
+    unsigned omx = 0u;
+    float s1 = 0.f, s2 = 0.f;            // moments of the row from every other register: they only choose where the select starts
     if (nk == 16 * NV) {                 // (a whole row: 512 / 256 / 128 keys)
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const float f = row[s + 16 * i] + 0.f;
             o[i] = f2ord(f);
-            omn = min(omn, o[i]); omx = max(omx, o[i]);
-            { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+            omx = max(omx, o[i]);
+            if (i % 2 == 0) { const float g = f > -3.0e38f ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
         }
     } else {
 #pragma unroll
@@ -233,11 +236,19 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
             const bool valid = idx < nk;
             const float f = row[min(idx, nk - 1)] + 0.f;       // (an address inside the row either way: no branch around the load)
             o[i] = valid ? f2ord(f) : 0u;
-            omn = min(omn, valid ? o[i] : ~0u); omx = max(omx, o[i]);
-            { const float g = (valid && f > -3.0e38f) ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
+            omx = max(omx, o[i]);
+            if (i % 2 == 0) { const float g = (valid && f > -3.0e38f) ? f : 0.f; s1 += g; s2 = fmaf(g, g, s2); }
         }
     }
-    omn = rq_min_u(omn); omx = rq_max_u(omx);
+    FT(8);
+    omx = rq_max_u(omx);
+    // the row's smallest value: only a row that restarts needs it (rare: computed there)
+    auto row_min = [&]() {
+        unsigned mn = ~0u;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) mn = min(mn, o[i] ? o[i] : ~0u);       // (pads are 0; no float's image is)
+        return rq_min_u(mn);
+    };
     RowSearch out{-__builtin_inff(), nk, 0, ord2f(omx), 1 << 30};
     if (k >= nk) return out;             // (the same for every row of the launch)
     rs_lds_int* hist = (rs_lds_int*)hist_ + rw * hist_pitch;
@@ -252,7 +263,7 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
     };
     {
         s1 = rq_sum_f(s1); s2 = rq_sum_f(s2);
-        const float inv_n = 1.0f / (float)nk;
+        const float inv_n = 2.0f / (float)nk;
         const float mu = s1 * inv_n;
         const float sd = sqrtf(fmaxf(s2 * inv_n - mu * mu, 0.f));
         // Where the select starts.  A level's cost is its values IN PLAY: their atomics meet in the banks of one histogram (the values
@@ -261,11 +272,14 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         // sd; with the moments taken over the whole row the start a quarter of a deviation below it still holds k values in all
         // but a few rows in a thousand (a row that does not starts over from its minimum), and a third of the row is in play.
         const unsigned cand = f2ord(mu + (zq - RQ_START_BELOW) * sd);
-        set_range((cand > omn && cand < omx) ? cand : omn);
+        if (cand < omx) set_range(cand); else set_range(row_min());
     }
     int above = 0, ceq = 0;
     unsigned width = 256u;
+    FT(9);
+    int ft_level = 0;
     for (;;) {
+        FT(10 + 3 * min(ft_level, 2));
         typedef int rq_i4 __attribute__((ext_vector_type(4)));
         typedef __attribute__((address_space(3))) rq_i4 rq_lds_int4;
         rq_lds_int4* h4 = (rq_lds_int4*)hist;
@@ -279,13 +293,14 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
             const unsigned d = (o[i] >> sh) - bq;               // below the base: wraps far beyond the width
             __atomic_fetch_add(hist + (d < width ? (int)d : 256 + s), 1, __ATOMIC_RELAXED);
         }
+        FT(11 + 3 * min(ft_level, 2));
         // stage 1: this lane's sixteen bins (16 s .. 16 s + 15) as one count; the lane whose bins hold the k-th largest
         const rq_i4 ha = h4[4 * s], hb = h4[4 * s + 1], hc = h4[4 * s + 2], hd = h4[4 * s + 3];
         const int t = (ha.x + ha.y + ha.z + ha.w) + (hb.x + hb.y + hb.z + hb.w) + (hc.x + hc.y + hc.z + hc.w) + (hd.x + hd.y + hd.z + hd.w);
         const int suf = rq_suffix_sum(t);
         const int tot = rq_sum(t);
         if (above + tot < k) {           // (first level only: fewer than k values above the start - not a bell-shaped row)
-            set_range(omn);
+            set_range(1u);               // (everything real is in play again: pads are 0; coarse first digits, more levels - rare)
             continue;
         }
         const int al = above + suf - t;                              // values in play above this lane's bins
@@ -300,6 +315,8 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         above = rq_sum(own1 ? a1 : 0);
         ceq = rq_sum(own1 ? h1 : 0);
         base += (unsigned)bin << sh;
+        FT(12 + 3 * min(ft_level, 2));
+        ++ft_level;
         if (sh == 0) break;                                          // the bin is one value: `ceq` values equal it
         if (ceq == 1) {                                              // one value left in play: it is the k-th largest
             const unsigned bb = base >> sh;
@@ -312,6 +329,7 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
         width = sh >= 8 ? 256u : 1u << sh;      // (the bin just chosen spans 2^sh values: the next level must not look beyond it)
         sh = sh > 8 ? sh - 8 : 0;
     }
+    FT(20);
     out.thr = ord2f(base); out.c_gt = above; out.c_ge = above + ceq;
     if (out.c_ge == k || ceq <= list_cap) return out;
     // more than list_cap values share the k-th place: the first k - c_gt of them in key order stay (key = s + 16 i)
