@@ -145,6 +145,7 @@ __device__ __forceinline__ int kept_count(f32x2 kept) { return (int)(kept[0] + k
 struct WaveComm {
     static constexpr bool LOCAL_VOTE = true;     // any() is one wave-level ballot
     static constexpr bool PACKED_COUNT = true;   // topk_threshold counts with ge_ind()
+    static constexpr bool LEAN_SEARCH = false;   // (see WideComm)
     __device__ __forceinline__ float rsum(float v) { return v + xor32(v); }
     __device__ __forceinline__ int rsum(int v) { return v + xor32i(v); }
     __device__ __forceinline__ float rmin(float v) { return fminf(v, xor32(v)); }
@@ -153,6 +154,7 @@ struct WaveComm {
     __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) {
         mn = fminf(mn, xor32(mn)); sum += xor32(sum); sq += xor32(sq);
     }
+    __device__ __forceinline__ void stats4(float&, float& mn, float& sum, float& sq) { stats(mn, sum, sq); }     // (LEAN_SEARCH comms only)
     // row count + "is any row of the voting domain still probing" in one step
     __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
         any_probing = __any(probing);
@@ -176,12 +178,14 @@ template <typename T, typename Op> __device__ __forceinline__ T quad_reduce(T v,
 struct QuadComm {
     static constexpr bool LOCAL_VOTE = true;
     static constexpr bool PACKED_COUNT = true;
+    static constexpr bool LEAN_SEARCH = false;
     __device__ __forceinline__ float rsum(float v) { return quad_reduce(v, [](float a, float b) { return a + b; }); }
     __device__ __forceinline__ int rsum(int v) { return quad_reduce(v, [](int a, int b) { return a + b; }); }
     __device__ __forceinline__ float rmin(float v) { return quad_reduce(v, [](float a, float b) { return fminf(a, b); }); }
     __device__ __forceinline__ float rmax(float v) { return quad_reduce(v, [](float a, float b) { return fmaxf(a, b); }); }
     __device__ __forceinline__ bool any(bool p) { return __any(p); }
     __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) { mn = rmin(mn); sum = rsum(sum); sq = rsum(sq); }
+    __device__ __forceinline__ void stats4(float&, float& mn, float& sum, float& sq) { stats(mn, sum, sq); }
     __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
         any_probing = __any(probing);
         return rsum(c);
@@ -199,11 +203,12 @@ struct QuadComm {
 // logits (fp32 logits closer than one ulp, duplicated keypoints); the kernels count what the softmax pass keeps and
 // call topk_break_ties() for such rows, so that every row keeps exactly k keys like torch.topk.
 template <int NBLK, bool EXACT, typename Comm>
-__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m, int k, int nk, float zq, Comm& comm) {
+__device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float& m, int k, int nk, float zq, Comm& comm, bool whole = false) {
     const float INF = __builtin_inff();
     // the packed indicator form needs the logits in vector registers proper: not the 256-logit instance (half of its
     // row lives in accumulation registers) and not the split-key kernel (no register to spare)
     constexpr bool PACKED = Comm::PACKED_COUNT && NBLK <= 8;
+    constexpr bool LEAN = EXACT || Comm::LEAN_SEARCH;
     float smin = INF, sum = 0.f, sq = 0.f;
     float mu, sd;
     if (EXACT) {
@@ -221,6 +226,22 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         const float inv_n = 4.0f / (float)nk;
         mu = sum * inv_n;
         sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
+    } else if (Comm::LEAN_SEARCH && whole) {
+        // (LEAN_SEARCH, a row without pads - `whole`, the same for the whole workgroup: as above, and the row maximum - `m` arrives
+        // as this wave's part of it - travels with the three statistics in ONE exchange instead of four)
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb)
+#pragma unroll
+            for (int r = 0; r < 16; r += 4) {
+                const float s = S[jb][r];
+                smin = fminf(fminf(smin, s), fminf(fminf(S[jb][r + 1], S[jb][r + 2]), S[jb][r + 3]));
+                sum += s;
+                sq = fmaf(s, s, sq);
+            }
+        comm.stats4(m, smin, sum, sq);
+        const float inv_n = 4.0f / (float)nk;
+        mu = sum * inv_n;
+        sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
     } else {
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
@@ -232,7 +253,8 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
                 sum += s;
                 sq = fmaf(s, s, sq);
             }
-        comm.stats(smin, sum, sq);
+        if (Comm::LEAN_SEARCH) comm.stats4(m, smin, sum, sq);
+        else comm.stats(smin, sum, sq);
         const float inv_n = 1.0f / (float)nk;
         mu = sum * inv_n;
         sd = sqrtf(fmaxf(sq * inv_n - mu * mu, 1e-12f));
@@ -283,16 +305,16 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
     float lo = smin, hv = m;
     // ties AT the maximum only matter for tiny k (with chi taken as 1 a tied maximum still ends in "collapsed", which
     // keeps all ties); the exact count costs a pass, so it is only made when it can change the outcome
-    int clo = nk, chi = (!EXACT || k <= 4) ? count_ge(m) : 1;
+    int clo = nk, chi = (!LEAN || k <= 4) ? count_ge(m) : 1;
     // state: 0 probing, 1 done, 2 finish from above (k - chi == 1), 3 finish from below (clo - k == 1; !EXACT only:
     // with whole blocks two more probes are cheaper than the three passes of that finish)
     int state = 0;
-    bool hv_est = EXACT && k > 4;                    // chi is still the assumption, not a measured count
+    bool hv_est = LEAN && k > 4;                    // chi is still the assumption, not a measured count
     bool lo_meas = false;                            // lo is a probe (not the row minimum)
     if (chi >= k) { thr = m; state = 1; }            // ties at the maximum (or k == 1)
     if (nk <= k) { thr = -INF; state = 1; }          // this frame has exactly k keys: keep all
     if (state == 0 && k - chi == 1) state = 2;
-    if (!EXACT && state == 0 && clo - k == 1) state = 3;
+    if (!LEAN && state == 0 && clo - k == 1) state = 3;
     float t = mu + zq * sd;
     // monotone integer image of a float (signed compare order) and back: bisection in this space closes ANY bracket in
     // at most 32 probes, whatever the distribution of the logits
@@ -314,18 +336,18 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
             if (!(t > lo && t < hv)) t = 0.5f * lo + 0.5f * hv;
         }
         const bool collapsed = !(t > lo && t < hv);   // no float strictly inside the bracket
-        if (EXACT && collapsed && hv_est) t = hv;      // the count at the maximum was assumed: this pass measures it
+        if (LEAN && collapsed && hv_est) t = hv;      // the count at the maximum was assumed: this pass measures it
         bool any_probing;
         const int c = comm.count_vote(count_local(t), state == 0, any_probing);   // one exchange per probe
         if (!any_probing) break;                       // every row had finished before this probe
         if (state == 0) {
             // ties at the k-th value (k or more of them at the maximum: only those)
-            if (collapsed) { thr = (EXACT && hv_est && c >= k) ? hv : lo; state = 1; }
+            if (collapsed) { thr = (LEAN && hv_est && c >= k) ? hv : lo; state = 1; }
             else if (c == k) { thr = t; state = 1; }
             else {
                 if (c > k) { lo = t; clo = c; lo_meas = true; } else { hv = t; chi = c; hv_est = false; }
                 if (k - chi == 1) state = 2;
-                else if (!EXACT && clo - k == 1) state = 3;
+                else if (!LEAN && clo - k == 1) state = 3;
                 else {
                     const float z = (t - mu) * inv_sd;
                     const float dens = (float)nk * 0.3989422804f * inv_sd * __builtin_amdgcn_exp2f(-0.7213475204f * z * z);
@@ -361,7 +383,7 @@ __device__ __forceinline__ float topk_threshold(const f32x16 (&S)[NBLK], float m
         mx = comm.rmax(mx);
         if (state == 2) thr = mx;
     }
-    if (!EXACT && comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
+    if (!LEAN && comm.any(state == 3)) {   // k + 1 logits are >= lo: drop the smallest of them
         float e1 = INF;
         const float loc = canon_thr(lo);
 #pragma unroll
@@ -400,8 +422,10 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
     // registers are only written after the loop: modifying S inside it costs the kernels dozens of spilled registers)
     int lim = 1 << 20;
     const float thi = tie_top(thr);
+    bool dropped = false;                           // (the same in every lane that shares the vote: comm.any is wave- or workgroup-wide)
 #pragma unroll 1
     while (comm.any(surplus > 0)) {
+        dropped = true;
         const int below = lim - lane_off;
         int cand = -1;                              // largest koff below the limit of a tied logit in this lane
 #pragma unroll
@@ -414,8 +438,8 @@ __device__ __forceinline__ void topk_break_ties(f32x16 (&S)[NBLK], float thr, in
         on_drop(top, surplus > 0);
         surplus -= 1;
     }
-    if (SWEEP) {
-        const int from = lim - lane_off;
+    if (SWEEP && dropped) {                         // (no row of the vote had a surplus - all but one tile in 10^4: nothing to sweep, and the
+        const int from = lim - lane_off;           // sweep is three instructions per logit: 384 per tile of the 2048-key kernel)
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
@@ -954,8 +978,14 @@ template <int NW>
 struct WideComm {
     static constexpr bool LOCAL_VOTE = false;    // any() crosses waves through LDS: the vote rides on the count exchange
     static constexpr bool PACKED_COUNT = false;  // (the kernel is at its register limit: 13 spilled registers this way, 250 with the packed count)
+    // Every counting pass of this kernel is 256 instructions per wave AND a workgroup exchange: the search spends as few as it can -
+    // the count at the row maximum is assumed 1 and only measured when the bracket collapses onto it (as the whole-block kernels do),
+    // and a row one logit ABOVE k keeps probing instead of the three-pass finish from below (two masked minima of three
+    // instructions per logit + a count: four probes' worth; simulation on rows of 2048: 9.7 -> 8.0 passes per tile).
+    static constexpr bool LEAN_SEARCH = true;
     float* buf;      // [2][8 waves][64 lanes] exchange slots, [1024..1039] vote flags
     int wave, lane, par;
+    float* buf4;     // [4][8 waves][64 lanes]: the four row statistics of a tile in one exchange (stats4; once per tile, so one buffer)
     template <typename Op>
     __device__ __forceinline__ float exch(float v, Op op) {
         float* b = buf + par * 512;
@@ -978,6 +1008,19 @@ struct WideComm {
     __device__ __forceinline__ float rmax(float v) { v = fmaxf(v, xor32(v)); return exch(v, [](float x, float y) { return fmaxf(x, y); }); }
     __device__ __forceinline__ bool any(bool p) { return __syncthreads_or(p) != 0; }
     __device__ __forceinline__ void stats(float& mn, float& sum, float& sq) { mn = rmin(mn); sum = rsum(sum); sq = rsum(sq); }
+    // row maximum (in: this wave's part, lane pair not yet combined), minimum, sum and sum of squares through ONE barrier
+    __device__ __forceinline__ void stats4(float& mx, float& mn, float& sum, float& sq) {
+        mx = fmaxf(mx, xor32(mx)); mn = fminf(mn, xor32(mn)); sum += xor32(sum); sq += xor32(sq);
+        float* b = buf4 + wave * 64 + lane;
+        b[0] = mx; b[512] = mn; b[1024] = sum; b[1536] = sq;
+        __syncthreads();
+        const float* g = buf4 + (wave / NW) * NW * 64 + lane;
+        mx = g[0]; mn = g[512]; sum = g[1024]; sq = g[1536];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            mx = fmaxf(mx, g[w * 64]); mn = fminf(mn, g[512 + w * 64]); sum += g[1024 + w * 64]; sq += g[1536 + w * 64];
+        }
+    }
     __device__ __forceinline__ int count_vote(int c, bool probing, bool& any_probing) {
         int* flags = reinterpret_cast<int*>(buf) + 1024 + par * 8;
         if (lane == 0) flags[wave] = 0;
@@ -998,7 +1041,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     constexpr int NG = 8 / NW;                // query tiles per workgroup pass
     extern __shared__ __attribute__((aligned(16))) float fsm[];
     float* xbuf = fsm;                        // WideComm: 1040 floats
-    float* obuf = fsm + 1040;                 // [8 waves][17][64] output partials and row sums
+    float* obuf = fsm + 1040;                 // [8 waves][18][64] output partials, row sums and kept counts
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1026,7 +1069,8 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     const bool last_partial = (nk & 31) != 0;
     const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64 + 8 * hi;
     const _Float16* vg = a.vt16 + (((size_t)b * 4 + head) * 64 + l31) * a.PP + (src ? a.Npad : 0) + 8 * hi;
-    WideComm<NW> comm{xbuf, wave, lane, 0};
+    WideComm<NW> comm{xbuf, wave, lane, 0, fsm + 1040 + 8 * 18 * 64};
+    const bool whole = nk == 256 * NW;        // every wave's eight blocks are real keys: no pads anywhere in a row
     const int npass = (nq + 32 * NG - 1) / (32 * NG);
 
     for (int pass = pass0; pass < npass; pass += npg) {
@@ -1091,13 +1135,16 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         for (int jb = 0; jb < NBLK; ++jb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) m = fmaxf(m, S[jb][r]);
-        m = comm.rmax(m);
         WT(2);
-        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm);
+        // (m goes in as this wave's part of the row maximum and comes back as the row's: it travels with the search's statistics)
+        const float thr = topk_threshold<NBLK, false>(S, m, a.topk, nk, a.zq, comm, whole);
         WT(3);
-        {
-            // exact ties at the k-th place (topk_break_ties): this kernel counts what the threshold keeps BEFORE its pass
-            // (a pass redone after the fact costs it 40 spilled registers, and a probe here is a workgroup exchange anyway)
+        // Exact ties at the k-th place (topk_break_ties; about one tile in 10^4).  The pass below counts what it keeps (softmax8); the
+        // counts travel to LDS with the output partials, every wave sums them for the rows of the workgroup's query groups, and only
+        // a tile that kept too much drops the surplus in the registers and runs the pass once more.  (Until round 6 a counting pass
+        // of 256 instructions, a workgroup exchange and a vote ran in front of EVERY tile's pass: 9 000 of a tile's 85 000 cycles.)
+        // The tap build still counts first: the selection it records must be final.
+        if (TAP) {
             int c = 0;
 #pragma unroll
             for (int jb = 0; jb < NBLK; ++jb)
@@ -1122,6 +1169,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
 
         WT(4);
         const float m11 = m - 11.0f;
+        bool redone = TAP;
+#pragma unroll 1
+      for (;;) {
         f32x2 l2 = {0.f, 0.f};
         f32x2 kept = {0.f, 0.f};
         f32x16 Om, Ox;
@@ -1158,19 +1208,41 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 }
             }
         }
-        (void)kept;
         WT(5);
         float l = l2[0] + l2[1];
         l += xor32(l);
-        float* ob = obuf + wave * 17 * 64;
+        int kc = kept_count(kept);
+        kc += xor32i(kc);
+        float* ob = obuf + wave * 18 * 64;
 #pragma unroll
         for (int r = 0; r < 16; ++r) ob[r * 64 + lane] = Om[r] + Ox[r];
         ob[16 * 64 + lane] = l;
+        ob[17 * 64 + lane] = __builtin_bit_cast(float, kc);
         __syncthreads();
+        if (redone) break;
+        {
+            // what each row of the workgroup kept, summed over the waves that share it; the same numbers in every wave, so the vote
+            // needs no exchange of its own
+            int own = 0;
+            bool any = false;
+#pragma unroll
+            for (int gq = 0; gq < NG; ++gq) {
+                int tot = 0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) tot += __builtin_bit_cast(int, obuf[(gq * NW + w) * 18 * 64 + 17 * 64 + lane]);
+                any |= tot > kexp;
+                if (gq == qgroup) own = tot;
+            }
+            if (!__any(any)) break;
+            __syncthreads();                 // (every wave has read the counts: the redone pass writes its partials over them)
+            topk_break_ties<KeyLayout32>(S, thr, own - kexp, comm, kw * NBLK * 32 + 8 * hi);
+            redone = true;
+        }
+      }
         if (kw == 0 && qw < nq) {
             float lt = 0.f;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) lt += obuf[(qgroup * NW + w) * 17 * 64 + 16 * 64 + lane];
+            for (int w = 0; w < NW; ++w) lt += obuf[(qgroup * NW + w) * 18 * 64 + 16 * 64 + lane];
             const float inv_l = 1.0f / lt;
             // (the addresses below do not depend on the pass: hoisted out of the pass loop they live across the whole kernel,
             // are spilled, and come back as 17 serialised scratch round trips - `late` keeps them here)
@@ -1184,7 +1256,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
                 const int q = qw + row;
                 float o = 0.f;
 #pragma unroll
-                for (int w = 0; w < NW; ++w) o += obuf[(qgroup * NW + w) * 17 * 64 + r * 64 + lane + late];
+                for (int w = 0; w < NW; ++w) o += obuf[(qgroup * NW + w) * 18 * 64 + r * 64 + lane + late];
                 if (q < nq) out[(size_t)q * 128] = o * inv;
             }
         }
@@ -1199,7 +1271,7 @@ static int launch_attention_topk_wide(const AttnArgs& a, int B, int nk_max, hipS
         mdgat_set_error("dynamic attention: %d keys per frame > 2048 supported", nk_max);
         return MDGAT_ERR_UNSUPPORTED;
     }
-    const size_t lds = (size_t)(1040 + 8 * 17 * 64) * sizeof(float);
+    const size_t lds = (size_t)(1040 + 8 * 18 * 64 + 4 * 8 * 64) * sizeof(float);
     AttnArgs w = a;
     w.grid_units = B * 2 * MDGAT_HEADS;
     const int ugroups = (w.grid_units + 7) / 8;
