@@ -245,6 +245,15 @@ int mdgat_set_layer_split_tiles(int tiles);
  * default.  Process-wide; the results are bit-identical either way.  Returns the previous value. */
 int mdgat_set_f64_layer_fusion(int mode);
 
+/* MDGAT_ARITH_FP64: how full attention (models/mdgat.py:190-194) is launched.  -1 (default; MDGAT_F64_ATTENTION_FORM in the
+ * environment selects another): by launch size - launches of at least four 128-query workgroups per compute unit (32 pairs of 512
+ * keypoints) give every wave 32 queries and all the keys of the frame, smaller ones split the keys of a 16- / 32-query tile over
+ * the four waves of a workgroup and combine them through LDS.  The two forms sum a row's terms in different orders: they agree to
+ * rounding (1e-15 relative), not bit for bit, so what a pair returns can differ in the last bits with the size of the batch it
+ * travels in.  0: always the split-key form - a pair's result is then bit-identical whatever the batch; 1: always one wave per
+ * 32 queries; mode < -1: back to the environment's / default.  Process-wide.  Returns the previous value. */
+int mdgat_set_f64_attention_form(int mode);
+
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
 
 /* log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308): scores [B][N][M] -> Z. */

@@ -76,6 +76,7 @@ SIGNATURES = {
     'mdgat_set_lanes': (C.c_int, [C.c_void_p, C.c_int]),
     'mdgat_set_layer_split_tiles': (C.c_int, [C.c_int]),
     'mdgat_set_f64_layer_fusion': (C.c_int, [C.c_int]),
+    'mdgat_set_f64_attention_form': (C.c_int, [C.c_int]),
     'mdgat_sinkhorn': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_float, C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_size_t, C.c_void_p]),
     'mdgat_sinkhorn_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),

@@ -287,9 +287,16 @@ size_t attn_lds_bytes(int QT, int nk_max, bool topk, int hist_ints) {
 // loses: 239 -> 260 us at batch 32.)
 // (three waves per SIMD at least - 168 registers: the 512-key dynamic instance sits right at that line, and one register more costs it
 // a third of its occupancy: 666 -> 797 us per launch at batch 64)
-template <bool TOPK, int QB, bool TAP, bool KEEP = false>
+// SOLO (full attention, launches that fill the chip several times over): the QUERIES of a workgroup are split over its waves instead
+// of the keys - a wave owns 16 QB queries and walks all the blocks of the frame, so there is nothing to combine: no partials through
+// LDS, no barrier, no second pass with its exponentials, and the prologue (query fragments) and epilogue are paid once per 32
+// blocks instead of once per 8.  Per 16 QB queries x 512 keys: 256 matrix instructions either way, ~1 250 vector instructions
+// instead of ~2 140.  Not for small launches: a wave's chain of blocks is four times as long, and a pair of 512 keypoints is
+// only 128 such waves.  (A row's terms are summed in another order than in the split form: the two agree to rounding, not bit for bit.)
+template <bool TOPK, int QB, bool TAP, bool KEEP = false, bool SOLO = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void attention_f64_kernel(AttnF64Args a) {
     static_assert(!KEEP || (TOPK && QB == 1), "KEEP: dynamic attention, one query block");
+    static_assert(!SOLO || !TOPK, "SOLO: full attention");
     constexpr int QT = 16 * QB;
     extern __shared__ __attribute__((aligned(16))) double asmem[];
     const AttnLds sm = attn_lds(asmem, QT, TOPK, a.hist_ints);
@@ -306,10 +313,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     const int nq = side ? a.M : a.N, q_off = side ? a.N : 0;
     const int src = a.cross ? 1 - side : side;
     const int nk = src ? a.M : a.N, k_off = src ? a.N : 0;
-    const int q0 = tile * QT;
-    if (q0 >= nq) return;
+    const int q0 = SOLO ? (tile * 4 + wave) * QT : tile * QT;
+    if (!SOLO && q0 >= nq) return;
     sm.tab[tid] = MDGAT_EXP2_TAB256[tid];        // (256 threads)
     if (!TOPK) __syncthreads();                  // (the dynamic kernels pass two barriers before their first exponential)
+    if (SOLO && q0 >= nq) return;                // (a wave of its own: behind the workgroup's only barrier)
     const ExpConst ec = exp_const();
     const int imgld = ((nk + 63) & ~63) + 4;
     const double* kbase = a.qkv + ((size_t)b * P + k_off) * 384 + 128 + head * 32;
@@ -330,19 +338,45 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     }
     const int nblk = (nk + 15) >> 4;                    // 16-key blocks; this wave: blocks wave, wave + 4, ...
     // K fragment of a block: dims 8 g .. 8 g + 7 of key 16 jb + l15 (A operand; dim 8 g + j at k-step j, as in qf)
+    // Buffer loads: a descriptor of this frame's keys (values) is built once in scalar registers, a block's offset into it is a scalar,
+    // this lane's offset into the block a constant of the kernel - so a trip spends NO vector instruction on addresses (per-key pointers
+    // clamped to the frame - add, min, 64-bit multiply-add - were 3 of them per block for K and 12 for V).  The scalar offset takes no
+    // part in the descriptor's range check, so the last block of a ragged frame gets descriptors of its own that start at the block
+    // (the k-step) and end with the frame: the keys it reaches beyond the frame load as zeros - their logits are masked below (logits()),
+    // their value rows contribute 0 (the clamped loads multiplied a real row by e^-700).
+    const int koff = (l15 * 384 + 8 * g) * (int)sizeof(double);
+    const int voff = (g * 384 + 2 * l15) * (int)sizeof(double);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(kbase), 0, (nk - 1) * 3072 + 256, 0x00020000);
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(vbase), 0, (nk - 1) * 3072 + 256, 0x00020000);
+    // K fragment of a block: dims 8 g .. 8 g + 7 of key 16 jb + l15 (A operand; dim 8 g + j at k-step j, as in qf)
     auto kload = [&](int jb, double (&kf)[8]) {
-        const int key = min(jb * 16 + l15, nk - 1);
-        const f64x2* p = reinterpret_cast<const f64x2*>(kbase + (size_t)key * 384 + 8 * g);
+        f64x2 v[4];
+        if (jb * 16 + 16 <= nk) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { const f64x2 v = p[j]; kf[2 * j] = v[0]; kf[2 * j + 1] = v[1]; }
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(krs, koff, jb * (16 * 3072) + 16 * j, 0));
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(kbase + (size_t)jb * (16 * 384)), 0,
+                                                                               (nk - 16 * jb - 1) * 3072 + 256, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, koff + 16 * j, 0, 0));
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { kf[2 * j] = v[j][0]; kf[2 * j + 1] = v[j][1]; }
     };
     // V fragments of a block: k-step s covers keys 16 jb + 4 s + g; this lane's A operand = dims 2 l15, 2 l15 + 1 of that key
     // (output dim blocks t = 0, 1: D register r of block t is dim 2 (g + 4 r) + t)
     auto vload = [&](int jb, f64x2 (&vf)[4]) {
+        if (jb * 16 + 16 <= nk) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int key = min(jb * 16 + 4 * s + g, nk - 1);
-            vf[s] = *reinterpret_cast<const f64x2*>(vbase + (size_t)key * 384 + 2 * l15);
+            for (int s = 0; s < 4; ++s) vf[s] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, (jb * 16 + 4 * s) * 3072, 0));
+        } else {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int left = nk - 16 * jb - 4 * s - 1;          // keys of the frame behind this step's first
+                const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(vbase + (size_t)(jb * 16 + 4 * s) * 384), 0,
+                                                                                   left < 0 ? 0 : left * 3072 + 256, 0x00020000);
+                vf[s] = __builtin_bit_cast(f64x2, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+            }
         }
     };
     // logits of one block for query block qb: S[r] = logit of key 16 jb + g + 4 r (pads: -inf)
@@ -350,11 +384,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         f64x4 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc = mfma64(kf[j], qf[qb][j], acc);
-        if (jb * 16 + 16 > nk) {          // (the last block of a ragged frame only: a scalar branch - the asm keeps the compiler from turning it
-            asm volatile("");             // into eight selects in every trip)
+        int over = jb * 16 + 16 - nk;     // (> 0: the last block of a ragged frame only.  A scalar branch; the empty asm keeps the compiler from
+        asm volatile("" : "+s"(over));    // turning it into eight selects in every trip - and from parking the condition in a vector register)
+        if (over > 0) {
+            int key;                      // (jb * 16 + g, computed HERE: as C++ the sum is hoisted in front of the branch, into every trip)
+            asm volatile("v_add_u32 %0, %1, %2" : "=v"(key) : "s"(jb * 16), "v"(g));
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                if (jb * 16 + g + 4 * r >= nk) acc[r] = -__builtin_inf();
+                if (key + 4 * r >= nk) acc[r] = -__builtin_inf();
         }
         return acc;
     };
@@ -376,13 +413,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
         // travel under the softmax and P V: a second register set copied at the top of the trip cost sixteen v_mov_b64 per block)
         double kf[8];
         f64x2 vf[4];
-        if (wave < nblk) kload(wave, kf);
-        for (int jb = wave; jb < nblk; jb += 4) {
+        constexpr int JS = SOLO ? 1 : 4;         // this wave's blocks: every one (SOLO), or wave, wave + 4, ...
+        const int jb0 = SOLO ? 0 : wave;
+        if (jb0 < nblk) kload(jb0, kf);
+        for (int jb = jb0; jb < nblk; jb += JS) {
             vload(jb, vf);
             f64x4 Sq[QB];
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) Sq[qb] = logits(jb, kf, qb);
-            if (jb + 4 < nblk) kload(jb + 4, kf);
+            if (jb + JS < nblk) kload(jb + JS, kf);
 #pragma unroll
             for (int qb = 0; qb < QB; ++qb) {
                 const f64x4 S = Sq[qb];
@@ -578,6 +617,28 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
     }
 
     if (TOPK) FT(5);
+    if (SOLO) {
+        // the wave's rows are complete: row sum over the row's four lanes, normalise, write (lane: dims 2 (g + 4 r), + 1 of query l15)
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+            const double inv = 1.0 / quad_sum(lsum[qb]);
+            const int q = q0 + qb * 16 + l15;
+            f64x2 o[4];
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                o[r] = f64x2{O[qb][0][r] * inv, O[qb][1][r] * inv};
+                bad |= f64_out_of_range(o[r][0]) || f64_out_of_range(o[r][1]);
+            }
+            if (q < nq) {
+                double* dst = a.msg + ((size_t)b * P + q_off + q) * 128 + head * 32 + 2 * g;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) *reinterpret_cast<f64x2*>(dst + 8 * r) = o[r];
+                if (bad) f64_raise(a.guard);
+            }
+        }
+        return;
+    }
     // ---- combine the four waves: row statistics and output partials through LDS ----
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
@@ -846,6 +907,23 @@ static float f64_normal_quantile_upper(double p) {
     return (float)(upper ? x : -x);
 }
 
+// full attention: workgroups (of four 32-query waves) per CU from which the one-wave-per-query-block form is launched
+constexpr long F64_SOLO_MIN_WG_PER_CU = 4;
+// -1: by launch size (default); 0: always the keys of a query tile split over the four waves (what a pair returns is then bit-identical
+// whatever batch it travels in); 1: always one wave per 32 queries.  MDGAT_F64_ATTENTION_FORM in the environment.
+static std::atomic<int> g_attention_form{-2};
+static int attention_form() {
+    const int v = g_attention_form.load(std::memory_order_relaxed);
+    if (v != -2) return v;
+    static const int env = [] { const char* e = getenv("MDGAT_F64_ATTENTION_FORM"); const int m = e ? atoi(e) : -1; return m == 0 || m == 1 ? m : -1; }();
+    return env;
+}
+extern "C" int mdgat_set_f64_attention_form(int mode) {
+    const int prev = attention_form();
+    g_attention_form.store(mode == 0 || mode == 1 ? mode : mode == -1 ? -1 : -2, std::memory_order_relaxed);
+    return prev;
+}
+
 int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s, unsigned* guard) {
     if (B <= 0 || N <= 0 || M <= 0) return MDGAT_OK;
     const int nk_max = N > M ? N : M, nk_min = N < M ? N : M;
@@ -877,8 +955,9 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         (void)tag;
         static std::atomic<unsigned long long> done{0};
         a.hist_ints = tk ? attn_hist_ints(nk_min, nk_max) : 0;
-        const size_t lds = attn_lds_bytes(QT, nk_max, tk, a.hist_ints);
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), attn_lds_bytes(QT, cap, tk, tk ? (cap > 512 ? 4 * RS_HIST_INTS : 16 * RQ_HIST_INTS) : 0), done, "attention_f64 LDS")) return rc;
+        const bool solo = QT > 32;        // (QT = the queries of a workgroup; the one-wave-per-query-block form keeps only the exponential's table in LDS)
+        const size_t lds = solo ? 256 * sizeof(double) : attn_lds_bytes(QT, nk_max, tk, a.hist_ints);
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), solo ? lds : attn_lds_bytes(QT, cap, tk, tk ? (cap > 512 ? 4 * RS_HIST_INTS : 16 * RQ_HIST_INTS) : 0), done, "attention_f64 LDS")) return rc;
         a.tiles = (nk_max + QT - 1) / QT;
         hipLaunchKernelGGL(kern, dim3(8 * a.tiles * ugroups), dim3(256), lds, s, a);
         return mdgat_check_hip(hipGetLastError(), "attention_f64 launch");
@@ -892,6 +971,11 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         static const int qb_env = [] { const char* e = getenv("MDGAT_F64_ATT_QB"); return e ? atoi(e) : 0; }();
         const bool small = 8L * ((nk_max + 31) / 32) * ugroups < 2L * f64_cu_count();
         if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false, 0, std::integral_constant<int, 0>());
+        // one wave per 32 queries (SOLO) from F64_SOLO_MIN_WG_PER_CU workgroups of four such waves per CU on (mdgat_set_f64_attention_form)
+        const int form = attention_form();
+        const long solo_wgs = 8L * ((nk_max + 127) / 128) * ugroups;
+        if (qb_env != 2 && (form == 1 || (form != 0 && solo_wgs >= F64_SOLO_MIN_WG_PER_CU * (long)f64_cu_count())))
+            return go(attention_f64_kernel<false, 2, false, false, true>, 128, false, 0, std::integral_constant<int, 6>());
         return go(attention_f64_kernel<false, 2, false>, 32, false, 0, std::integral_constant<int, 1>());
     }
     if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 1, true, true>, 16, true, 512, std::integral_constant<int, 2>())

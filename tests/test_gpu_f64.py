@@ -60,11 +60,20 @@ def _sides(qkv, N, M, cross):
 
 @pytest.mark.parametrize('N,M', [(64, 64), (40, 56), (512, 512), (257, 130), (33, 31), (2048, 1300), (16, 16), (5, 3)])
 @pytest.mark.parametrize('cross', [False, True])
-def test_attention_f64_full(N, M, cross):
+@pytest.mark.parametrize('form', [0, 1])
+def test_attention_f64_full(N, M, cross, form):
+    """Both launch forms of the full-attention kernel (mdgat_set_f64_attention_form: 0 = the keys of a query tile split over the four
+    waves, what launches of this size get by default; 1 = one wave per 32 queries, what batches of 32 pairs of 512 keypoints get)."""
+    from mdgat_matcher_amd import _lib
+    lib = _lib.load()
     rs = np.random.RandomState(N + 7 * M + cross)
     B = 2 if N <= 512 else 1
     qkv = torch.from_numpy(rs.standard_normal((B, N + M, 3, 4, 32)) * 1.3)
-    out = ops.attention_f64(qkv.to(DEV), N, M, cross).cpu()
+    lib.mdgat_set_f64_attention_form(form)
+    try:
+        out = ops.attention_f64(qkv.to(DEV), N, M, cross).cpu()
+    finally:
+        lib.mdgat_set_f64_attention_form(-2)
     for (lo, hi), q, k, v in _sides(qkv, N, M, cross):
         ref, _ = O.attention(q, k, v)
         assert (out[:, lo:hi] - _ref_msg_to_lib(ref)).abs().max() < F64_TOL
@@ -448,8 +457,12 @@ def test_f64_refuses_non_finite_values_mid_stack(plant):
 
 def test_f64_large_batch_runs_in_slices_on_two_lanes():
     """40 pairs of 512 keypoints are more than 32 768 keypoints: the library cuts the batch into two slices on two lanes (csrc/api.hip:
-    forward_batched) - in the exact mode too, each lane with its own fp64 workspace.  What a pair returns does not depend on the
-    batch it travels in: bit-identical to the pair run alone, and the lanes setting changes nothing."""
+    forward_batched) - in the exact mode too, each lane with its own fp64 workspace.  The lanes setting changes no bit.  What a pair
+    returns does not depend on the batch it travels in: with full attention in the split-key form at every launch size
+    (mdgat_set_f64_attention_form(0)) bit for bit; by default the 32-pair slice runs the one-wave-per-query-block form, which sums a
+    row in another order than the form a single pair gets - the same matches, Z equal to the rounding of the fp32 hand-over."""
+    from mdgat_matcher_amd import _lib
+    lib = _lib.load()
     L = 2
     cfg = synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=20, arithmetic='fp64')
     net = MDGAT(cfg).double()
@@ -457,16 +470,26 @@ def test_f64_large_batch_runs_in_slices_on_two_lanes():
     net = net.eval().to(DEV)
     data = synth.make_batch(40, 512, 512, device=DEV, first_pair=500)
     args = (data['keypoints0'], data['descriptors0'], data['keypoints1'], data['descriptors1'], data['scores0'], data['scores1'])
-    m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
-    torch.cuda.synchronize()
-    net.check(DEV)
-    for b in (0, 19, 20, 39):
-        one = net.match(*[a[b:b + 1] for a in args], return_scores=True)
-        assert torch.equal(one[0][0], m0[b]) and torch.equal(one[1][0], m1[b]) and torch.equal(one[4][0], Z[b]), b
-    net.set_lanes(1)
-    again = net.match(*args, return_scores=True)
-    assert torch.equal(again[0], m0) and torch.equal(again[4], Z)
-    net.set_lanes(2)
+    for form in (0, -1):
+        prev = lib.mdgat_set_f64_attention_form(form)
+        try:
+            m0, m1, s0, s1, Z = net.match(*args, return_scores=True)
+            torch.cuda.synchronize()
+            net.check(DEV)
+            for b in (0, 19, 20, 39):
+                one = net.match(*[a[b:b + 1] for a in args], return_scores=True)
+                assert torch.equal(one[0][0], m0[b]) and torch.equal(one[1][0], m1[b]), (form, b)
+                if form == 0:
+                    assert torch.equal(one[4][0], Z[b]), b
+                else:
+                    assert (one[4][0] - Z[b]).abs().max().item() < 1e-5, (b, (one[4][0] - Z[b]).abs().max().item())
+            net.set_lanes(1)
+            again = net.match(*args, return_scores=True)
+            assert torch.equal(again[0], m0) and torch.equal(again[4], Z)
+            net.set_lanes(2)
+        finally:
+            lib.mdgat_set_f64_attention_form(-2)
+            assert prev == -1
 
 
 def test_fuzz_forward_f64_short():
