@@ -1067,8 +1067,13 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
     const float NEG_INF = -__builtin_inff();
     const int last_lim = nk - (nblk - 1) * 32 - 8 * hi;
     const bool last_partial = (nk & 31) != 0;
-    const _Float16* kg = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64 + 8 * hi;
-    const _Float16* vg = a.vt16 + (((size_t)b * 4 + head) * 64 + l31) * a.PP + (src ? a.Npad : 0) + 8 * hi;
+    const _Float16* kg0 = a.k16 + (((size_t)b * P + k_off) * 4 + head) * 64;     // (wave-uniform: the base of the K descriptors)
+    const int koff = (krow * 256 + 8 * hi) * (int)sizeof(_Float16);             // this lane's key row and half of the dims inside a block
+    // (V^T likewise: one descriptor of this unit's two planes, the lane's row (dim l31) and half of a 16-key step as its offset, the
+    // step's column as the scalar offset; the key blocks are clamped to the frame, the rows are padded: everything is in range)
+    const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(a.vt16 + ((size_t)b * 4 + head) * 64 * a.PP + (src ? a.Npad : 0)), 0,
+                                                                        64 * a.PP * (int)sizeof(_Float16), 0x00020000);
+    const int voff = (l31 * a.PP + 8 * hi) * (int)sizeof(_Float16);
     WideComm<NW> comm{xbuf, wave, lane, 0, fsm + 1040 + 8 * 18 * 64};
     const bool whole = nk == 256 * NW;        // every wave's eight blocks are real keys: no pads anywhere in a row
     const int npass = (nq + 32 * NG - 1) / (32 * NG);
@@ -1086,26 +1091,33 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         }
         const int kexp = nk <= a.topk ? (1 << 30) : a.topk;     // (every key is kept when the frame has just k of them)
         f32x16 S[NBLK];
-        // K fragments come straight from L2: the loads of block jb + 1 are issued before the products of block jb (left to
-        // itself the compiler puts every load right in front of its use and waits for it: ~24 exposed round trips per tile)
-        f16x8 kn[4];
-        auto kload = [&](int jb, f16x8 (&k)[4]) __attribute__((always_inline)) {
-            const int gb = kw * NBLK + jb;
-            const int key = min(gb * 32 + krow, nk - 1);          // rows past the end: any finite data, masked below
-            const _Float16* kp = kg + (size_t)key * 256;
-            k[0] = *reinterpret_cast<const f16x8*>(kp);
-            k[1] = *reinterpret_cast<const f16x8*>(kp + 16);
-            k[2] = *reinterpret_cast<const f16x8*>(kp + 32);
-            k[3] = *reinterpret_cast<const f16x8*>(kp + 48);
-        };
+        // K fragments come straight from L2.  ALL eight blocks' loads are issued before the first product: a block's fragments are
+        // sixteen registers - exactly what its logits S[jb] will take - and S is dead at this point of a pass, so the loads of the
+        // whole row cost no register the tile does not hold anyway, and the phase waits for ONE round trip to L2 instead of one per
+        // block.  (Round 2-5: the loads of block jb + 1 issued before the products of block jb - one block of lookahead is ~400
+        // cycles of work against a round trip of ~2 000: the phase took 18 700 cycles for 48 MFMAs.  Left to itself the compiler puts
+        // every load right in front of its use and waits for it: ~24 exposed round trips per tile.)
+        // Buffer loads: a block's descriptor (its first key's row of this head; bytes up to the end of the frame's keys) is built in
+        // scalar registers, the lane's offset into the block is one register for the whole kernel.  Per-key 64-bit pointers - the
+        // same in every pass - were hoisted out of the pass loop by the compiler, spilled (the kernel sits at 256 registers), and
+        // reloaded from scratch in front of each block's loads: a scratch reload waits for EVERY load in flight.  Keys a ragged
+        // last block reaches beyond the frame are out of range and load as zeros (masked below).
+        f16x8 kf[NBLK][4];
         WT(0);
-        kload(0, kn);
 #pragma unroll
         for (int jb = 0; jb < NBLK; ++jb) {
             const int gb = kw * NBLK + jb;
-            const f16x8 kh0 = kn[0], kh1 = kn[1], kl0 = kn[2], kl1 = kn[3];
-            if (jb + 1 < NBLK) kload(jb + 1, kn);
-            __builtin_amdgcn_sched_barrier(0);
+            const int left = nk - gb * 32 - 1;                    // keys of the frame behind this block's first
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<_Float16*>(kg0 + (size_t)gb * (32 * 256)), 0,
+                                                                               left < 0 ? 0 : left * 512 + 128, 0x00020000);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kf[jb][j] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, koff, 32 * j, 0));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int jb = 0; jb < NBLK; ++jb) {
+            const int gb = kw * NBLK + jb;
+            const f16x8 kh0 = kf[jb][0], kh1 = kf[jb][1], kl0 = kf[jb][2], kl1 = kf[jb][3];
             if (gb < nblk) {
                 f32x16 acc, acx;
 #pragma unroll
@@ -1128,6 +1140,7 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) S[jb][r] = NEG_INF;
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         WT(1);
         float m = NEG_INF;
@@ -1181,9 +1194,9 @@ __global__ __launch_bounds__(512, 2) void attention_topk_wide_kernel(AttnArgs a)
         f16x8 vhn, vln;
         auto vload = [&](int step, f16x8& h, f16x8& l) __attribute__((always_inline)) {
             const int gb = min(kw * NBLK + (step >> 1), nblk - 1);
-            const _Float16* vp = vg + gb * 32 + (step & 1) * 16;
-            h = *reinterpret_cast<const f16x8*>(vp);
-            l = *reinterpret_cast<const f16x8*>(vp + (size_t)32 * a.PP);
+            const int col = (gb * 32 + (step & 1) * 16) * (int)sizeof(_Float16);
+            h = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, col, 0));
+            l = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(vrs, voff, col + 32 * a.PP * (int)sizeof(_Float16), 0));
         };
         vload(0, vhn, vln);
 #pragma unroll
