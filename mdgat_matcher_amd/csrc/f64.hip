@@ -23,7 +23,9 @@
 //   attention_f64_kernel  attention / dynamic_attention (mdgat.py:190-210) for 16 (or 32) queries of a (pair, frame, head) per
 //                         workgroup, the KEYS split over the four waves: S^T = K Q^T puts a query's logits into the four lanes
 //                         (q, q + 16, q + 32, q + 48), the D fragment of a 16-key block is the B operand of the P.V product as
-//                         it stands.  Full attention: online softmax per wave, the waves combined at the end.  Dynamic attention:
+//                         it stands.  Full attention: online softmax per wave, the waves combined at the end - or, for launches
+//                         that fill the chip, the QUERIES split over the waves (SOLO: a wave walks all keys, nothing to combine).
+//                         K / V fragments by buffer loads (scalar descriptor, constant lane offset).  Dynamic attention:
 //                         pass A writes the fp32 roundings of the logits to LDS, one wave per row finds the
 //                         exact k-th largest of them, pass B recomputes the fp64 logits and keeps what lies above; logits whose
 //                         fp32 roundings TIE at the k-th place are ranked by their fp64 values (a short list per row, resolved
@@ -336,8 +338,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) void a
             qf[qb][2 * j + 1] = v[1] * 0.17677669529663687;
         }
     }
-    const int nblk = (nk + 15) >> 4;                    // 16-key blocks; this wave: blocks wave, wave + 4, ...
-    // K fragment of a block: dims 8 g .. 8 g + 7 of key 16 jb + l15 (A operand; dim 8 g + j at k-step j, as in qf)
+    const int nblk = (nk + 15) >> 4;                    // 16-key blocks; this wave: blocks wave, wave + 4, ... (SOLO: all of them)
     // Buffer loads: a descriptor of this frame's keys (values) is built once in scalar registers, a block's offset into it is a scalar,
     // this lane's offset into the block a constant of the kernel - so a trip spends NO vector instruction on addresses (per-key pointers
     // clamped to the frame - add, min, 64-bit multiply-add - were 3 of them per block for K and 12 for V).  The scalar offset takes no
