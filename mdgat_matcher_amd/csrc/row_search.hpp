@@ -277,7 +277,8 @@ __device__ RowSearch topk_quad_search(const float* rows_, int pitch, int nk, int
     int above = 0, ceq = 0;
     unsigned width = 256u;
     FT(9);
-    int ft_level = 0;
+    int ft_level = 0;                    // (only the -DF64_TRACE build reads it)
+    (void)ft_level;
     for (;;) {
         FT(10 + 3 * min(ft_level, 2));
         typedef int rq_i4 __attribute__((ext_vector_type(4)));
