@@ -970,13 +970,14 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         // same arithmetic per row; MDGAT_F64_ATT_QB=1|2 forces one for measurements.  64 queries per workgroup - 234 registers, two
         // waves per SIMD - lose: 236 -> 289 us at batch 32)
         static const int qb_env = [] { const char* e = getenv("MDGAT_F64_ATT_QB"); return e ? atoi(e) : 0; }();
-        const bool small = 8L * ((nk_max + 31) / 32) * ugroups < 2L * f64_cu_count();
-        if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false, 0, std::integral_constant<int, 0>());
-        // one wave per 32 queries (SOLO) from F64_SOLO_MIN_WG_PER_CU workgroups of four such waves per CU on (mdgat_set_f64_attention_form)
+        // one wave per 32 queries (SOLO) from F64_SOLO_MIN_WG_PER_CU workgroups of four such waves per CU on; mdgat_set_f64_attention_form(1)
+        // forces it at every size (tests: ragged frames, one pair), (0) never
         const int form = attention_form();
         const long solo_wgs = 8L * ((nk_max + 127) / 128) * ugroups;
-        if (qb_env != 2 && (form == 1 || (form != 0 && solo_wgs >= F64_SOLO_MIN_WG_PER_CU * (long)f64_cu_count())))
-            return go(attention_f64_kernel<false, 2, false, false, true>, 128, false, 0, std::integral_constant<int, 6>());
+        const bool solo = qb_env == 0 && (form == 1 || (form != 0 && solo_wgs >= F64_SOLO_MIN_WG_PER_CU * (long)f64_cu_count()));
+        if (solo) return go(attention_f64_kernel<false, 2, false, false, true>, 128, false, 0, std::integral_constant<int, 6>());
+        const bool small = 8L * ((nk_max + 31) / 32) * ugroups < 2L * f64_cu_count();
+        if (qb_env == 1 || (qb_env != 2 && small)) return go(attention_f64_kernel<false, 1, false>, 16, false, 0, std::integral_constant<int, 0>());
         return go(attention_f64_kernel<false, 2, false>, 32, false, 0, std::integral_constant<int, 1>());
     }
     if (nk_max <= 512) return a.sel ? go(attention_f64_kernel<true, 1, true, true>, 16, true, 512, std::integral_constant<int, 2>())

@@ -233,6 +233,40 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     assert torch.equal(plain[0], m0) and torch.equal(plain[1], m1) and torch.equal(plain[4], Z)
 
 
+@pytest.mark.parametrize('name', ['cfg_n512_L9_S100', 'cfg_n256_L4_S20', 'cfg_n2048_L9_S200'])
+def test_literal_bar_in_the_big_batch_attention_form(golden_dir, name):
+    """The same bar with full attention forced into the form batches of 32 pairs and more get (one wave per 32 queries over all keys,
+    mdgat_set_f64_attention_form(1)): the reference-held pairs are batches of 8 / 8 / 1, so by default they exercise the split-key form
+    only.  Matches bit-identical to the reference's, Z within the literal 1e-4 on every held entry - and matches and Z (to the rounding
+    of the fp32 hand-over) the same as in the default form."""
+    from mdgat_matcher_amd import _lib
+    lib = _lib.load()
+    g = _g(golden_dir, name)
+    net, cfg, sd, data, (B, n, m, L) = _build(g)
+    assert net.exact()
+    dev = {k: v.to(DEV) for k, v in data.items()}
+    args = (dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'])
+    base = net._run(*args, want_Z=True)
+    assert lib.mdgat_set_f64_attention_form(1) == -1
+    try:
+        m0, m1, s0, s1, Z = net._run(*args, want_Z=True)
+        torch.cuda.synchronize()
+        net.check(DEV)
+    finally:
+        lib.mdgat_set_f64_attention_form(-2)
+    Zc = Z.cpu().double().numpy()
+    sub = int(g['sub']) if 'sub' in g else 8
+    mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    err = np.abs(mine - ref_Z).reshape(B, -1).max(1)
+    print(f'[parity-f64] {name}, one wave per 32 queries: per-pair max|dZ| vs the reference {np.array2string(err, precision=2)}; '
+          f'against the split-key form {(Z - base[4]).abs().max().item():.2e}')
+    np.testing.assert_array_equal(m0.cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(m1.cpu().numpy(), g['default_matches1'])
+    assert (err < Z_TOL).all(), err
+    assert torch.equal(m0, base[0]) and torch.equal(m1, base[1]) and (Z - base[4]).abs().max().item() < 1e-5
+
+
 @pytest.mark.parametrize('name', ['var_n256_L4_S20', 'var_n512_L9_S100', 'var_n400m512_L9_S100'])
 def test_literal_bar_on_the_reference_held_variants(golden_dir, name):
     """The other reference-held pairs at config scale (tests/golden/var_*.npz): all four extraction branches of mdgat.py:441-483 and
