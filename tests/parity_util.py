@@ -108,6 +108,28 @@ def assert_attributed(res, tag=''):
     assert res['flip_rows'] <= max(4, int(8e-4 * res['topk_rows'])), (res['flip_rows'], res['topk_rows'])
 
 
+def near_tie_mismatches(Z, m0, m1, ref_m0, ref_m1, tol):
+    """Entries of matches0 / matches1 (default extraction branch, mdgat.py:461-464, 480-483: arg-max over a row / column of Z including
+    the dustbin) that differ from the reference's, each checked to be a NEAR TIE by the HIP path's own Z: the reference's choice lies
+    within ``tol`` of the maximum this path found.  Returns the list of (side, pair, index, mine, ref, gap); asserts that every
+    mismatch is such a near tie.  (An arg-max is decided by the gap between its two best candidates; a Z that is accurate to 6e-6 -
+    the exact mode, whose Sinkhorn runs in fp32 - cannot order candidates the reference's fp64 Z separates by 1e-6.)"""
+    import numpy as np
+    Zc = Z.cpu().double().numpy()
+    B, N1, M1 = Zc.shape
+    N, M = N1 - 1, M1 - 1
+    out = []
+    for side, mine, ref in ((0, m0.cpu().numpy(), np.asarray(ref_m0)), (1, m1.cpu().numpy(), np.asarray(ref_m1))):
+        for b, i in zip(*np.nonzero(mine != ref)):
+            lim = M if side == 0 else N
+            a = int(mine[b, i]) if mine[b, i] >= 0 else lim          # -1 = the dustbin = the last column / row
+            r = int(ref[b, i]) if ref[b, i] >= 0 else lim
+            gap = (Zc[b, i, a] - Zc[b, i, r]) if side == 0 else (Zc[b, a, i] - Zc[b, r, i])
+            out.append((side, int(b), int(i), int(mine[b, i]), int(ref[b, i]), float(gap)))
+            assert 0.0 <= gap < tol, f'matches{side}[{b}, {i}] = {mine[b, i]} (reference {ref[b, i]}) is not a near tie: Z gap {gap:.3e}'
+    return out
+
+
 def assert_plain(res, ref_Z, ref_m0, ref_m1, ref_s0, ref_s1, tag='', z_index=None):
     """Unconditional comparison of a forward (``res`` from attributed_parity) with the UNFORCED fp64 result: the
     reference's golden output or the plain oracle.  ``ref_Z`` may be a subsample: ``z_index(Z) -> array`` then picks

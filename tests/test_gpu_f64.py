@@ -233,6 +233,43 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     assert torch.equal(plain[0], m0) and torch.equal(plain[1], m1) and torch.equal(plain[4], Z)
 
 
+def test_literal_bar_on_a_reference_held_batch_that_runs_in_slices(golden_dir):
+    """tests/golden/cfg_n512_L9_S100_b40.npz: 40 pairs of the headline shape run through the REFERENCE as one batch.  Here they are
+    more than 32 768 keypoints: the library cuts them into slices of 32 + 8 pairs on two lanes, and the 32-pair slice gets the
+    kernels big launches get (full attention with one wave per 32 queries, 32-keypoint layer tiles).  Through the dict API of a
+    float64 module with no extra key, against the reference's own outputs: matching scores and every held entry of Z within the
+    literal 1e-4 on all 40 pairs; matches identical except arg-max NEAR TIES below this mode's Z accuracy (its Sinkhorn and the layers
+    behind the last dynamic one run in fp32: Z is good to 6e-6) - the batch holds exactly one: pair 18, column 71, whose two best
+    rows the reference's fp64 Z separates by 1.3e-6 (40 960 arg-maxes in the batch).  Every mismatch is checked to be such a tie
+    by this path's own Z (2e-5)."""
+    g = _g(golden_dir, 'cfg_n512_L9_S100_b40')
+    net, cfg, sd, data, (B, n, m, L) = _build(g)
+    assert net.exact() and 'arithmetic' not in cfg and B == 40
+    dev = {k: v.to(DEV) for k, v in data.items()}
+    with torch.no_grad():
+        out = net(dev)
+        Z = net.match(dev['keypoints0'], dev['descriptors0'], dev['keypoints1'], dev['descriptors1'], dev['scores0'], dev['scores1'],
+                      return_scores=True)[4]
+    torch.cuda.synchronize()
+    net.check(DEV)
+    from parity_util import near_tie_mismatches
+    ties = near_tie_mismatches(Z, out['matches0'], out['matches1'], g['default_matches0'], g['default_matches1'], 2e-5)
+    print(f'[parity-f64] cfg_n512_L9_S100_b40: arg-max near ties decided the other way: {ties}')
+    assert len(ties) <= 2, ties
+    es = max(np.abs(out['matching_scores0'].cpu().numpy() - g['default_mscores0']).max(),
+             np.abs(out['matching_scores1'].cpu().numpy() - g['default_mscores1']).max())
+    Zc = Z.cpu().double().numpy()
+    sub = int(g['sub'])
+    mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    err = np.abs(mine - ref_Z).reshape(B, -1).max(1)
+    print(f'[parity-f64] cfg_n512_L9_S100_b40: worst pair max|dZ| vs the reference {err.max():.2e}, mscores {es:.2e}; '
+          f'pairs within the literal 1e-4: {int((err < Z_TOL).sum())}/{B}')
+    assert (err < Z_TOL).all(), err
+    assert es < Z_TOL
+    assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
+
+
 @pytest.mark.parametrize('name', ['cfg_n512_L9_S100', 'cfg_n256_L4_S20', 'cfg_n2048_L9_S200'])
 def test_literal_bar_in_the_big_batch_attention_form(golden_dir, name):
     """The same bar with full attention forced into the form batches of 32 pairs and more get (one wave per 32 queries over all keys,

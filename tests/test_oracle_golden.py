@@ -63,7 +63,8 @@ def test_extraction_variants(golden_dir, name):
         np.testing.assert_allclose(s1.numpy(), g[f'{tag}_mscores1'], atol=TOL, err_msg=tag)
 
 
-@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b', 'cfg_n512_L9_S100_seed7'])
+@pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b', 'cfg_n512_L9_S100_seed7',
+                                  'cfg_n512_L9_S100_b40'])
 def test_config_shapes(golden_dir, name):
     g = _load(golden_dir, name)
     sd, data, k, L, S, n, m = _setup(g)

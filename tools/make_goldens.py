@@ -332,6 +332,9 @@ def main():
         ('cfg_n2048_L9_S200_b', lambda nm: gen_config(M, nm, 3, 2048, 2048, 9, 200, synth.DEFAULT_K, first_pair=1, sub=16)),
         # other weights, other bin score
         ('cfg_n512_L9_S100_seed7', lambda nm: gen_config(M, nm, 4, 512, 512, 9, 100, synth.DEFAULT_K, seed=7, first_pair=40, bin_score=0.37)),
+        # a batch of the headline shape large enough to run in slices on two lanes in the library (40 pairs: 32 + 8), so that the kernels
+        # big launches get (round 6: full attention with one wave per 32 queries) are pinned to the reference's outputs too
+        ('cfg_n512_L9_S100_b40', lambda nm: gen_config(M, nm, 40, 512, 512, 9, 100, synth.DEFAULT_K, first_pair=200, sub=32)),
         ('var_n256_L4_S20', lambda nm: gen_config_variants(M, nm, 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)),
         ('var_n512_L9_S100', lambda nm: gen_config_variants(M, nm, 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)),
         ('var_n400m512_L9_S100', lambda nm: gen_config_variants(M, nm, 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)),
