@@ -261,6 +261,17 @@ int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, in
                    float* Z, void* workspace, size_t workspace_bytes, void* stream);
 size_t mdgat_sinkhorn_workspace_bytes(int B, int N, int M);
 
+/* The same in fp64 - the reference's own arithmetic (mdgat.py:279-308 run in float64, test.py:193) - on fp64 scores: Z [B][N+1][M+1]
+ * fp64; M <= 575.  workspace: mdgat_sinkhorn_f64_workspace_bytes, 256-byte aligned. */
+int mdgat_sinkhorn_f64(int B, int N, int M, const double* scores, double bin_score, int iters,
+                       double* Z, void* workspace, size_t workspace_bytes, void* stream);
+size_t mdgat_sinkhorn_f64_workspace_bytes(int B, int N, int M);
+/* ... followed by the match extraction (mdgat.py:441-483) with every arg-max decided on the fp64 Z (a near tie of 1e-6 between two
+ * candidates is below what an fp32 Z resolves); Z_or_null: optional fp32 rounding of Z [B][N+1][M+1]. */
+int mdgat_sinkhorn_f64_extract(int B, int N, int M, const double* scores, double bin_score, int iters, int mode, float match_threshold,
+                               int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z_or_null,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
 /* match extraction (mdgat.py:441-483) from Z [B][N+1][M+1]. */
 int mdgat_extract(int B, int N, int M, const float* Z, int mode, float match_threshold,
                   int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1,

@@ -183,6 +183,8 @@ size_t mdgat_sinkhorn_ws_bytes_impl(int B, int N, int M);
 
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1,
                    float* s0, float* s1, hipStream_t s);
+int launch_extract_from_bests(int B, int N, int M, const SkExtract* ex, const int* rbest_idx, const float* rbest_val, const int* cbest_idx,
+                              const float* cbest_val, hipStream_t s);
 
 int launch_pose(int B, int N, int M, const float* kpts0, const float* kpts1, const int64_t* matches0, const double* T_gt,
                 double inlier_dist, double* T, double* stats, hipStream_t s);

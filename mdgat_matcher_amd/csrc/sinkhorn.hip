@@ -1337,6 +1337,15 @@ static int launch_extract_impl(int B, int N, int M, ExArgs a, hipStream_t s, boo
     return launch_alldust_fixup(B, N, M, a.mode, a.m0, a.s1, s);
 }
 
+// the extraction from arg-maxes another kernel has decided (sinkhorn_f64.hip: on the fp64 Z): rbest [B][N], cbest [B][M]
+int launch_extract_from_bests(int B, int N, int M, const SkExtract* ex, const int* rbest_idx, const float* rbest_val, const int* cbest_idx,
+                              const float* cbest_val, hipStream_t s) {
+    if (B <= 0) return MDGAT_OK;
+    ExArgs xa{nullptr, N, M, ex->mode, ex->thr, ex->m0, ex->m1, ex->s0, ex->s1, nullptr, nullptr, nullptr, nullptr, B, rbest_idx, rbest_val, cbest_idx, cbest_val,
+              1, 1, ex->matched, ex->matched_token};
+    return launch_extract_impl(B, N, M, xa, s, ex->defer_alldust != 0);
+}
+
 int launch_extract(int B, int N, int M, const float* Z, int mode, float thr, int64_t* m0, int64_t* m1, float* s0,
                    float* s1, hipStream_t s) {
     if (B <= 0) return MDGAT_OK;

@@ -1,0 +1,362 @@
+// log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308) in fp64 - the reference's own arithmetic - for the
+// reference-exact mode's arg-max.  Why: with the encoders and the layers in fp64 (f64.hip, layer_f64.hip) what is left of the
+// exact mode's Z error is its fp32-class tail: 1.35e-6 rms, 7e-6 max (profiles/NOTES_r6.md section 11).  That is far inside the
+// bar on Z (1e-4) but not below the gap of every arg-max: among 40 960 arg-maxes of a reference-held batch of 40 pairs one had its
+// two candidates 1.3e-6 apart in the reference's fp64 Z, and fell the other way.  With the scores and the transport in fp64 the
+// arg-maxes are the reference's down to gaps of 1e-12.
+//
+// The iteration, in the scaling form (as sinkhorn.hip runs it in fp32; the same map as the log-domain one the reference writes):
+// with Z0 the couplings (scores, bin score on the border), r_i = max_j Z0_ij and K_ij = exp(Z0_ij - r_i),
+//      a_i = mu_i / sum_j K_ij b_j,     b_j = nu_j / sum_i K_ij a_i      (b = 1 at start: v = 0, mdgat.py:281-284 updates u first)
+//      Z_ij = Z0_ij - r_i + log a_i + log b_j - norm,      mu, nu, norm as mdgat.py:300-307.
+// fp64 has the range for it: every K is in (e^-700, 1], the scaling factors stay within e^(+-|scores|).
+//
+// gfx950 mapping.  A pair's N x (M + 1) block of K stays in REGISTERS for all iterations, spread over G = ceil(N / 32) workgroups of
+// eight waves: workgroup g owns rows 32 g .. 32 g + 31, wave w of it four of them, lane l the columns l, l + 64, ... (nine per lane
+// at M = 512: 36 doubles); the dustbin ROW is all ones after its maximum is taken out and is carried as one scalar.  Row sums are in-lane dot products and one butterfly per row; column sums are in-lane over
+// the wave's four rows, merged over the eight waves through LDS and over the G workgroups through memory: every workgroup publishes
+// its M + 1 partials (write-through stores, acknowledged before the workgroup's flag goes out), waits for its partners' flags and adds
+// the G partials of a column in slab order - the same bits in every workgroup.  Two slot sets alternate by iteration parity (a workgroup can only be two
+// iterations ahead of a partner it has not heard from).  Spins are bounded: a timeout raises the error word and the call fails.
+// The partners of a pair sit on one XCD under round-robin dispatch (blockIdx % 8), which only matters for speed.
+#include "common.hpp"
+#include "f64.hpp"
+#include "sinkhorn_f64.hpp"
+
+namespace {
+
+constexpr int S64_THREADS = 512, S64_ROWS = 32, S64_NC = 9;          // nine columns per lane: M + 1 <= 576
+constexpr int S64_SLOT = 576;                                        // doubles per published vector (>= M + 1, 64-aligned)
+constexpr int S64_GMAX = 18;                                         // row slabs of a pair at most: N + 1 <= 576
+
+struct Sk64Args {
+    const double* scores;      // [B][N][M]
+    double alpha;
+    int B, N, M, iters, G, inner;
+    double* Z64;               // optional [B][N + 1][M + 1]
+    float* Z32;                // optional, the fp32 rounding of the same
+    int* rbest_idx; float* rbest_val;      // optional [B][N]: arg-max of every row (over the columns the extraction mode scans)
+    int* cslab_idx; double* cslab_val;     // optional [B][G][M]: arg-max of every column over this workgroup's rows, value in fp64 (merged by
+                                           // sinkhorn_f64_merge_kernel: a merge on fp32 roundings would undo the fp64 decision between slabs)
+    double* slots;             // [B][2][G][S64_SLOT]
+    unsigned* flags;           // [B][3][G], zeroed per launch: two sets of iteration flags, then the partners' XCC ids + 1
+    unsigned* error_word;      // bit 0: a workgroup gave up waiting for a partner
+};
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) {
+        const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+        const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
+        v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+    }
+    return v;
+}
+__device__ __forceinline__ double shfl_xor_d(double v, int m) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
+__global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a) {
+    __shared__ double colbuf[8][S64_SLOT];      // column partials of the eight waves; in the epilogue the values of the column arg-max
+    __shared__ double bl[S64_SLOT];             // the new b, for every lane to pick its columns from; in the epilogue the dustbin row of Z
+    __shared__ int cidx[8][S64_SLOT];           // row indices of the column arg-max (epilogue)
+    __shared__ int dead, same_xcd_s;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, M = a.M, G = a.G;
+    // blockIdx = (pair / 8) * (8 G) + g * 8 + pair % 8: the G workgroups of a pair share blockIdx % 8
+    const int grp = blockIdx.x / (8 * G), rem = blockIdx.x % (8 * G);
+    const int pair = grp * 8 + (rem & 7), g = rem >> 3;
+    if (pair >= a.B) return;
+    if (tid == 0) dead = 0;
+    const double* sc = a.scores + (size_t)pair * N * M;
+    const int row0 = g * S64_ROWS + wave * 4;            // this wave's rows row0 .. row0 + 3 (real rows: < N)
+    const double nm = (double)(N + M);
+    const double norm = -log(nm);
+    const bool last = g == G - 1;                        // the slab that also carries the dustbin row
+    auto z0 = [&](int i, int j) -> double { return j < M ? sc[(size_t)i * M + j] : a.alpha; };      // (real rows only)
+
+    // K = exp(Z0 - row maximum): 4 x 9 doubles per lane.  The DUSTBIN ROW needs no storage: its couplings are the bin score in every
+    // column (mdgat.py:296-298), so K = 1 throughout - its row sum is the sum of b, its share of every column sum is a_N itself.
+    double K[4][S64_NC], r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + i;
+        double m = -__builtin_inf();
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) {
+            const int j = lane + 64 * c;
+            K[i][c] = (row < N && j <= M) ? z0(row, j) : -__builtin_inf();
+            m = fmax(m, K[i][c]);
+        }
+#pragma unroll
+        for (int s = 1; s < 64; s <<= 1) m = fmax(m, shfl_xor_d(m, s));
+        r[i] = m;
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) K[i][c] = (row < N && lane + 64 * c <= M) ? exp(K[i][c] - m) : 0.0;
+    }
+    const double mu = 1.0 / nm, muN = (double)M / nm;
+    double b[S64_NC], av[4], aN = 0.0;
+#pragma unroll
+    for (int c = 0; c < S64_NC; ++c) b[c] = lane + 64 * c <= M ? 1.0 : 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) av[i] = 0.0;
+    double* slots = a.slots + (size_t)pair * 2 * G * S64_SLOT;
+    unsigned* flags = a.flags + (size_t)pair * 3 * G;
+    // Do the G workgroups of this pair share an XCD (they do under round-robin dispatch: blockIdx % 8)?  Then they share an L2: PLAIN
+    // stores (the CU's L1 writes through to the XCD's L2 and the line stays there) and L1-bypassing loads carry the exchange inside the
+    // L2.  Agent-scope write-through stores - right wherever the partners run - send every partial on to memory.  Checked once per
+    // launch with an agent-scope exchange.
+    if (tid == 0) {
+        const unsigned my_xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;      // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(flags + 2 * G + g, my_xcc + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int same = 1;
+        for (int q = 0; q < G && same >= 0; ++q) {
+            unsigned v = 0;
+            long spins = 0;
+            while ((v = __hip_atomic_load(flags + 2 * G + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                if (++spins > (1L << 26)) { dead = 1; same = -1; break; }
+            if (same > 0 && v != my_xcc + 1u) same = 0;
+        }
+        same_xcd_s = same > 0;
+    }
+    __syncthreads();
+    const bool same_xcd = same_xcd_s != 0;
+
+    for (int it = 0; it < a.iters; ++it) {
+        // a_i = mu_i / sum_j K_ij b_j; the dustbin row: a_N = mu_N / sum_j b_j (the same bits in every wave of every workgroup)
+        {
+            double sb = 0.0;
+#pragma unroll
+            for (int c = 0; c < S64_NC; ++c) sb += b[c];
+            aN = muN / wave_sum_f64(sb);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double p = 0.0;
+#pragma unroll
+            for (int c = 0; c < S64_NC; ++c) p = __builtin_fma(K[i][c], b[c], p);
+            p = wave_sum_f64(p);
+            av[i] = row0 + i < N ? mu / p : 0.0;
+        }
+        // column partials of this wave's rows -> LDS
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) {
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) q = __builtin_fma(K[i][c], av[i], q);
+            colbuf[wave][lane + 64 * c] = q;
+        }
+        __syncthreads();
+        // The exchange.  Stores (plain inside an XCD: they stay in its L2; write-through otherwise), acknowledged before the workgroup
+        // meets and its flag goes out; the partners' flags polled by G threads; then every thread loads the G partials of its column,
+        // all in flight at once (relaxed agent-scope loads: they pass the non-coherent L1).  Measured against it: release / acquire
+        // FENCES by every thread (a write-back / invalidation of the L2 each): 34 us per iteration for one pair instead of 5.3; the G
+        // loads in a run-time loop (a round trip each): 11.8; the data as its own flag (a tag in the lowest mantissa bit, every thread
+        // polling its G granules): 7.1 - the polling rounds of 512 threads x 16 granules cost more than the two round trips they save.
+        double* mine = slots + ((size_t)(it & 1) * G + g) * S64_SLOT;
+        for (int j = tid; j <= M; j += S64_THREADS) {
+            double p = colbuf[0][j];
+#pragma unroll
+            for (int w = 1; w < 8; ++w) p += colbuf[w][j];
+            if (last) p += aN;                              // the dustbin row's share of the column (K = 1), by one slab
+            if (same_xcd) mine[j] = p;
+            else __hip_atomic_store(mine + j, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        unsigned* fl = flags + (size_t)(it & 1) * G;
+        if (tid == 0) __hip_atomic_store(fl + g, (unsigned)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < G && tid != g && !dead) {
+            long spins = 0;
+            while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(it + 1)) {
+                if (++spins > (1L << 26)) { dead = 1; break; }
+            }
+        }
+        __syncthreads();
+        const double* all = slots + (size_t)(it & 1) * G * S64_SLOT;
+        for (int j = tid; j <= M; j += S64_THREADS) {
+            double v[S64_GMAX];
+#pragma unroll
+            for (int q = 0; q < S64_GMAX; ++q) v[q] = q < G ? __hip_atomic_load(all + (size_t)q * S64_SLOT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            double tot = v[0];
+#pragma unroll
+            for (int q = 1; q < S64_GMAX; ++q) tot += v[q];  // slab order: the same bits in every workgroup (+ 0.0 beyond G)
+            bl[j] = (j < M ? 1.0 / nm : (double)N / nm) / tot;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) b[c] = lane + 64 * c <= M ? bl[lane + 64 * c] : 0.0;
+    }
+    if (dead && tid == 0 && a.error_word) __hip_atomic_store(a.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+
+    // Z = Z0 - r + log a + log b - norm; arg-maxes decided on the fp64 values
+    double lb[S64_NC];
+#pragma unroll
+    for (int c = 0; c < S64_NC; ++c) lb[c] = lane + 64 * c <= M ? log(b[c]) - norm : 0.0;
+    const int jlim = a.inner ? M : M + 1;                  // columns a row's arg-max scans
+    double cb[S64_NC];
+    int ci[S64_NC];
+#pragma unroll
+    for (int c = 0; c < S64_NC; ++c) { cb[c] = -__builtin_inf(); ci[c] = 0x7fffffff; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = row0 + i;
+        if (row >= N) continue;                             // (wave-uniform)
+        const double la = log(av[i]) - r[i];
+        double best = -__builtin_inf();
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) {
+            const int j = lane + 64 * c;
+            if (j > M) continue;
+            const double z = z0(row, j) + la + lb[c];
+            if (a.Z64) a.Z64[((size_t)pair * (N + 1) + row) * (M + 1) + j] = z;
+            if (a.Z32) a.Z32[((size_t)pair * (N + 1) + row) * (M + 1) + j] = (float)z;
+            if (j < jlim && z > best) { best = z; bj = j; }            // ascending j within the lane: the first maximum stays
+            if (z > cb[c]) { cb[c] = z; ci[c] = row; }                 // ascending rows within the wave
+        }
+        if (a.rbest_idx) {
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double ob = shfl_xor_d(best, s);
+                const int oj = __shfl_xor(bj, s, 64);
+                if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }      // torch.max: the first of equal maxima
+            }
+            if (lane == 0) { a.rbest_idx[(size_t)pair * N + row] = bj; a.rbest_val[(size_t)pair * N + row] = (float)best; }
+        }
+    }
+    // the dustbin row of Z (row N: Z0 - r = 0), by the last slab's first wave
+    __syncthreads();
+    if (last && wave == 0) {
+        const double laN = log(aN);
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) {
+            const int j = lane + 64 * c;
+            if (j > M) continue;
+            const double z = laN + lb[c];
+            bl[j] = z;
+            if (a.Z64) a.Z64[((size_t)pair * (N + 1) + N) * (M + 1) + j] = z;
+            if (a.Z32) a.Z32[((size_t)pair * (N + 1) + N) * (M + 1) + j] = (float)z;
+        }
+    }
+    if (a.cslab_idx) {
+        // the column arg-max over this workgroup's rows: waves in ascending row order, strict compare (the first of equal maxima); the
+        // dustbin row - the last of all - joins unless the extraction scans the inner block only
+#pragma unroll
+        for (int c = 0; c < S64_NC; ++c) { colbuf[wave][lane + 64 * c] = cb[c]; cidx[wave][lane + 64 * c] = ci[c]; }
+        __syncthreads();
+        for (int j = tid; j < M; j += S64_THREADS) {
+            double bv = colbuf[0][j];
+            int bi = cidx[0][j];
+#pragma unroll
+            for (int w = 1; w < 8; ++w)
+                if (colbuf[w][j] > bv) { bv = colbuf[w][j]; bi = cidx[w][j]; }
+            if (last && !a.inner && bl[j] > bv) { bv = bl[j]; bi = N; }
+            a.cslab_val[((size_t)pair * G + g) * M + j] = bv;
+            a.cslab_idx[((size_t)pair * G + g) * M + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
+// column arg-max over the G row slabs of a pair, in fp64: ascending slabs, strict compare (the first of equal maxima)
+__global__ __launch_bounds__(256) void sinkhorn_f64_merge_kernel(const int* sidx, const double* sval, int B, int G, int M, int* cbest_idx, float* cbest_val) {
+    const size_t total = (size_t)B * M;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t pair = e / M, j = e % M;
+        const size_t base = pair * G * M + j;
+        double bv = sval[base];
+        int bi = sidx[base];
+        for (int g = 1; g < G; ++g)
+            if (sval[base + (size_t)g * M] > bv) { bv = sval[base + (size_t)g * M]; bi = sidx[base + (size_t)g * M]; }
+        cbest_idx[e] = bi;
+        cbest_val[e] = (float)bv;
+    }
+}
+
+}  // namespace
+
+static size_t s64_align(size_t v) { return (v + 255) & ~(size_t)255; }
+
+size_t sinkhorn_f64_workspace_bytes(int B, int N, int M) {
+    if (B <= 0) return 0;
+    const size_t G = (N + S64_ROWS - 1) / S64_ROWS;
+    return s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double)) + s64_align((size_t)B * 3 * G * sizeof(unsigned)) +
+           s64_align((size_t)B * G * M * sizeof(double)) + s64_align((size_t)B * G * M * sizeof(int));
+}
+
+bool sinkhorn_f64_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= S64_ROWS * S64_GMAX; }
+
+int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
+                        float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, size_t workspace_bytes, unsigned* error_word,
+                        hipStream_t s) {
+    if (B <= 0) return MDGAT_OK;
+    if (!sinkhorn_f64_supported(N, M)) { mdgat_set_error("fp64 Sinkhorn: %d x %d keypoints > %d supported", N, M, 64 * S64_NC - 1); return MDGAT_ERR_UNSUPPORTED; }
+    if (!workspace || workspace_bytes < sinkhorn_f64_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+        mdgat_set_error("fp64 Sinkhorn: workspace too small or not 256-byte aligned");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    const int G = (N + S64_ROWS - 1) / S64_ROWS;
+    char* w = static_cast<char*>(workspace);
+    Sk64Args a{};
+    a.scores = scores; a.alpha = alpha; a.B = B; a.N = N; a.M = M; a.iters = iters; a.G = G; a.inner = inner;
+    a.Z64 = Z64; a.Z32 = Z32; a.rbest_idx = rbest_idx; a.rbest_val = rbest_val;
+    a.slots = reinterpret_cast<double*>(w); w += s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double));
+    a.flags = reinterpret_cast<unsigned*>(w); w += s64_align((size_t)B * 3 * G * sizeof(unsigned));
+    double* sval = reinterpret_cast<double*>(w); w += s64_align((size_t)B * G * M * sizeof(double));
+    int* sidx = reinterpret_cast<int*>(w);
+    a.cslab_idx = cbest_idx ? sidx : nullptr; a.cslab_val = cbest_idx ? sval : nullptr;
+    a.error_word = error_word;
+    if (int rc = mdgat_check_hip(hipMemsetAsync(a.flags, 0, (size_t)B * 3 * G * sizeof(unsigned), s), "memset(fp64 Sinkhorn flags)")) return rc;
+    const int groups = (B + 7) / 8;
+    hipLaunchKernelGGL(sinkhorn_f64_kernel, dim3(groups * 8 * G), dim3(S64_THREADS), 0, s, a);
+    if (int rc = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 launch")) return rc;
+    if (cbest_idx) {
+        const size_t total = (size_t)B * M;
+        hipLaunchKernelGGL(sinkhorn_f64_merge_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, sidx, sval, B, G, M,
+                           cbest_idx, cbest_val);
+        if (int rc = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 merge launch")) return rc;
+    }
+    return MDGAT_OK;
+}
+
+// ---- per-op entry points (include/mdgat_hip.h) ----
+static size_t s64_bests_bytes(int B, int N, int M) { return s64_align((size_t)B * N * 4) * 2 + s64_align((size_t)B * M * 4) * 2; }
+
+extern "C" size_t mdgat_sinkhorn_f64_workspace_bytes(int B, int N, int M) {
+    if (B <= 0 || N <= 0 || M <= 0) return 0;
+    return sinkhorn_f64_workspace_bytes(B, N, M) + s64_bests_bytes(B, N, M);
+}
+
+extern "C" int mdgat_sinkhorn_f64(int B, int N, int M, const double* scores, double bin_score, int iters, double* Z, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+    if (!scores || !Z) { mdgat_set_error("mdgat_sinkhorn_f64: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("mdgat_sinkhorn_f64: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
+    return launch_sinkhorn_f64(B, N, M, scores, bin_score, iters, Z, nullptr, 0, nullptr, nullptr, nullptr, nullptr, workspace, workspace_bytes, nullptr,
+                               static_cast<hipStream_t>(stream));
+}
+
+extern "C" int mdgat_sinkhorn_f64_extract(int B, int N, int M, const double* scores, double bin_score, int iters, int mode, float match_threshold,
+                                          int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* Z_or_null, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+    if (!scores || !matches0 || !matches1 || !mscores0 || !mscores1) { mdgat_set_error("mdgat_sinkhorn_f64_extract: null pointer"); return MDGAT_ERR_BAD_ARG; }
+    if (N <= 0 || M <= 0 || iters < 0) { mdgat_set_error("mdgat_sinkhorn_f64_extract: bad shape N=%d M=%d iters=%d", N, M, iters); return MDGAT_ERR_BAD_ARG; }
+    if (!workspace || workspace_bytes < mdgat_sinkhorn_f64_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
+        mdgat_set_error("mdgat_sinkhorn_f64_extract: workspace too small or not 256-byte aligned");
+        return MDGAT_ERR_BAD_ARG;
+    }
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    char* w = static_cast<char*>(workspace) + sinkhorn_f64_workspace_bytes(B, N, M);
+    int* ri = reinterpret_cast<int*>(w); w += s64_align((size_t)B * N * 4);
+    float* rv = reinterpret_cast<float*>(w); w += s64_align((size_t)B * N * 4);
+    int* ci = reinterpret_cast<int*>(w); w += s64_align((size_t)B * M * 4);
+    float* cv = reinterpret_cast<float*>(w);
+    const int inner = mode >= MDGAT_EXTRACT_THRESHOLD;
+    if (int rc = launch_sinkhorn_f64(B, N, M, scores, bin_score, iters, nullptr, Z_or_null, inner, ri, rv, ci, cv, workspace, sinkhorn_f64_workspace_bytes(B, N, M),
+                                     nullptr, s))
+        return rc;
+    const SkExtract ex{mode, match_threshold, matches0, matches1, mscores0, mscores1, 0, nullptr, 0u};
+    return launch_extract_from_bests(B, N, M, &ex, ri, rv, ci, cv, s);
+}

@@ -39,6 +39,44 @@ def sinkhorn(scores: torch.Tensor, bin_score: float, iters: int, streaming: bool
     return Z
 
 
+def sinkhorn_f64(scores: torch.Tensor, bin_score: float, iters: int) -> torch.Tensor:
+    """log_optimal_transport (mdgat.py:288-308) in fp64 (csrc/sinkhorn_f64.hip): scores [B, N, M] float64 -> Z [B, N+1, M+1] float64."""
+    _need_cuda(scores)
+    s = scores.to(torch.float64).contiguous()
+    B, N, M = s.shape
+    Z = torch.empty((B, N + 1, M + 1), dtype=torch.float64, device=s.device)
+    lib = _lib.load()
+    with torch.cuda.device(s.device):
+        need = lib.mdgat_sinkhorn_f64_workspace_bytes(B, N, M)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=s.device)
+        off = (-ws.data_ptr()) % 256
+        _lib.check(lib.mdgat_sinkhorn_f64(B, N, M, s.data_ptr(), float(bin_score), int(iters), Z.data_ptr(), ws.data_ptr() + off, need, _stream(s)),
+                   'mdgat_sinkhorn_f64')
+    return Z
+
+
+def sinkhorn_f64_extract(scores: torch.Tensor, bin_score: float, iters: int, mode: int = _lib.EXTRACT_DUSTBIN, match_threshold: float = 0.2,
+                         want_Z: bool = False):
+    """fp64 Sinkhorn + match extraction with every arg-max decided on the fp64 Z: (matches0, matches1, mscores0, mscores1[, Z fp32])."""
+    _need_cuda(scores)
+    s = scores.to(torch.float64).contiguous()
+    B, N, M = s.shape
+    m0 = torch.empty((B, N), dtype=torch.int64, device=s.device)
+    m1 = torch.empty((B, M), dtype=torch.int64, device=s.device)
+    s0 = torch.empty((B, N), dtype=torch.float32, device=s.device)
+    s1 = torch.empty((B, M), dtype=torch.float32, device=s.device)
+    Z = torch.empty((B, N + 1, M + 1), dtype=torch.float32, device=s.device) if want_Z else None
+    lib = _lib.load()
+    with torch.cuda.device(s.device):
+        need = lib.mdgat_sinkhorn_f64_workspace_bytes(B, N, M)
+        ws = torch.empty(need + 256, dtype=torch.uint8, device=s.device)
+        off = (-ws.data_ptr()) % 256
+        _lib.check(lib.mdgat_sinkhorn_f64_extract(B, N, M, s.data_ptr(), float(bin_score), int(iters), int(mode), float(match_threshold), m0.data_ptr(),
+                                                  m1.data_ptr(), s0.data_ptr(), s1.data_ptr(), Z.data_ptr() if Z is not None else None,
+                                                  ws.data_ptr() + off, need, _stream(s)), 'mdgat_sinkhorn_f64_extract')
+    return (m0, m1, s0, s1, Z) if want_Z else (m0, m1, s0, s1)
+
+
 def extract(Z: torch.Tensor, mode: int = _lib.EXTRACT_DUSTBIN, match_threshold: float = 0.2):
     """Match extraction (mdgat.py:441-483) from Z [B, N+1, M+1]."""
     _need_cuda(Z)

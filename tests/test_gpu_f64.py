@@ -167,6 +167,49 @@ def _build(g, **cfg_over):
     return net, cfg, sd, data, (B, n, m, L)
 
 
+@pytest.mark.parametrize('B,N,M,iters,alpha,scale', [(1, 7, 5, 20, 1.0, 3.0), (2, 64, 64, 100, 0.37, 3.0), (2, 48, 64, 50, 1.0, 3.0), (3, 512, 512, 100, 1.0, 3.0),
+                                                     (2, 400, 512, 100, 1.0, 6.0), (1, 100, 31, 10, 2.0, 1.0), (9, 256, 256, 20, 1.0, 3.0), (1, 1, 1, 5, 1.0, 1.0),
+                                                     (2, 575, 33, 30, 1.0, 2.0), (1, 33, 575, 30, 0.5, 10.0)])
+def test_sinkhorn_f64(B, N, M, iters, alpha, scale):
+    """csrc/sinkhorn_f64.hip (log_optimal_transport in the reference's own arithmetic, mdgat.py:279-308 run in float64) against the
+    oracle: Z to 1e-12, and the match extraction of all four branches - every arg-max decided on the fp64 Z inside the kernel - equal to
+    the extraction of the oracle's Z."""
+    rs = np.random.RandomState(N + 3 * M + iters)
+    s = torch.from_numpy(rs.standard_normal((B, N, M)) * scale)
+    Zr = O.log_optimal_transport(s, torch.tensor(alpha, dtype=torch.float64), iters)
+    Z = ops.sinkhorn_f64(s.to(DEV), alpha, iters).cpu()
+    assert (Z - Zr).abs().max().item() < 1e-12
+    for mode in range(4):
+        m0, m1, s0, s1, Z32 = ops.sinkhorn_f64_extract(s.to(DEV), alpha, iters, mode=mode, match_threshold=0.01, want_Z=True)
+        r0, r1, rs0, rs1 = ops.extract(Zr.float().to(DEV), mode=mode, match_threshold=0.01)
+        assert torch.equal(m0, r0) and torch.equal(m1, r1), mode
+        assert (s0 - rs0).abs().max().item() < 1e-6 and (s1 - rs1).abs().max().item() < 1e-6
+        assert (Z32.cpu().double() - Zr).abs().max().item() < 4e-6 * max(1.0, Zr.abs().max().item() / 32)      # the fp32 rounding of the fp64 Z
+
+
+def test_sinkhorn_f64_decides_near_ties_like_fp64():
+    """Two rows that are the same but for 1e-9 in one column: their potentials agree, so the two candidates of that column are 8e-10
+    apart in the fp64 Z - equal as fp32 numbers.  The kernel's arg-max (superglue branch: over the inner block, mdgat.py:444) follows
+    the larger one, whichever row holds it; an exact tie goes to the first index, as torch.max."""
+    rs = np.random.RandomState(5)
+    N = M = 96
+    s = torch.from_numpy(rs.standard_normal((2, N, M)) * 2.0)
+    s[:, 20, 7] = 6.0
+    s[:, 60, :] = s[:, 20, :]
+    s[0, 60, 7] += 1e-9                                     # pair 0: row 60 wins column 7
+    s[1, 20, 7] += 1e-9                                     # pair 1: row 20
+    Zr = O.log_optimal_transport(s, torch.tensor(1.0, dtype=torch.float64), 50)
+    ref1 = Zr[:, :-1, :-1].max(1).indices
+    assert int(ref1[0, 7]) == 60 and int(ref1[1, 7]) == 20 and 0 < float(Zr[0, 60, 7] - Zr[0, 20, 7]) < 2e-9
+    assert float(Zr.float()[0, 60, 7]) == float(Zr.float()[0, 20, 7])             # (what an fp32 Z can see)
+    m0, m1, s0, s1 = ops.sinkhorn_f64_extract(s.to(DEV), 1.0, 50, mode=2, match_threshold=0.01)
+    assert int(m1[0, 7]) == 60 and int(m1[1, 7]) == 20
+    assert torch.equal(m1.cpu(), ref1)                       # (every column clears the threshold here)
+    s[1, 20, 7] = s[1, 60, 7]                               # an exact tie: the lower row
+    m0, m1, s0, s1 = ops.sinkhorn_f64_extract(s.to(DEV), 1.0, 50, mode=2, match_threshold=0.01)
+    assert int(m1[1, 7]) == 20
+
+
 @pytest.mark.parametrize('name', ['fwd_n64_L1_S1', 'fwd_n64_L4_S20', 'fwd_n64_L5_S20', 'fwd_n48m64_L4_S20'])
 def test_f64_stages_vs_reference(golden_dir, name):
     """Every stage tensor of the fp64 layers against the reference's (forward hooks, tools/make_goldens.py): fp32 taps of fp64
