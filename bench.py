@@ -173,32 +173,49 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
     data = synth.make_batch(B, n, n, first_pair=0, dtype=torch.float64, device=dev)
     inputs = (data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'], data['descriptors1'])
     sched = net._topk_schedule()
-    n64 = max([i + 1 for i, k in enumerate(sched) if k > 0], default=0)
-    with torch.no_grad():
+    # the tail (every layer, final_proj, scores, Sinkhorn, the extraction's arg-maxes) is fp64 as well for frames of at most 575 keypoints
+    # (config['sinkhorn_arithmetic'] = 'auto'); beyond that fp64 runs through the last dynamic layer
+    tail64 = n <= 575 and getattr(net, 'sinkhorn_arithmetic', 'fp32') != 'fp32'
+    n64 = 2 * L if tail64 else max([i + 1 for i, k in enumerate(sched) if k > 0], default=0)
+    one = tuple(t[:1].contiguous() for t in inputs)
+
+    def timed(m):
         for _ in range(3):
-            net._run(*inputs)
+            m._run(*inputs)
         torch.cuda.synchronize()
         ws = []
         for _ in range(windows):
             t0 = time.perf_counter()
             for _ in range(steps):
-                net._run(*inputs)
+                m._run(*inputs)
             torch.cuda.synchronize()
             ws.append((time.perf_counter() - t0) / steps)
-        dt = sorted(ws)[len(ws) // 2]
         # one pair per call, as test.py:132 runs the matcher (batch_size = 1)
-        one = tuple(t[:1].contiguous() for t in inputs)
         for _ in range(3):
-            net._run(*one)
+            m._run(*one)
         torch.cuda.synchronize()
         reps = []
         for _ in range(5):     # (median of five loops: a collection of an earlier module - its handle's hipFree - may land in one)
             t0 = time.perf_counter()
             for _ in range(20):
-                net._run(*one)
+                m._run(*one)
             torch.cuda.synchronize()
             reps.append((time.perf_counter() - t0) / 20 * 1e3)
-        one_ms = sorted(reps)[len(reps) // 2]
+        return sorted(ws)[len(ws) // 2], sorted(reps)[len(reps) // 2]
+
+    with torch.no_grad():
+        dt, one_ms = timed(net)
+        fp32_tail = None
+        if tail64:       # the same with the fp32-class tail behind the last dynamic layer (rounds 5 / 6; sinkhorn_arithmetic = 'fp32')
+            net32 = MDGAT({**cfg, 'sinkhorn_arithmetic': 'fp32'}).double()
+            net32.load_state_dict(synth.make_state_dict(L=L, seed=0))
+            net32 = net32.eval().to(dev)
+            dt32, one32 = timed(net32)
+            net32.check(dev)
+            net32._invalidate()
+            fp32_tail = {'pairs_per_s': B / dt32, 'ms_per_step': 1e3 * dt32, 'one_pair_per_call_ms': one32,
+                         'note': "config['sinkhorn_arithmetic'] = 'fp32': fp64 through the last dynamic layer only, the fp32-class kernels behind it - Z "
+                                 'good to 7e-6 (inside the bar), an arg-max whose two candidates lie closer than that may fall the other way'}
         # the kernel classes with the launches NOT overlapping (one lane), as `roofline` / `kernels` of the headline: under two lanes
         # an interval between events also holds the other lane's launches
         net.set_lanes(1)
@@ -212,7 +229,8 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
     att = B * 2 * 4 * (2 * 2.0 * n * n * 32)
     n_topk = sum(1 for k in sched[:n64] if k > 0)
     # algorithmic FLOPs of the fp64 classes per step
-    flops = {'f64_gemm': 2.0 * R * (4 * 32 + 32 * 64 + 64 * 128 + 33 * 64 + 64 * 128 + 256 * 128) + n64 * 2.0 * R * (128 * 384 + 256 * 256 + 256 * 128),
+    flops = {'f64_gemm': 2.0 * R * (4 * 32 + 32 * 64 + 64 * 128 + 33 * 64 + 64 * 128 + 256 * 128) + n64 * 2.0 * R * (128 * 384 + 256 * 256 + 256 * 128) +
+                         (2.0 * R * 128 * 128 + B * 2.0 * n * n * 128 - 2.0 * R * 128 * 384 if tail64 else 0.0),     # final_proj + scores instead of a next q|k|v
              'f64_attention_full': (n64 - n_topk) * att, 'f64_attention_topk': n_topk * att}
     ms, fl, _ = ops.mfma_f64_probe(dev, 3000)
     sustained = fl / ms / 1e9
@@ -230,10 +248,12 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
     traffic, traffic_source = pmc_traffic('1_f64' if (B, n, L, S) == (64, 512, 9, 100) else -1, dom)
     ach = flops[dom] / (prof[dom][0] / 3 * 1e-3) / 1e12
     total_f64 = sum(flops.values())
-    return {'arithmetic': "fp64 (v_mfma_f64_16x16x4_f64) for the encoders and layers 0.." + str(n64 - 1) + ' of ' + str(2 * L) +
-                          ' (through the last dynamic layer); split-f16 kernels behind it',
+    return {'arithmetic': ("fp64 (v_mfma_f64_16x16x4_f64) for the encoders, all " + str(2 * L) + ' layers, final_proj and the score matrix; fp64 Sinkhorn, the '
+                           "extraction's arg-maxes decided on the fp64 Z (csrc/sinkhorn_f64.hip)") if tail64 else
+                          ("fp64 (v_mfma_f64_16x16x4_f64) for the encoders and layers 0.." + str(n64 - 1) + ' of ' + str(2 * L) +
+                           ' (through the last dynamic layer); split-f16 kernels behind it'),
             'pairs_per_s': B / dt, 'ms_per_pair': 1e3 * dt / B, 'ms_per_step': 1e3 * dt, 'batch': B, 'steps': steps, 'windows': windows,
-            'one_pair_per_call_ms': one_ms,
+            'one_pair_per_call_ms': one_ms, 'fp32_tail': fp32_tail,
             'roofline': {'kernel': dom, 'bound': 'mfma', 'achieved': ach, 'peak': PEAK_F64_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': ach / PEAK_F64_MFMA_TFLOPS, 'sustained_peak': sustained, 'frac_of_sustained': ach / sustained, 'traffic': traffic, 'traffic_source': traffic_source,
                          'all_f64_classes': {'achieved': total_f64 / (f64_ms * 1e-3) / 1e12, 'frac': total_f64 / (f64_ms * 1e-3) / 1e12 / PEAK_F64_MFMA_TFLOPS,
@@ -247,7 +267,7 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
             'kernels': kernels}
 
 
-PARITY_FIXTURES = {(256, 4, 20): 'cfg_n256_L4_S20', (512, 9, 100): 'cfg_n512_L9_S100', (2048, 9, 200): 'cfg_n2048_L9_S200_b'}
+PARITY_FIXTURES = {(256, 4, 20): 'cfg_n256_L4_S20', (512, 9, 100): 'cfg_n512_L9_S100_b40', (2048, 9, 200): 'cfg_n2048_L9_S200_b'}
 
 
 def parity_block(dev, n, L, S, stub=False):
@@ -285,9 +305,9 @@ def parity_block(dev, n, L, S, stub=False):
         mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
         err = np.abs(mine - ref_Z).max(1)
         es = max(np.abs(s0.cpu().double().numpy() - g['default_mscores0']).max(), np.abs(s1.cpu().double().numpy() - g['default_mscores1']).max())
+        mm = int((m0.cpu().numpy() != g['default_matches0']).sum() + (m1.cpu().numpy() != g['default_matches1']).sum())
         modes[mode] = {'pairs': B, 'pairs_within_1e-4': int((err < 1e-4).sum()), 'max_abs_dZ': float(err.max()),
-                       'matches_identical': bool(np.array_equal(m0.cpu().numpy(), g['default_matches0']) and
-                                                 np.array_equal(m1.cpu().numpy(), g['default_matches1'])),
+                       'matches_identical': mm == 0, 'matches_differing': mm, 'arg_maxes': int(m0.numel() + m1.numel()),
                        'max_abs_d_mscores': float(es)}
         net._invalidate()
     return {'fixture': f'tests/golden/{name}.npz: {B} pairs, N={gn} M={gm} L={gL} S={gS}, weights seed {seed} - outputs of the imported '

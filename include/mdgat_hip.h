@@ -91,8 +91,15 @@ typedef struct {
                                           zero-initialised config holds): automatic - up to and including the last layer with
                                           topk > 0 (the encoders only when no layer has one); n > 0: exactly n (2L: all of them);
                                           MDGAT_F64_ENCODERS_ONLY (-1): none, the encoders only */
+    int32_t f64_sinkhorn;              /* MDGAT_ARITH_FP64: the tail as well - EVERY layer, final_proj, the score matrix and the optimal
+                                          transport in fp64, the extraction's arg-maxes decided on the fp64 Z (csrc/sinkhorn_f64.hip).
+                                          0 (a zero-initialised config): automatic - on for frames of at most 575 keypoints (and
+                                          f64_layers == 0), else the fp32-class tail; 1: required (larger frames are refused);
+                                          MDGAT_F64_SINKHORN_OFF (-1): the fp32-class tail behind the last dynamic layer (rounds 5 / 6:
+                                          Z good to 7e-6, an arg-max whose candidates lie closer than that may fall the other way) */
 } mdgat_config;
 #define MDGAT_F64_ENCODERS_ONLY (-1)
+#define MDGAT_F64_SINKHORN_OFF (-1)
 
 typedef struct mdgat_handle mdgat_handle;
 

@@ -41,6 +41,7 @@ class MdgatConfig(C.Structure):
         ('attention_mode', C.c_int32),
         ('arithmetic', C.c_int32),
         ('f64_layers', C.c_int32),
+        ('f64_sinkhorn', C.c_int32),
     ]
 
 

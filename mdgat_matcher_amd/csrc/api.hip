@@ -8,6 +8,7 @@
 
 #include "common.hpp"
 #include "f64.hpp"
+#include "sinkhorn_f64.hpp"
 
 // ---------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -301,6 +302,7 @@ namespace {
 struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
     double *x64, *qkv64, *hid64, *msg64;   // MDGAT_ARITH_FP64 only: the residual stream, q|k|v, hidden layer and message of the fp64 layers
+    float* sk64; size_t sk64_bytes;        // ... and the workspace of the fp64 Sinkhorn + its arg-max arrays (0: the shape is beyond that kernel)
     _Float16* qkv16;
     size_t sk_bytes;
     size_t total;   // floats
@@ -324,6 +326,8 @@ Workspace carve(float* base, int B, int N, int M, bool f64) {
         w.qkv64 = reinterpret_cast<double*>(take(R * 384 * 2));     // qkv64 and hid64 are contiguous: the encoder stages live there
         w.hid64 = reinterpret_cast<double*>(take(R * 256 * 2));
         w.msg64 = reinterpret_cast<double*>(take(R * 128 * 2));
+        w.sk64_bytes = sinkhorn_f64_supported(N, M) ? sinkhorn_f64_workspace_bytes(B, N, M) + sinkhorn_f64_bests_bytes(B, N, M) : 0;
+        w.sk64 = take((w.sk64_bytes + 3) / 4);
     }
     w.total = o;
     return w;
@@ -442,6 +446,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
     if ((N & 31) || (M & 31))   // the attention kernel reads V^T in whole 32-key blocks: pad columns must be zero
         if ((rc = mdgat_check_hip(hipMemsetAsync(q16.vt16, 0, (size_t)B * 256 * q16.PP * sizeof(_Float16), s), "memset(V^T pads)"))) return rc;
     int first = 0;              // the first propagation layer the fp32-class kernels run
+    bool tail64 = false;        // MDGAT_ARITH_FP64: final_proj, scores, Sinkhorn and the extraction's arg-maxes in fp64 too
     if (!f64) {
         // ---- encoders (mdgat.py:392-393), one fused launch ----
         EncoderLaunch e{};
@@ -477,6 +482,16 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         if (rc) return rc;
         mark(MDGAT_PROF_F64_OTHER);
         first = f64_layer_count(h->cfg);
+        // The TAIL in fp64 as well (mdgat_config.f64_sinkhorn; round 6): every layer, final_proj, the score matrix and the optimal
+        // transport in the reference's own arithmetic, every arg-max of the extraction decided on the fp64 Z (sinkhorn_f64.hip).  With
+        // the fp32-class tail Z is good to 7e-6 - inside the bar of 1e-4, but among 40 960 arg-maxes of a reference-held batch one had
+        // its two candidates 1.3e-6 apart and fell the other way (profiles/NOTES_r6.md section 11).
+        if (h->cfg.f64_sinkhorn > 0 && !ws.sk64_bytes) {
+            mdgat_set_error("mdgat_forward_f64: f64_sinkhorn = 1 and %d x %d keypoints are beyond the fp64 Sinkhorn kernel (575)", N, M);
+            return MDGAT_ERR_UNSUPPORTED;
+        }
+        tail64 = h->cfg.f64_sinkhorn >= 0 && ws.sk64_bytes != 0 && h->cfg.f64_layers == 0;
+        if (tail64) first = L2;
         // The tail of a layer - mlp.0 + ReLU, mlp.3 + residual (mdgat.py:246-248, 274) - and the NEXT layer's q | k | v projection
         // (227-232) run as one launch (layer_f64.hip), the hidden activation never leaving the chip, and so do the two encoders with
         // layer 0's projection; the last fp64 launch also writes the fp32 rounding of x, the hand-over.  mdgat_set_f64_layer_fusion(0)
@@ -536,6 +551,35 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
             mark(MDGAT_PROF_F64_GEMM);
             if (taps && taps->x_layers)
                 if ((rc = launch_f64_to_f32(ws.x64, taps->x_layers + (size_t)i * Rz * 128, Rz * 128, nullptr, s))) return rc;
+        }
+        if (tail64) {
+            // final_proj (mdgat.py:397), the score matrix (430-431), the optimal transport (434-436) and the extraction (441-483)
+            double* mdesc64 = ws.msg64;          // (the message and q | k | v of the last layer are dead)
+            double* scores64 = ws.qkv64;         // [B][N][M]: N M <= 384 (N + M) for every shape the kernel takes
+            if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, bl.final_w, bl.final_b, 0, nullptr, mdesc64, 128, 128, 128))) return rc;
+            if (taps && taps->mdesc)
+                if ((rc = launch_f64_to_f32(mdesc64, taps->mdesc, Rz * 128, nullptr, s))) return rc;
+            GemmF64Args sg{mdesc64, 128, 128, nullptr, 0, mdesc64 + (size_t)N * 128, 128, nullptr, nullptr, 0, scores64, M, N, M, 128, 0, status_dev + MDGAT_STATUS_RANGE};
+            sg.scale = 0.08838834764831845;      // 1 / sqrt(128)
+            sg.batch = B; sg.sA = sg.sW = (long long)(N + M) * 128; sg.sC = (long long)N * M;
+            if ((rc = launch_gemm_f64(sg, s))) return rc;
+            mark(MDGAT_PROF_F64_GEMM);
+            if (taps && taps->scores)
+                if ((rc = launch_f64_to_f32(scores64, taps->scores, (size_t)B * N * M, nullptr, s))) return rc;
+            const size_t kb = sinkhorn_f64_workspace_bytes(B, N, M);
+            char* bw = reinterpret_cast<char*>(ws.sk64) + kb;
+            auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+            int* ri = reinterpret_cast<int*>(bw); bw += al((size_t)B * N * 4);
+            float* rv = reinterpret_cast<float*>(bw); bw += al((size_t)B * N * 4);
+            int* ci = reinterpret_cast<int*>(bw); bw += al((size_t)B * M * 4);
+            float* cv = reinterpret_cast<float*>(bw);
+            const SkExtract ex64{h->cfg.extract_mode, h->cfg.match_threshold, matches0, matches1, mscores0, mscores1, defer_alldust,
+                                 status_dev + MDGAT_STATUS_MATCHED + (h->match_token % MDGAT_MATCH_SLOTS), h->match_token};
+            if ((rc = launch_sinkhorn_f64(B, N, M, scores64, 0.0, h->cfg.sinkhorn_iters, nullptr, Z, h->cfg.extract_mode >= MDGAT_EXTRACT_THRESHOLD, ri, rv, ci, cv,
+                                          ws.sk64, kb, status_dev + MDGAT_STATUS_RANGE, s, w64 + bl.bin_score))) return rc;
+            if ((rc = launch_extract_from_bests(B, N, M, &ex64, ri, rv, ci, cv, s))) return rc;
+            mark(MDGAT_PROF_SINKHORN);
+            return MDGAT_OK;
         }
         // hand-over: nothing behind the last dynamic layer is discontinuous
         if (!handed_over) {

@@ -60,6 +60,7 @@ constexpr int G_BM = 64, G_KC = 32;      // row pitch KC + 2 doubles (34: 68 dwo
 template <int WN, bool FAST, int KC = G_KC>      // 16-column blocks per wave: workgroup tile 64 x (32 WN)
 __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
     static_assert(KC == 32 || (KC == 64 && FAST), "chunk depth");
+    if (a.batch > 1) { a.A0 += (size_t)blockIdx.z * a.sA; a.W += (size_t)blockIdx.z * a.sW; a.C += (size_t)blockIdx.z * a.sC; }
     constexpr int BN = 32 * WN, G_LD = KC + 2, G_KC = KC, RSH = KC == 64 ? 5 : 4, RMASK = (1 << RSH) - 1;
     extern __shared__ __attribute__((aligned(16))) double gsm[];
     double* As = gsm;                       // [64][G_LD]
@@ -165,7 +166,7 @@ __global__ __launch_bounds__(256) void gemm_f64_kernel(GemmF64Args a) {
             for (int i = 0; i < 4; ++i) {
                 const int row = row0 + wm * 32 + mb * 16 + g + 4 * i;
                 if (row >= a.M) continue;
-                double v = acc[mb][nb][i] + bias;
+                double v = acc[mb][nb][i] * a.scale + bias;          // (scale = 1: the same bits as acc + bias, contracted or not)
                 bad |= f64_out_of_range(v);
                 if (a.relu) v = v > 0.0 ? v : 0.0;
                 if (a.R) { v += a.R[(size_t)row * a.ldr + n]; bad |= f64_out_of_range(v); }
@@ -866,7 +867,7 @@ int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     int wn = 2;
     if (a.N > 64) {
         const int cus = f64_cu_count();
-        const long tiles_m64 = (a.M + G_BM - 1) / G_BM;
+        const long tiles_m64 = (long)((a.M + G_BM - 1) / G_BM) * (a.batch > 1 ? a.batch : 1);
         const long tw = tiles_m64 * ((a.N + 127) / 128), tn = tiles_m64 * ((a.N + 63) / 64);
         const long rw = (tw + 3 * cus - 1) / (3 * cus), rn = (tn + 4 * cus - 1) / (4 * cus);
         wn = (tw <= 6L * cus && rn * 55 < rw * 100) ? 2 : 4;
@@ -875,14 +876,14 @@ int launch_gemm_f64(const GemmF64Args& a, hipStream_t s) {
     const int bn = 32 * wn;
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     const bool fast = a.M % G_BM == 0 && a.N % bn == 0 && a.K % G_KC == 0 && a.K0 % G_KC == 0 && a.lda0 % 2 == 0 && a.ldw % 2 == 0 && al16(a.A0) && al16(a.W) &&
-                      (a.K0 >= a.K || (a.lda1 % 2 == 0 && al16(a.A1)));
+                      (a.K0 >= a.K || (a.lda1 % 2 == 0 && al16(a.A1))) && (a.batch <= 1 || (a.sA % 2 == 0 && a.sW % 2 == 0));
     // (chunks of 64 for whole-tile launches of at most one 64 x 64 tile per CU: one or two pairs of 512 keypoints - 19.0 -> 17.8 us
     // at K = 256, the one-pair forward 1.54 -> 1.48 ms; from eight pairs on the shallower chunks' third resident workgroup wins)
     static const bool deep_off = [] { const char* e = getenv("MDGAT_F64_GEMM_DEEP"); return e && atoi(e) == 0; }();      // (measurements)
     const bool deep = !deep_off && fast && wn == 2 && a.K % 64 == 0 && (a.K0 >= a.K || a.K0 % 64 == 0) &&
-                      (long)((a.M + G_BM - 1) / G_BM) * ((a.N + 63) / 64) <= (long)f64_cu_count();
+                      (long)((a.M + G_BM - 1) / G_BM) * ((a.N + 63) / 64) * (a.batch > 1 ? a.batch : 1) <= (long)f64_cu_count();
     const size_t lds = (size_t)(G_BM + bn) * ((deep ? 64 : G_KC) + 2) * sizeof(double);
-    const dim3 grid((a.M + G_BM - 1) / G_BM, (a.N + bn - 1) / bn);
+    const dim3 grid((a.M + G_BM - 1) / G_BM, (a.N + bn - 1) / bn, a.batch > 1 ? a.batch : 1);
     auto go = [&](auto kern, std::atomic<unsigned long long>& done) -> int {
         if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(kern), lds, done, "gemm_f64 LDS")) return rc;
         hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);

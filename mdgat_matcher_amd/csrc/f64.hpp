@@ -17,6 +17,9 @@ struct GemmF64Args {
     int relu;
     unsigned* guard;                   // host-mapped status word (MDGAT_STATUS_RANGE) or nullptr: raised when an output is not finite or
                                        // beyond 2^500 in magnitude (f64_out_of_range in f64.hip)
+    double scale = 1.0;                // C = act(scale A W^T + bias) (+ R)   (the score matrix: 1 / sqrt(128), mdgat.py:431)
+    int batch = 1;                     // independent products; A0, W, C of product z at + z sA, + z sW, + z sC (no second source, bias, residual shared)
+    long long sA = 0, sW = 0, sC = 0;
 };
 int launch_gemm_f64(const GemmF64Args& a, hipStream_t s);
 

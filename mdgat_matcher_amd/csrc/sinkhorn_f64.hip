@@ -31,7 +31,8 @@ constexpr int S64_GMAX = 18;                                         // row slab
 
 struct Sk64Args {
     const double* scores;      // [B][N][M]
-    double alpha;
+    double alpha;              // the bin score (mdgat.py:359-360) ...
+    const double* alpha_dev;   // ... or where it lives on the device (the forward: the weight blob), if not null
     int B, N, M, iters, G, inner;
     double* Z64;               // optional [B][N + 1][M + 1]
     float* Z32;                // optional, the fp32 rounding of the same
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
     const double nm = (double)(N + M);
     const double norm = -log(nm);
     const bool last = g == G - 1;                        // the slab that also carries the dustbin row
-    auto z0 = [&](int i, int j) -> double { return j < M ? sc[(size_t)i * M + j] : a.alpha; };      // (real rows only)
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
+    auto z0 = [&](int i, int j) -> double { return j < M ? sc[(size_t)i * M + j] : alpha; };      // (real rows only)
 
     // K = exp(Z0 - row maximum): 4 x 9 doubles per lane.  The DUSTBIN ROW needs no storage: its couplings are the bin score in every
     // column (mdgat.py:296-298), so K = 1 throughout - its row sum is the sum of b, its share of every column sum is a_N itself.
@@ -191,6 +193,11 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
         for (int c = 0; c < S64_NC; ++c) b[c] = lane + 64 * c <= M ? bl[lane + 64 * c] : 0.0;
     }
     if (dead && tid == 0 && a.error_word) __hip_atomic_store(a.error_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (a.iters == 0) {         // u = v = 0 (mdgat.py:281): a = e^r in the shifted form, the dustbin row's e^alpha
+#pragma unroll
+        for (int i = 0; i < 4; ++i) av[i] = exp(r[i]);
+        aN = exp(alpha);
+    }
 
     // Z = Z0 - r + log a + log b - norm; arg-maxes decided on the fp64 values
     double lb[S64_NC];
@@ -291,7 +298,7 @@ bool sinkhorn_f64_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 
 
 int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
                         float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, size_t workspace_bytes, unsigned* error_word,
-                        hipStream_t s) {
+                        hipStream_t s, const double* alpha_dev) {
     if (B <= 0) return MDGAT_OK;
     if (!sinkhorn_f64_supported(N, M)) { mdgat_set_error("fp64 Sinkhorn: %d x %d keypoints > %d supported", N, M, 64 * S64_NC - 1); return MDGAT_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < sinkhorn_f64_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
@@ -301,7 +308,7 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     const int G = (N + S64_ROWS - 1) / S64_ROWS;
     char* w = static_cast<char*>(workspace);
     Sk64Args a{};
-    a.scores = scores; a.alpha = alpha; a.B = B; a.N = N; a.M = M; a.iters = iters; a.G = G; a.inner = inner;
+    a.scores = scores; a.alpha = alpha; a.alpha_dev = alpha_dev; a.B = B; a.N = N; a.M = M; a.iters = iters; a.G = G; a.inner = inner;
     a.Z64 = Z64; a.Z32 = Z32; a.rbest_idx = rbest_idx; a.rbest_val = rbest_val;
     a.slots = reinterpret_cast<double*>(w); w += s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double));
     a.flags = reinterpret_cast<unsigned*>(w); w += s64_align((size_t)B * 3 * G * sizeof(unsigned));
@@ -323,11 +330,11 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
 }
 
 // ---- per-op entry points (include/mdgat_hip.h) ----
-static size_t s64_bests_bytes(int B, int N, int M) { return s64_align((size_t)B * N * 4) * 2 + s64_align((size_t)B * M * 4) * 2; }
+size_t sinkhorn_f64_bests_bytes(int B, int N, int M) { return s64_align((size_t)B * N * 4) * 2 + s64_align((size_t)B * M * 4) * 2; }
 
 extern "C" size_t mdgat_sinkhorn_f64_workspace_bytes(int B, int N, int M) {
     if (B <= 0 || N <= 0 || M <= 0) return 0;
-    return sinkhorn_f64_workspace_bytes(B, N, M) + s64_bests_bytes(B, N, M);
+    return sinkhorn_f64_workspace_bytes(B, N, M) + sinkhorn_f64_bests_bytes(B, N, M);
 }
 
 extern "C" int mdgat_sinkhorn_f64(int B, int N, int M, const double* scores, double bin_score, int iters, double* Z, void* workspace,

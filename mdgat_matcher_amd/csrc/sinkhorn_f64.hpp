@@ -11,4 +11,5 @@ size_t sinkhorn_f64_workspace_bytes(int B, int N, int M);
 bool sinkhorn_f64_supported(int N, int M);
 int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
                         float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, size_t workspace_bytes, unsigned* error_word,
-                        hipStream_t s);
+                        hipStream_t s, const double* alpha_dev = nullptr);      // alpha_dev: the bin score on the device (replaces alpha)
+size_t sinkhorn_f64_bests_bytes(int B, int N, int M);      // room for rbest / cbest (idx + val each) behind the kernel's own workspace

@@ -171,6 +171,14 @@ class MDGAT(nn.Module):
             raise ValueError(f"arithmetic={self.arithmetic!r}: expected 'auto', 'fp32' or 'fp64'")
         f64_layers = self.config.get('f64_layers')
         self.f64_layers = None if f64_layers is None or int(f64_layers) < 0 else int(f64_layers)
+        # 'sinkhorn_arithmetic' (optional; MDGAT_SINKHORN_ARITHMETIC in the environment): the exact mode's TAIL - every layer, final_proj,
+        # the score matrix and the optimal transport in fp64, every arg-max of the extraction decided on the fp64 Z (csrc/sinkhorn_f64.hip).
+        #   'auto' (default): on for frames of at most 575 keypoints, else the fp32-class tail behind the last dynamic layer;
+        #   'fp64': required (larger frames are refused);  'fp32': the fp32-class tail (Z good to 7e-6: inside the bar of 1e-4, but an
+        #   arg-max whose two candidates lie closer than that may fall the other way - one in 40 960 on a reference-held batch).
+        self.sinkhorn_arithmetic = str(self.config.get('sinkhorn_arithmetic') or os.environ.get('MDGAT_SINKHORN_ARITHMETIC') or 'auto')
+        if self.sinkhorn_arithmetic not in ('auto', 'fp32', 'fp64'):
+            raise ValueError(f"sinkhorn_arithmetic={self.sinkhorn_arithmetic!r}: expected 'auto', 'fp32' or 'fp64'")
         if self.arithmetic == 'fp64' and self.attention_dtype != 'fp32':
             raise ValueError("arithmetic='fp64' and attention_dtype='f16' exclude each other")
         if self.descriptor != 'FPFH':
@@ -333,6 +341,7 @@ class MDGAT(nn.Module):
             cfg.arithmetic = _lib.ARITH_FP64 if f64 else _lib.ARITH_FP32
             fl = getattr(self, 'f64_layers', None)
             cfg.f64_layers = 0 if fl is None else (_lib.F64_ENCODERS_ONLY if fl == 0 else int(fl))     # (C ABI: 0 = automatic)
+            cfg.f64_sinkhorn = {'auto': 0, 'fp64': 1, 'fp32': -1}[getattr(self, 'sinkhorn_arithmetic', 'auto')]
             handle = C.c_void_p()
             _lib.check(lib.mdgat_create(C.byref(cfg), idx, C.byref(handle)), 'mdgat_create')
             st = _DeviceState(handle, idx, f64)

@@ -29,7 +29,7 @@ def test_blob_layout_matches_library():
     lib = _lib.load()
     for L in (0, 1, 4, 9, 32):
         assert lib.mdgat_blob_floats(L) == pack.blob_layout(L)['total']
-    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 5)     # L, iters, topk[64], extract_mode, threshold, attention_mode, arithmetic, f64_layers
+    assert C.sizeof(_lib.MdgatConfig) == 4 * (2 + 64 + 6)     # L, iters, topk[64], extract_mode, threshold, attention_mode, arithmetic, f64_layers, f64_sinkhorn
 
 
 def test_state_dict_names_match_reference_fixture():

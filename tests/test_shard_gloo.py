@@ -277,17 +277,18 @@ def test_bench_eight_ranks_gloo_stub(tmp_path):
     # the parity fields are COMPUTED in the run (here on the recorder's zeros: presence and shape, not values)
     pm = d['parity']['modes']
     assert set(pm) == {'fp32', 'fp64'} and 'cfg_n512_L9_S100' in d['parity']['fixture']
-    for mode in pm.values():
-        assert mode['pairs'] == 8 and 0 <= mode['pairs_within_1e-4'] <= 8 and isinstance(mode['matches_identical'], bool)
+    for mode in pm.values():       # (the 40-pair batch the reference ran as one: tests/golden/cfg_n512_L9_S100_b40.npz)
+        assert mode['pairs'] == 40 and 0 <= mode['pairs_within_1e-4'] <= 40 and isinstance(mode['matches_identical'], bool)
         assert isinstance(mode['max_abs_dZ'], float) and isinstance(mode['max_abs_d_mscores'], float)
-    assert d['status']['literal_1e-4_pairs'] == {m: f"{pm[m]['pairs_within_1e-4']}/8" for m in pm} and 'measured' in d['status']['parity_source']
+        assert mode['arg_maxes'] == 40 * 1024 and mode['matches_differing'] >= 0
+    assert d['status']['literal_1e-4_pairs'] == {m: f"{pm[m]['pairs_within_1e-4']}/40" for m in pm} and 'measured' in d['status']['parity_source']
     # every rank ran its own 512 pairs, and only those: 8 + warmup + windows x steps forwards of 512 x 512 x 512
     for r in range(8):
         calls = open(f'{log}.{r}').read().split('\n')[:-1]
         timed = calls[:8 + 1 + 2 * 3]
         assert timed and set(timed) == {'512 512 512'} and len(timed) == 8 + 1 + 2 * 3, (r, len(calls))
-        # behind them, on rank 0 only: the parity block's two forwards over the 8 reference-held pairs (one per arithmetic mode)
-        assert calls[len(timed):] == (['8 512 512'] * 2 if r == 0 else []), (r, calls[len(timed):])
+        # behind them, on rank 0 only: the parity block's two forwards over the 40 reference-held pairs (one per arithmetic mode)
+        assert calls[len(timed):] == (['40 512 512'] * 2 if r == 0 else []), (r, calls[len(timed):])
 
 
 def test_bench_plain_form_starts_its_own_ranks(tmp_path):
@@ -310,7 +311,7 @@ def test_bench_plain_form_starts_its_own_ranks(tmp_path):
     assert d['n_gpus'] == 8 and d['config']['rccl_world_size'] == 8 and d['config']['pairs_per_rank'] == [512] * 8
     assert 'starting 8 ranks' in p.stderr
     for r in range(8):
-        assert set(open(f'{log}.{r}').read().split()) == ({'512', '8'} if r == 0 else {'512'})     # ('8': rank 0's parity block)
+        assert set(open(f'{log}.{r}').read().split()) == ({'512', '40'} if r == 0 else {'512'})     # ('40': rank 0's parity block)
     # a launcher that started 2 ranks for a --gpus 4 request: every rank refuses, nothing is printed
     port = 29911 + (os.getpid() % 80)
     p = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2', '--master-addr', '127.0.0.1',

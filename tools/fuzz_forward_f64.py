@@ -58,8 +58,14 @@ def one_case(rs):
         O.mdgat_forward(sd, cfg, data, cap2, forced_topk=forced)                   # ... and with the library's selections fed back
         r['flip_rows'] = sum(x['rows'] for reps in cap2.get('topk_report', {}).values() for x in reps)
         r['bad_count'] = sum(x['bad_count'] for reps in cap2.get('topk_report', {}).values() for x in reps)
-        e0, e1, es0, es1 = O.extract_matches(Z.cpu().double(), loss_method, mutual, cfg['match_threshold'])
-        r['matches_vs_own_Z'] = bool(torch.equal(m0.cpu(), e0) and torch.equal(m1.cpu(), e1))
+        tail64 = f64_layers < 0 and max(N, M) <= 575           # every layer, the scores and the Sinkhorn in fp64 too (sinkhorn_f64.hip)
+        if tail64:
+            # the arg-maxes are decided on the fp64 Z, of which the returned Z is the fp32 rounding (two candidates 1e-9 apart are equal
+            # there): the matches must be the ORACLE's own, all of them
+            r['matches_vs_own_Z'] = bool(torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1']))
+        else:
+            e0, e1, es0, es1 = O.extract_matches(Z.cpu().double(), loss_method, mutual, cfg['match_threshold'])
+            r['matches_vs_own_Z'] = bool(torch.equal(m0.cpu(), e0) and torch.equal(m1.cpu(), e1))
         # matches against the oracle's: identical unless the oracle's Z holds a near-tie where they differ
         diff0 = (m0.cpu() != ref['matches0'])
         Zo = cap['Z']
