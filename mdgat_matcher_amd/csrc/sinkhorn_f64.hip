@@ -12,8 +12,9 @@
 // fp64 has the range for it: every K is in (e^-700, 1], the scaling factors stay within e^(+-|scores|).
 //
 // gfx950 mapping.  A pair's N x (M + 1) block of K stays in REGISTERS for all iterations, spread over G = ceil(N / 32) workgroups of
-// eight waves: workgroup g owns rows 32 g .. 32 g + 31, wave w of it four of them, lane l the columns l, l + 64, ... (nine per lane
-// at M = 512: 36 doubles); the dustbin ROW is all ones after its maximum is taken out and is carried as one scalar.  Row sums are in-lane dot products and one butterfly per row; column sums are in-lane over
+// eight waves (or ceil(N / 64) of sixteen): workgroup g owns rows 32 g .. 32 g + 31, wave w of it four of them, lane l the columns
+// l, l + 64, ... (nine per lane at M = 512: 36 doubles); the dustbin ROW is all ones after its maximum is taken out and is carried as
+// one scalar.  Row sums are in-lane dot products and one butterfly per row; column sums are in-lane over
 // the wave's four rows, merged over the eight waves through LDS and over the G workgroups through memory: every workgroup publishes
 // its M + 1 partials (write-through stores, acknowledged before the workgroup's flag goes out), waits for its partners' flags and adds
 // the G partials of a column in slab order - the same bits in every workgroup.  Two slot sets alternate by iteration parity (a workgroup can only be two
@@ -25,9 +26,9 @@
 
 namespace {
 
-constexpr int S64_THREADS = 512, S64_ROWS = 32, S64_NC = 9;          // nine columns per lane: M + 1 <= 576
+constexpr int S64_NC = 9;                                            // nine columns per lane: M + 1 <= 576
 constexpr int S64_SLOT = 576;                                        // doubles per published vector (>= M + 1, 64-aligned)
-constexpr int S64_GMAX = 18;                                         // row slabs of a pair at most: N + 1 <= 576
+constexpr int S64_GMAX = 18;                                         // row slabs of a pair at most (eight-wave workgroups): N <= 576
 
 struct Sk64Args {
     const double* scores;      // [B][N][M]
@@ -44,14 +45,37 @@ struct Sk64Args {
     unsigned* error_word;      // bit 0: a workgroup gave up waiting for a partner
 };
 
+// sum over the 64 lanes, the same bits in every lane: four rotations inside the DPP rows (no LDS crossbar), then the two steps across
+// rows (ds_bpermute).  (Six ds_bpermute steps of two 32-bit halves each: a dependent chain of 12 crossbar round trips per sum, five
+// sums per iteration.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_d(double v) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xf, 0xf, false);
+    const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(u >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
 __device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_mov_d<0x128>(v);      // row_ror:8
+    v += dpp_mov_d<0x124>(v);      // row_ror:4
+    v += dpp_mov_d<0x122>(v);      // row_ror:2
+    v += dpp_mov_d<0x121>(v);      // row_ror:1   (every lane of a row holds the row's sum)
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) {
+    for (int m = 16; m < 64; m <<= 1) {
         const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
         const unsigned lo = (unsigned)__shfl_xor((int)(unsigned)u, m, 64), hi = (unsigned)__shfl_xor((int)(unsigned)(u >> 32), m, 64);
         v += __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
     }
     return v;
+}
+// 1 / p for the scaling factors (p a positive sum, far from the ends of the exponent range): the hardware's estimate and two Newton
+// steps - 2^-53 relative, not correctly rounded, the same bits wherever it is evaluated.  The IEEE division is ~35 instructions, and an
+// iteration holds six of them per lane: nearly half of its vector instructions.
+__device__ __forceinline__ double recip_f64(double p) {
+    double r = __builtin_amdgcn_rcp(p);
+    r = __builtin_fma(__builtin_fma(-p, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-p, r, 1.0), r, r);
+    return r;
 }
 __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
@@ -59,10 +83,20 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-__global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a) {
-    __shared__ double colbuf[8][S64_SLOT];      // column partials of the eight waves; in the epilogue the values of the column arg-max
-    __shared__ double bl[S64_SLOT];             // the new b, for every lane to pick its columns from; in the epilogue the dustbin row of Z
-    __shared__ int cidx[8][S64_SLOT];           // row indices of the column arg-max (epilogue)
+// S64_WAVES waves of four rows each per workgroup: 8 (32 rows; two workgroups per CU) for small launches - a pair is 16 workgroups on 16 CUs -
+// or 16 (64 rows, one workgroup per CU: half the partners, half the flags) when the launch fills the chip: 32 pairs 894 -> 810 us per
+// 100 iterations, but one pair 442 -> 617.
+template <int S64_WAVES>
+__global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_kernel(Sk64Args a) {
+    // (one workgroup per CU either way: eight waves at 168 registers, sixteen at 128.  Two eight-wave workgroups per CU - 128 registers,
+    // 152 bytes of scratch - are no faster: 32 pairs 917 against 878 us, one pair 502 against 432: a CU's iteration time is its
+    // instruction count - ~450 per wave, of which the 72 products are a sixth; the rest is the five wave reductions, the exchange and
+    // the reciprocals)
+    constexpr int S64_THREADS = 64 * S64_WAVES, S64_ROWS = 4 * S64_WAVES;
+    extern __shared__ __attribute__((aligned(16))) double s64_lds[];
+    double (*colbuf)[S64_SLOT] = reinterpret_cast<double (*)[S64_SLOT]>(s64_lds);       // [waves]: column partials; in the epilogue the values of the column arg-max
+    double* bl = s64_lds + (size_t)S64_WAVES * S64_SLOT;                                // the new b, for every lane to pick its columns from; in the epilogue the dustbin row of Z
+    int (*cidx)[S64_SLOT] = reinterpret_cast<int (*)[S64_SLOT]>(bl + S64_SLOT);         // [waves]: row indices of the column arg-max (epilogue)
     __shared__ int dead, same_xcd_s;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -99,7 +133,7 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
 #pragma unroll
         for (int c = 0; c < S64_NC; ++c) K[i][c] = (row < N && lane + 64 * c <= M) ? exp(K[i][c] - m) : 0.0;
     }
-    const double mu = 1.0 / nm, muN = (double)M / nm;
+    const double mu = 1.0 / nm, muN = (double)M / nm, nuM = (double)N / nm;      // (mu, nu of mdgat.py:300-303; real columns: nu = mu)
     double b[S64_NC], av[4], aN = 0.0;
 #pragma unroll
     for (int c = 0; c < S64_NC; ++c) b[c] = lane + 64 * c <= M ? 1.0 : 0.0;
@@ -133,7 +167,7 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
             double sb = 0.0;
 #pragma unroll
             for (int c = 0; c < S64_NC; ++c) sb += b[c];
-            aN = muN / wave_sum_f64(sb);
+            aN = muN * recip_f64(wave_sum_f64(sb));
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -141,7 +175,7 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
 #pragma unroll
             for (int c = 0; c < S64_NC; ++c) p = __builtin_fma(K[i][c], b[c], p);
             p = wave_sum_f64(p);
-            av[i] = row0 + i < N ? mu / p : 0.0;
+            av[i] = row0 + i < N ? mu * recip_f64(p) : 0.0;
         }
         // column partials of this wave's rows -> LDS
 #pragma unroll
@@ -162,7 +196,7 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
         for (int j = tid; j <= M; j += S64_THREADS) {
             double p = colbuf[0][j];
 #pragma unroll
-            for (int w = 1; w < 8; ++w) p += colbuf[w][j];
+            for (int w = 1; w < S64_WAVES; ++w) p += colbuf[w][j];
             if (last) p += aN;                              // the dustbin row's share of the column (K = 1), by one slab
             if (same_xcd) mine[j] = p;
             else __hip_atomic_store(mine + j, p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -180,13 +214,14 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
         __syncthreads();
         const double* all = slots + (size_t)(it & 1) * G * S64_SLOT;
         for (int j = tid; j <= M; j += S64_THREADS) {
-            double v[S64_GMAX];
+            constexpr int GM = S64_GMAX * 8 / S64_WAVES;     // (64-row slabs: at most nine)
+            double v[GM];
 #pragma unroll
-            for (int q = 0; q < S64_GMAX; ++q) v[q] = q < G ? __hip_atomic_load(all + (size_t)q * S64_SLOT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+            for (int q = 0; q < GM; ++q) v[q] = q < G ? __hip_atomic_load(all + (size_t)q * S64_SLOT + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
             double tot = v[0];
 #pragma unroll
-            for (int q = 1; q < S64_GMAX; ++q) tot += v[q];  // slab order: the same bits in every workgroup (+ 0.0 beyond G)
-            bl[j] = (j < M ? 1.0 / nm : (double)N / nm) / tot;
+            for (int q = 1; q < GM; ++q) tot += v[q];        // slab order: the same bits in every workgroup (+ 0.0 beyond G)
+            bl[j] = (j < M ? mu : nuM) * recip_f64(tot);
         }
         __syncthreads();
 #pragma unroll
@@ -259,7 +294,7 @@ __global__ __launch_bounds__(S64_THREADS, 2) void sinkhorn_f64_kernel(Sk64Args a
             double bv = colbuf[0][j];
             int bi = cidx[0][j];
 #pragma unroll
-            for (int w = 1; w < 8; ++w)
+            for (int w = 1; w < S64_WAVES; ++w)
                 if (colbuf[w][j] > bv) { bv = colbuf[w][j]; bi = cidx[w][j]; }
             if (last && !a.inner && bl[j] > bv) { bv = bl[j]; bi = N; }
             a.cslab_val[((size_t)pair * G + g) * M + j] = bv;
@@ -286,15 +321,17 @@ __global__ __launch_bounds__(256) void sinkhorn_f64_merge_kernel(const int* sidx
 }  // namespace
 
 static size_t s64_align(size_t v) { return (v + 255) & ~(size_t)255; }
+static size_t s64_lds_bytes(int waves) { return ((size_t)waves * S64_SLOT + S64_SLOT) * sizeof(double) + (size_t)waves * S64_SLOT * sizeof(int); }
 
+// (sized for the eight-wave form: the larger slab count)
 size_t sinkhorn_f64_workspace_bytes(int B, int N, int M) {
     if (B <= 0) return 0;
-    const size_t G = (N + S64_ROWS - 1) / S64_ROWS;
+    const size_t G = (N + 31) / 32;
     return s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double)) + s64_align((size_t)B * 3 * G * sizeof(unsigned)) +
            s64_align((size_t)B * G * M * sizeof(double)) + s64_align((size_t)B * G * M * sizeof(int));
 }
 
-bool sinkhorn_f64_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= S64_ROWS * S64_GMAX; }
+bool sinkhorn_f64_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= 32 * S64_GMAX; }
 
 int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
                         float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, size_t workspace_bytes, unsigned* error_word,
@@ -305,20 +342,36 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
         mdgat_set_error("fp64 Sinkhorn: workspace too small or not 256-byte aligned");
         return MDGAT_ERR_BAD_ARG;
     }
-    const int G = (N + S64_ROWS - 1) / S64_ROWS;
+    // 16-wave workgroups once the 8-wave ones would not all have a CU of their own (MDGAT_SK64_WAVES=8|16 forces one: measurements).
+    // 100 iterations at N = M = 512, us: B = 1 / 8 / 16 / 32: eight waves 432 / 441 / 452 / 878, sixteen 602 / 617 / 627 / 818
+    static const int waves_env = [] { const char* e = getenv("MDGAT_SK64_WAVES"); return e ? atoi(e) : 0; }();
+    int num_cu = 256, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    int waves = (long)B * ((N + 31) / 32) > num_cu ? 16 : 8;
+    if (waves_env == 8 || waves_env == 16) waves = waves_env;
+    const int G = (N + 4 * waves - 1) / (4 * waves);
     char* w = static_cast<char*>(workspace);
     Sk64Args a{};
     a.scores = scores; a.alpha = alpha; a.alpha_dev = alpha_dev; a.B = B; a.N = N; a.M = M; a.iters = iters; a.G = G; a.inner = inner;
     a.Z64 = Z64; a.Z32 = Z32; a.rbest_idx = rbest_idx; a.rbest_val = rbest_val;
-    a.slots = reinterpret_cast<double*>(w); w += s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double));
-    a.flags = reinterpret_cast<unsigned*>(w); w += s64_align((size_t)B * 3 * G * sizeof(unsigned));
-    double* sval = reinterpret_cast<double*>(w); w += s64_align((size_t)B * G * M * sizeof(double));
+    const size_t Gmax = (N + 31) / 32;
+    a.slots = reinterpret_cast<double*>(w); w += s64_align((size_t)B * 2 * Gmax * S64_SLOT * sizeof(double));
+    a.flags = reinterpret_cast<unsigned*>(w); w += s64_align((size_t)B * 3 * Gmax * sizeof(unsigned));
+    double* sval = reinterpret_cast<double*>(w); w += s64_align((size_t)B * Gmax * M * sizeof(double));
     int* sidx = reinterpret_cast<int*>(w);
     a.cslab_idx = cbest_idx ? sidx : nullptr; a.cslab_val = cbest_idx ? sval : nullptr;
     a.error_word = error_word;
     if (int rc = mdgat_check_hip(hipMemsetAsync(a.flags, 0, (size_t)B * 3 * G * sizeof(unsigned), s), "memset(fp64 Sinkhorn flags)")) return rc;
     const int groups = (B + 7) / 8;
-    hipLaunchKernelGGL(sinkhorn_f64_kernel, dim3(groups * 8 * G), dim3(S64_THREADS), 0, s, a);
+    const size_t lds = s64_lds_bytes(waves);
+    static std::atomic<unsigned long long> optin8{0}, optin16{0};
+    if (waves == 16) {
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<16>), lds, optin16, "sinkhorn_f64 LDS")) return rc;
+        hipLaunchKernelGGL(sinkhorn_f64_kernel<16>, dim3(groups * 8 * G), dim3(1024), lds, s, a);
+    } else {
+        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<8>), lds, optin8, "sinkhorn_f64 LDS")) return rc;
+        hipLaunchKernelGGL(sinkhorn_f64_kernel<8>, dim3(groups * 8 * G), dim3(512), lds, s, a);
+    }
     if (int rc = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 launch")) return rc;
     if (cbest_idx) {
         const size_t total = (size_t)B * M;
