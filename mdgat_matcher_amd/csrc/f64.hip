@@ -914,14 +914,14 @@ constexpr long F64_SOLO_MIN_WG_PER_CU = 4;
 // -1: by launch size (default); 0: always the keys of a query tile split over the four waves (what a pair returns is then bit-identical
 // whatever batch it travels in); 1: always one wave per 32 queries.  MDGAT_F64_ATTENTION_FORM in the environment.
 static std::atomic<int> g_attention_form{-2};
-static int attention_form() {
+int f64_attention_form() {
     const int v = g_attention_form.load(std::memory_order_relaxed);
     if (v != -2) return v;
     static const int env = [] { const char* e = getenv("MDGAT_F64_ATTENTION_FORM"); const int m = e ? atoi(e) : -1; return m == 0 || m == 1 ? m : -1; }();
     return env;
 }
 extern "C" int mdgat_set_f64_attention_form(int mode) {
-    const int prev = attention_form();
+    const int prev = f64_attention_form();
     g_attention_form.store(mode == 0 || mode == 1 ? mode : mode == -1 ? -1 : -2, std::memory_order_relaxed);
     return prev;
 }
@@ -973,7 +973,7 @@ int launch_attention_f64(int B, int N, int M, int cross, int topk, const double*
         static const int qb_env = [] { const char* e = getenv("MDGAT_F64_ATT_QB"); return e ? atoi(e) : 0; }();
         // one wave per 32 queries (SOLO) from F64_SOLO_MIN_WG_PER_CU workgroups of four such waves per CU on; mdgat_set_f64_attention_form(1)
         // forces it at every size (tests: ragged frames, one pair), (0) never
-        const int form = attention_form();
+        const int form = f64_attention_form();
         const long solo_wgs = 8L * ((nk_max + 127) / 128) * ugroups;
         const bool solo = qb_env == 0 && (form == 1 || (form != 0 && solo_wgs >= F64_SOLO_MIN_WG_PER_CU * (long)f64_cu_count()));
         if (solo) return go(attention_f64_kernel<false, 2, false, false, true>, 128, false, 0, std::integral_constant<int, 6>());

@@ -348,6 +348,10 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     int num_cu = 256, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
     int waves = (long)B * ((N + 31) / 32) > num_cu ? 16 : 8;
+    // (the two sum a column's partials in different groupings - equal to rounding, not bit for bit: mdgat_set_f64_attention_form(0), the
+    // request for results that do not depend on the batch a pair travels in, keeps eight waves at every size; (1) sixteen)
+    if (f64_attention_form() == 0) waves = 8;
+    else if (f64_attention_form() == 1) waves = 16;
     if (waves_env == 8 || waves_env == 16) waves = waves_env;
     const int G = (N + 4 * waves - 1) / (4 * waves);
     char* w = static_cast<char*>(workspace);
