@@ -316,6 +316,33 @@ def test_literal_bar_on_a_reference_held_batch_that_runs_in_slices(golden_dir, t
     assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
 
 
+def test_literal_bar_on_a_second_reference_held_batch(golden_dir):
+    """tests/golden/cfg_n400_L9_S100_b24.npz: 24 pairs of 400 keypoints (no multiple of the 32-row slabs of the fp64 Sinkhorn, of the
+    64-key register blocks, of the 128-query workgroups) the REFERENCE ran as one batch, with other weights (seed 7) and bin score
+    0.37.  A float64 module, no extra key: every match identical, Z to the rounding of its fp32 output, matching scores to 1e-6."""
+    g = _g(golden_dir, 'cfg_n400_L9_S100_b24')
+    net, cfg, sd, data, (B, n, m, L) = _build(g)
+    assert net.exact() and B == 24 and n == 400
+    dev = {k: v.to(DEV) for k, v in data.items()}
+    with torch.no_grad():
+        out = net(dev)
+        Z = net.match(dev['keypoints0'], dev['descriptors0'], dev['keypoints1'], dev['descriptors1'], dev['scores0'], dev['scores1'],
+                      return_scores=True)[4]
+    torch.cuda.synchronize()
+    net.check(DEV)
+    np.testing.assert_array_equal(out['matches0'].cpu().numpy(), g['default_matches0'])
+    np.testing.assert_array_equal(out['matches1'].cpu().numpy(), g['default_matches1'])
+    es = max(np.abs(out['matching_scores0'].cpu().numpy() - g['default_mscores0']).max(),
+             np.abs(out['matching_scores1'].cpu().numpy() - g['default_mscores1']).max())
+    Zc = Z.cpu().double().numpy()
+    sub = int(g['sub'])
+    mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
+    ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
+    err = np.abs(mine - ref_Z).max()
+    print(f'[parity-f64] cfg_n400_L9_S100_b24: max|dZ| vs the reference {err:.2e}, mscores {es:.2e}, every match identical')
+    assert err < 2e-6 and es < 1e-6
+
+
 def test_sinkhorn_arithmetic_key():
     """config['sinkhorn_arithmetic']: 'fp64' refuses frames beyond the fp64 Sinkhorn kernel (575 keypoints), 'auto' falls back to the
     fp32-class tail there, 'fp32' always takes it; the three agree on the matches of an ordinary pair."""
