@@ -163,8 +163,8 @@ __global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_ke
 
     for (int it = 0; it < a.iters; ++it) {
         // a_i = mu_i / sum_j K_ij b_j; the dustbin row: a_N = mu_N / sum_j b_j (the same bits in every wave of every workgroup)
-        {
-            double sb = 0.0;
+        {                    // (only the last slab needs it; under `if (last)` the sixteen-wave instance - 128 registers, spills - computed
+            double sb = 0.0;     // garbage at every size: measured, reverted)
 #pragma unroll
             for (int c = 0; c < S64_NC; ++c) sb += b[c];
             aN = muN * recip_f64(wave_sum_f64(sb));
