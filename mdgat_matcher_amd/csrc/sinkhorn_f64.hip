@@ -346,7 +346,14 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     // 100 iterations at N = M = 512, us: B = 1 / 8 / 16 / 32: eight waves 432 / 441 / 452 / 878, sixteen 602 / 617 / 627 / 818
     static const int waves_env = [] { const char* e = getenv("MDGAT_SK64_WAVES"); return e ? atoi(e) : 0; }();
     int num_cu = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {      // (asked once per device)
+        static std::atomic<int> cached[16];
+        num_cu = cached[dev].load(std::memory_order_relaxed);
+        if (num_cu <= 0) {
+            if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0) num_cu = 256;
+            cached[dev].store(num_cu, std::memory_order_relaxed);
+        }
+    }
     int waves = (long)B * ((N + 31) / 32) > num_cu ? 16 : 8;
     // (the two sum a column's partials in different groupings - equal to rounding, not bit for bit: mdgat_set_f64_attention_form(0), the
     // request for results that do not depend on the batch a pair travels in, keeps eight waves at every size; (1) sixteen)
