@@ -258,9 +258,7 @@ int mdgat_set_f64_layer_fusion(int mode);
  * the four waves of a workgroup and combine them through LDS.  The two forms sum a row's terms in different orders: they agree to
  * rounding (1e-15 relative), not bit for bit, so what a pair returns can differ in the last bits with the size of the batch it
  * travels in.  0: always the split-key form - a pair's result is then bit-identical whatever the batch; 1: always one wave per
- * 32 queries; mode < -1: back to the environment's / default.  Process-wide.  Returns the previous value.
- * The fp64 Sinkhorn follows the same switch: 8-wave workgroups for launches that give each a CU, 16-wave ones beyond (two groupings of
- * a column's partial sums); 0 keeps eight waves, 1 sixteen. */
+ * 32 queries; mode < -1: back to the environment's / default.  Process-wide.  Returns the previous value. */
 int mdgat_set_f64_attention_form(int mode);
 
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */

@@ -35,8 +35,8 @@ struct AttnF64Args {
     unsigned* guard;       // as GemmF64Args::guard, for the message rows
 };
 // attention (topk == 0) / dynamic_attention (mdgat.py:190-210) on fp64 q / k / v; sel: optional tap of the kept keys
-// mdgat_set_f64_attention_form / MDGAT_F64_ATTENTION_FORM: -1 kernels by launch size; 0 the forms whose results do not depend on the batch a
-// pair travels in (split-key full attention, eight-wave fp64 Sinkhorn); 1 the big-launch forms at every size
+// mdgat_set_f64_attention_form / MDGAT_F64_ATTENTION_FORM: -1 full attention by launch size; 0 always the split-key form (results do not
+// depend on the batch a pair travels in); 1 the big-launch form at every size
 int f64_attention_form();
 int launch_attention_f64(int B, int N, int M, int cross, int topk, const double* qkv, double* msg, uint32_t* sel, hipStream_t s, unsigned* guard = nullptr);
 // in4 [R][4] = x y z saliency, in33 [R][33] = FPFH; rows pair-major, frame 0 then frame 1

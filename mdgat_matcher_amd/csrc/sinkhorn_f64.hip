@@ -12,7 +12,7 @@
 // fp64 has the range for it: every K is in (e^-700, 1], the scaling factors stay within e^(+-|scores|).
 //
 // gfx950 mapping.  A pair's N x (M + 1) block of K stays in REGISTERS for all iterations, spread over G = ceil(N / 32) workgroups of
-// eight waves (or ceil(N / 64) of sixteen): workgroup g owns rows 32 g .. 32 g + 31, wave w of it four of them, lane l the columns
+// eight waves: workgroup g owns rows 32 g .. 32 g + 31, wave w of it four of them, lane l the columns
 // l, l + 64, ... (nine per lane at M = 512: 36 doubles); the dustbin ROW is all ones after its maximum is taken out and is carried as
 // one scalar.  Row sums are in-lane dot products and one butterfly per row; column sums are in-lane over
 // the wave's four rows, merged over the eight waves through LDS and over the G workgroups through memory: every workgroup publishes
@@ -23,6 +23,7 @@
 #include "common.hpp"
 #include "f64.hpp"
 #include "sinkhorn_f64.hpp"
+#include <mutex>
 
 namespace {
 
@@ -83,9 +84,7 @@ __device__ __forceinline__ double shfl_xor_d(double v, int m) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
-// S64_WAVES waves of four rows each per workgroup: 8 (32 rows; two workgroups per CU) for small launches - a pair is 16 workgroups on 16 CUs -
-// or 16 (64 rows, one workgroup per CU: half the partners, half the flags) when the launch fills the chip: 32 pairs 894 -> 810 us per
-// 100 iterations, but one pair 442 -> 617.
+// S64_WAVES waves of four rows each per workgroup: 8 (32 rows) is what is launched - a pair of 512 keypoints is 16 workgroups on 16 CUs.
 template <int S64_WAVES>
 __global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_kernel(Sk64Args a) {
     // (one workgroup per CU either way: eight waves at 168 registers, sixteen at 128.  Two eight-wave workgroups per CU - 128 registers,
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_ke
             unsigned v = 0;
             long spins = 0;
             while ((v = __hip_atomic_load(flags + 2 * G + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
-                if (++spins > (1L << 26)) { dead = 1; same = -1; break; }
+                if (++spins > (1L << 22)) { dead = 1; same = -1; break; }
             if (same > 0 && v != my_xcc + 1u) same = 0;
         }
         same_xcd_s = same > 0;
@@ -208,7 +207,7 @@ __global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_ke
         if (tid < G && tid != g && !dead) {
             long spins = 0;
             while (__hip_atomic_load(fl + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(it + 1)) {
-                if (++spins > (1L << 26)) { dead = 1; break; }
+                if (++spins > (1L << 22)) { dead = 1; break; }
             }
         }
         __syncthreads();
@@ -321,6 +320,7 @@ __global__ __launch_bounds__(256) void sinkhorn_f64_merge_kernel(const int* sidx
 }  // namespace
 
 static size_t s64_align(size_t v) { return (v + 255) & ~(size_t)255; }
+struct S64Serial { std::mutex m; hipEvent_t ev = nullptr; bool recorded = false; };
 static size_t s64_lds_bytes(int waves) { return ((size_t)waves * S64_SLOT + S64_SLOT) * sizeof(double) + (size_t)waves * S64_SLOT * sizeof(int); }
 
 // (sized for the eight-wave form: the larger slab count)
@@ -342,24 +342,11 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
         mdgat_set_error("fp64 Sinkhorn: workspace too small or not 256-byte aligned");
         return MDGAT_ERR_BAD_ARG;
     }
-    // 16-wave workgroups once the 8-wave ones would not all have a CU of their own (MDGAT_SK64_WAVES=8|16 forces one: measurements).
-    // 100 iterations at N = M = 512, us: B = 1 / 8 / 16 / 32: eight waves 432 / 441 / 452 / 878, sixteen 602 / 617 / 627 / 818
-    static const int waves_env = [] { const char* e = getenv("MDGAT_SK64_WAVES"); return e ? atoi(e) : 0; }();
-    int num_cu = 256, dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 16) {      // (asked once per device)
-        static std::atomic<int> cached[16];
-        num_cu = cached[dev].load(std::memory_order_relaxed);
-        if (num_cu <= 0) {
-            if (hipDeviceGetAttribute(&num_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || num_cu <= 0) num_cu = 256;
-            cached[dev].store(num_cu, std::memory_order_relaxed);
-        }
-    }
-    int waves = (long)B * ((N + 31) / 32) > num_cu ? 16 : 8;
-    // (the two sum a column's partials in different groupings - equal to rounding, not bit for bit: mdgat_set_f64_attention_form(0), the
-    // request for results that do not depend on the batch a pair travels in, keeps eight waves at every size; (1) sixteen)
-    if (f64_attention_form() == 0) waves = 8;
-    else if (f64_attention_form() == 1) waves = 16;
-    if (waves_env == 8 || waves_env == 16) waves = waves_env;
+    // Eight-wave workgroups at every launch size.  Sixteen-wave ones (64 rows, half the partners, one per CU) were 7 % faster once the
+    // launch no longer gives every workgroup a CU (32 pairs of 512: 818 against 878 us per 100 iterations; one pair 602 against 432) -
+    // at 128 registers with spills, a second grouping of the column sums (so results that depend on the batch a pair travels in), and a
+    // code generation that turned to garbage under a harmless edit (profiles/NOTES_r6.md section 12): not kept.
+    constexpr int waves = 8;
     const int G = (N + 4 * waves - 1) / (4 * waves);
     char* w = static_cast<char*>(workspace);
     Sk64Args a{};
@@ -372,18 +359,36 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     int* sidx = reinterpret_cast<int*>(w);
     a.cslab_idx = cbest_idx ? sidx : nullptr; a.cslab_val = cbest_idx ? sval : nullptr;
     a.error_word = error_word;
+    // ONE launch of this kernel at a time per device: a launch waits (on its own stream) for the previous one, whatever stream that was on.
+    // The workgroups of a pair wait for each other, and a workgroup that waits holds its CU.  Within one launch that is safe - an XCD gets
+    // its pairs in order, each as a contiguous run of workgroups, so at most one pair per XCD is partly resident and the other slots hold
+    // a complete pair that finishes - and other kernels that occupy CUs are finite.  But three launches in flight can each hold a partly
+    // resident pair on an XCD (3 x 15 of its 32 slots) with no slot left for any of them: measured - four streams, launches of 20 and
+    // 40 pairs: every spin ran into its bound and the results were garbage.  (Streams being captured into a graph are left alone.)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    static S64Serial serial[16];
+    S64Serial& sr = serial[dev >= 0 && dev < 16 ? dev : 0];
+    std::lock_guard<std::mutex> lock(sr.m);
+    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+    (void)hipStreamIsCapturing(s, &capturing);
+    const bool chain = capturing == hipStreamCaptureStatusNone;
+    if (chain) {
+        if (!sr.ev && hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming) != hipSuccess) sr.ev = nullptr;
+        if (sr.ev && sr.recorded)
+            if (int rc = mdgat_check_hip(hipStreamWaitEvent(s, sr.ev, 0), "fp64 Sinkhorn: wait for the previous launch")) return rc;
+    }
     if (int rc = mdgat_check_hip(hipMemsetAsync(a.flags, 0, (size_t)B * 3 * G * sizeof(unsigned), s), "memset(fp64 Sinkhorn flags)")) return rc;
     const int groups = (B + 7) / 8;
     const size_t lds = s64_lds_bytes(waves);
-    static std::atomic<unsigned long long> optin8{0}, optin16{0};
-    if (waves == 16) {
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<16>), lds, optin16, "sinkhorn_f64 LDS")) return rc;
-        hipLaunchKernelGGL(sinkhorn_f64_kernel<16>, dim3(groups * 8 * G), dim3(1024), lds, s, a);
-    } else {
-        if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<8>), lds, optin8, "sinkhorn_f64 LDS")) return rc;
-        hipLaunchKernelGGL(sinkhorn_f64_kernel<8>, dim3(groups * 8 * G), dim3(512), lds, s, a);
-    }
+    static std::atomic<unsigned long long> optin8{0};
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<8>), lds, optin8, "sinkhorn_f64 LDS")) return rc;
+    hipLaunchKernelGGL(sinkhorn_f64_kernel<8>, dim3(groups * 8 * G), dim3(512), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 launch")) return rc;
+    if (chain && sr.ev) {
+        if (int rc = mdgat_check_hip(hipEventRecord(sr.ev, s), "fp64 Sinkhorn: record")) return rc;
+        sr.recorded = true;
+    }
     if (cbest_idx) {
         const size_t total = (size_t)B * M;
         hipLaunchKernelGGL(sinkhorn_f64_merge_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, sidx, sval, B, G, M,

@@ -170,19 +170,11 @@ def _build(g, **cfg_over):
 @pytest.mark.parametrize('B,N,M,iters,alpha,scale', [(1, 7, 5, 20, 1.0, 3.0), (2, 64, 64, 100, 0.37, 3.0), (2, 48, 64, 50, 1.0, 3.0), (3, 512, 512, 100, 1.0, 3.0),
                                                      (2, 400, 512, 100, 1.0, 6.0), (1, 100, 31, 10, 2.0, 1.0), (9, 256, 256, 20, 1.0, 3.0), (1, 1, 1, 5, 1.0, 1.0),
                                                      (2, 575, 33, 30, 1.0, 2.0), (1, 33, 575, 30, 0.5, 10.0)])
-@pytest.mark.parametrize('form', [0, 1])
-def test_sinkhorn_f64(B, N, M, iters, alpha, scale, form):
+def test_sinkhorn_f64(B, N, M, iters, alpha, scale):
     """csrc/sinkhorn_f64.hip (log_optimal_transport in the reference's own arithmetic, mdgat.py:279-308 run in float64) against the
     oracle: Z to 1e-12, and the match extraction of all four branches - every arg-max decided on the fp64 Z inside the kernel - equal to
-    the extraction of the oracle's Z.  Both workgroup shapes at every size (mdgat_set_f64_attention_form: 0 = eight waves, what small
-    launches get; 1 = sixteen, what launches beyond one workgroup per CU get)."""
-    from mdgat_matcher_amd import _lib
-    lib = _lib.load()
-    lib.mdgat_set_f64_attention_form(form)
-    try:
-        _sinkhorn_f64_case(B, N, M, iters, alpha, scale)
-    finally:
-        lib.mdgat_set_f64_attention_form(-2)
+    the extraction of the oracle's Z."""
+    _sinkhorn_f64_case(B, N, M, iters, alpha, scale)
 
 
 def _sinkhorn_f64_case(B, N, M, iters, alpha, scale):
