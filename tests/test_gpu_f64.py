@@ -191,6 +191,28 @@ def _sinkhorn_f64_case(B, N, M, iters, alpha, scale):
         assert (Z32.cpu().double() - Zr).abs().max().item() < 4e-6 * max(1.0, Zr.abs().max().item() / 32)      # the fp32 rounding of the fp64 Z
 
 
+def test_sinkhorn_f64_launches_on_concurrent_streams():
+    """Launches of the fp64 Sinkhorn in flight on four streams, some of more workgroups than the device has CUs: the workgroups of a
+    pair wait for each other while holding their CUs, so unadmitted concurrent launches can starve each other (three partly resident
+    pairs fill an XCD; measured: every spin ran into its bound).  The launcher admits one launch at a time per device; every output
+    must be bit-equal to the serial run's."""
+    torch.manual_seed(0)
+    cases = [(torch.randn(B, N, M, dtype=torch.float64, device=DEV) * 3, it) for (B, N, M, it) in
+             [(3, 512, 512, 40), (9, 256, 300, 20), (1, 575, 575, 30), (20, 512, 512, 15), (40, 400, 400, 10), (2, 33, 17, 50)]]
+    ref = [ops.sinkhorn_f64_extract(s, 1.0, it, want_Z=True) for s, it in cases]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(DEV) for _ in range(4)]
+    for rnd in range(3):
+        outs = []
+        for i, (s, it) in enumerate(cases * 2):
+            with torch.cuda.stream(streams[(i + rnd) % 4]):
+                outs.append((i % len(cases), ops.sinkhorn_f64_extract(s, 1.0, it, want_Z=True)))
+        torch.cuda.synchronize()
+        for ci, o in outs:
+            for a, b in zip(o, ref[ci]):
+                assert torch.equal(a, b), (rnd, ci)
+
+
 def test_sinkhorn_f64_decides_near_ties_like_fp64():
     """Two rows that are the same but for 1e-9 in one column: their potentials agree, so the two candidates of that column are 8e-10
     apart in the fp64 Z - equal as fp32 numbers.  The kernel's arg-max (superglue branch: over the inner block, mdgat.py:444) follows
