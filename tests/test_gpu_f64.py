@@ -369,6 +369,21 @@ def test_literal_bar_on_a_second_reference_held_batch(golden_dir):
     assert err < 2e-6 and es < 1e-6
 
 
+@pytest.mark.parametrize('B', [3, 40])
+def test_f64_tail_applies_the_batch_wide_dustbin_rule(B):
+    """mdgat.py:465-467 through the fp64 tail (the extraction runs from the arg-maxes the fp64 Sinkhorn decided): a bin score of 60 sends
+    every keypoint to the dustbin - all matches -1 and, the reference's quirk, INTEGER zero scores - for one launch and for a batch that
+    runs in slices on two lanes (the rule is batch-wide: applied after the slices)."""
+    cfg = synth.default_config(L=2, k=[64, None, 32, None], sinkhorn_iterations=10)
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5, bin_score=60.0))
+    net = net.eval().to(DEV)
+    assert net.exact()
+    out = net(synth.make_batch(B, 512, 512, device=DEV))
+    assert (out['matches0'] == -1).all() and (out['matches1'] == -1).all()
+    assert out['matching_scores0'].dtype == torch.int64 and (out['matching_scores0'] == 0).all() and (out['matching_scores1'] == 0).all()
+
+
 def test_sinkhorn_arithmetic_key():
     """config['sinkhorn_arithmetic']: 'fp64' refuses frames beyond the fp64 Sinkhorn kernel (575 keypoints), 'auto' falls back to the
     fp32-class tail there, 'fp32' always takes it; the three agree on the matches of an ordinary pair."""
