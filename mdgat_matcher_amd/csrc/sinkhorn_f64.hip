@@ -69,6 +69,44 @@ __device__ __forceinline__ double wave_sum_f64(double v) {
     }
     return v;
 }
+// Four wave-wide sums at once (the scheme of sinkhorn.hip's wave_sum16, in fp64): in: this lane's partials p[0..3] of the wave's four
+// rows; out: in EVERY lane of the 16-lane DPP row q the wave total of row q.  Lane-half swap (v_permlane32_swap on two copies: lanes
+// below 32 then hold rows 0 / 1, the others rows 2 / 3), 16-lane-row swap, four rotations inside the rows: ~30 instructions and one
+// dependency chain instead of four chains of ~24 (wave_sum_f64 per row).  (Inline asm: the compiler inserts none of the wait states
+// these instructions need around a vector write / read of their operands - sinkhorn.hip.)
+__device__ __forceinline__ void swap_halves32_d(double& a, double& b) {
+    unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl_ = (unsigned)ub, bh = (unsigned)(ub >> 32);
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3\n\ts_nop 1" : "+v"(al), "+v"(bl_), "+v"(ah), "+v"(bh));
+    a = __builtin_bit_cast(double, ((unsigned long long)ah << 32) | al);
+    b = __builtin_bit_cast(double, ((unsigned long long)bh << 32) | bl_);
+}
+__device__ __forceinline__ void swap_rows16_d(double& a, double& b) {
+    unsigned long long ua = __builtin_bit_cast(unsigned long long, a), ub = __builtin_bit_cast(unsigned long long, b);
+    unsigned al = (unsigned)ua, ah = (unsigned)(ua >> 32), bl_ = (unsigned)ub, bh = (unsigned)(ub >> 32);
+    asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3\n\ts_nop 1" : "+v"(al), "+v"(bl_), "+v"(ah), "+v"(bh));
+    a = __builtin_bit_cast(double, ((unsigned long long)ah << 32) | al);
+    b = __builtin_bit_cast(double, ((unsigned long long)bh << 32) | bl_);
+}
+__device__ __forceinline__ double wave_sum4_f64(const double (&p)[4]) {
+    double x0 = p[0], y0 = p[2], x1 = p[1], y1 = p[3];
+    swap_halves32_d(x0, y0);                 // x0 = (p0 | p2 from the lower half), y0 = (p0 | p2 from the upper half)
+    swap_halves32_d(x1, y1);
+    double s0 = x0 + y0, s1 = x1 + y1;       // lanes < 32: rows 0 / 1 summed over the halves; lanes >= 32: rows 2 / 3
+    swap_rows16_d(s0, s1);                   // s0 = (s0 r0, s1 r0, s0 r2, s1 r2), s1 = (s0 r1, s1 r1, s0 r3, s1 r3)
+    double t = s0 + s1;                      // DPP row q: row q's partials summed over the four 16-lane rows
+    t += dpp_mov_d<0x128>(t);
+    t += dpp_mov_d<0x124>(t);
+    t += dpp_mov_d<0x122>(t);
+    t += dpp_mov_d<0x121>(t);
+    return t;
+}
+__device__ __forceinline__ double readlane_d(double v, int lane) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, v);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 // 1 / p for the scaling factors (p a positive sum, far from the ends of the exponent range): the hardware's estimate and two Newton
 // steps - 2^-53 relative, not correctly rounded, the same bits wherever it is evaluated.  The IEEE division is ~35 instructions, and an
 // iteration holds six of them per lane: nearly half of its vector instructions.
@@ -162,19 +200,26 @@ __global__ __launch_bounds__(64 * S64_WAVES, S64_WAVES / 4) void sinkhorn_f64_ke
 
     for (int it = 0; it < a.iters; ++it) {
         // a_i = mu_i / sum_j K_ij b_j; the dustbin row: a_N = mu_N / sum_j b_j (the same bits in every wave of every workgroup)
-        {                    // (only the last slab needs it; under `if (last)` the sixteen-wave instance - 128 registers, spills - computed
-            double sb = 0.0;     // garbage at every size: measured, reverted)
+        {                    // (only the last slab needs it, but every slab waits for the last one anyway: under `if (last)` 392 against 399 us for
+            double sb = 0.0;     // one pair, 823-847 against 804-827 for 32 - nothing; and that branch once broke a since-dropped instantiation)
 #pragma unroll
             for (int c = 0; c < S64_NC; ++c) sb += b[c];
             aN = muN * recip_f64(wave_sum_f64(sb));
         }
+        {
+            double p[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            double p = 0.0;
+            for (int i = 0; i < 4; ++i) {
+                p[i] = 0.0;
 #pragma unroll
-            for (int c = 0; c < S64_NC; ++c) p = __builtin_fma(K[i][c], b[c], p);
-            p = wave_sum_f64(p);
-            av[i] = row0 + i < N ? mu * recip_f64(p) : 0.0;
+                for (int c = 0; c < S64_NC; ++c) p[i] = __builtin_fma(K[i][c], b[c], p[i]);
+            }
+            // the four row sums in one reduction: DPP row q ends up with row q's total, ONE reciprocal serves the four rows, and the
+            // scalings go back to every lane through scalar registers
+            const double tq = wave_sum4_f64(p);
+            const double aq = row0 + (lane >> 4) < N ? mu * recip_f64(tq) : 0.0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = readlane_d(aq, 16 * i);
         }
         // column partials of this wave's rows -> LDS
 #pragma unroll
