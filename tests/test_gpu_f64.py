@@ -342,13 +342,15 @@ def test_literal_bar_on_a_reference_held_batch_that_runs_in_slices(golden_dir, t
     assert np.abs(torch.logsumexp(Z.double(), 1).cpu().numpy() - g['Z_col_lse']).max() < Z_TOL
 
 
-def test_literal_bar_on_a_second_reference_held_batch(golden_dir):
+@pytest.mark.parametrize('name,pairs', [('cfg_n400_L9_S100_b24', 24), ('cfg_n256_L4_S20_b64', 64)])
+def test_literal_bar_on_a_second_reference_held_batch(golden_dir, name, pairs):
     """tests/golden/cfg_n400_L9_S100_b24.npz: 24 pairs of 400 keypoints (no multiple of the 32-row slabs of the fp64 Sinkhorn, of the
     64-key register blocks, of the 128-query workgroups) the REFERENCE ran as one batch, with other weights (seed 7) and bin score
-    0.37.  A float64 module, no extra key: every match identical, Z to the rounding of its fp32 output, matching scores to 1e-6."""
-    g = _g(golden_dir, 'cfg_n400_L9_S100_b24')
+    0.37; cfg_n256_L4_S20_b64.npz: 64 pairs of BASELINE configs[0]'s shape (L = 4: every self layer dynamic; weights seed 3).  A float64
+    module, no extra key: every match identical, Z to the rounding of its fp32 output, matching scores to 1e-6."""
+    g = _g(golden_dir, name)
     net, cfg, sd, data, (B, n, m, L) = _build(g)
-    assert net.exact() and B == 24 and n == 400
+    assert net.exact() and B == pairs
     dev = {k: v.to(DEV) for k, v in data.items()}
     with torch.no_grad():
         out = net(dev)
@@ -365,7 +367,7 @@ def test_literal_bar_on_a_second_reference_held_batch(golden_dir):
     mine = np.concatenate([Zc[:, ::sub, ::sub].reshape(B, -1), Zc[:, -1, :], Zc[:, :, -1]], axis=1)
     ref_Z = np.concatenate([g['Z_sub'].reshape(B, -1), g['Z_lastrow'], g['Z_lastcol']], axis=1)
     err = np.abs(mine - ref_Z).max()
-    print(f'[parity-f64] cfg_n400_L9_S100_b24: max|dZ| vs the reference {err:.2e}, mscores {es:.2e}, every match identical')
+    print(f'[parity-f64] {name}: max|dZ| vs the reference {err:.2e}, mscores {es:.2e}, every match identical')
     assert err < 2e-6 and es < 1e-6
 
 

@@ -64,7 +64,7 @@ def test_extraction_variants(golden_dir, name):
 
 
 @pytest.mark.parametrize('name', ['cfg_n256_L4_S20', 'cfg_n512_L9_S100', 'cfg_n2048_L9_S200', 'cfg_n2048_L9_S200_b', 'cfg_n512_L9_S100_seed7',
-                                  'cfg_n512_L9_S100_b40', 'cfg_n400_L9_S100_b24'])
+                                  'cfg_n512_L9_S100_b40', 'cfg_n400_L9_S100_b24', 'cfg_n256_L4_S20_b64'])
 def test_config_shapes(golden_dir, name):
     g = _load(golden_dir, name)
     sd, data, k, L, S, n, m = _setup(g)

@@ -337,6 +337,8 @@ def main():
         ('cfg_n512_L9_S100_b40', lambda nm: gen_config(M, nm, 40, 512, 512, 9, 100, synth.DEFAULT_K, first_pair=200, sub=32)),
         # ... and one with other weights, another bin score and a keypoint count that is no multiple of the kernels' tiles (24 pairs of 400: one slice)
         ('cfg_n400_L9_S100_b24', lambda nm: gen_config(M, nm, 24, 400, 400, 9, 100, synth.DEFAULT_K, seed=7, first_pair=300, bin_score=0.37, sub=32)),
+        # ... and configs[0]'s shape as a batch of 64 (every layer dynamic or cross at L = 4; weights seed 3)
+        ('cfg_n256_L4_S20_b64', lambda nm: gen_config(M, nm, 64, 256, 256, 4, 20, synth.DEFAULT_K, seed=3, first_pair=500, sub=32)),
         ('var_n256_L4_S20', lambda nm: gen_config_variants(M, nm, 256, 256, 4, 20, synth.DEFAULT_K, first_pair=11)),
         ('var_n512_L9_S100', lambda nm: gen_config_variants(M, nm, 512, 512, 9, 100, synth.DEFAULT_K, first_pair=12)),
         ('var_n400m512_L9_S100', lambda nm: gen_config_variants(M, nm, 400, 512, 9, 100, synth.DEFAULT_K, first_pair=13)),
