@@ -173,9 +173,9 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
     data = synth.make_batch(B, n, n, first_pair=0, dtype=torch.float64, device=dev)
     inputs = (data['keypoints0'], data['scores0'], data['descriptors0'], data['keypoints1'], data['scores1'], data['descriptors1'])
     sched = net._topk_schedule()
-    # the tail (every layer, final_proj, scores, Sinkhorn, the extraction's arg-maxes) is fp64 as well for frames of at most 575 keypoints
-    # (config['sinkhorn_arithmetic'] = 'auto'); beyond that fp64 runs through the last dynamic layer
-    tail64 = n <= 575 and getattr(net, 'sinkhorn_arithmetic', 'fp32') != 'fp32'
+    # the tail (every layer, final_proj, scores, Sinkhorn, the extraction's arg-maxes) is fp64 as well (config['sinkhorn_arithmetic'] =
+    # 'auto'; frames beyond 575 keypoints: the streaming form of the fp64 Sinkhorn, beyond 2175 the fp32-class tail)
+    tail64 = n <= 2175 and getattr(net, 'sinkhorn_arithmetic', 'fp32') != 'fp32'
     n64 = 2 * L if tail64 else max([i + 1 for i, k in enumerate(sched) if k > 0], default=0)
     one = tuple(t[:1].contiguous() for t in inputs)
 
@@ -249,7 +249,7 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
     ach = flops[dom] / (prof[dom][0] / 3 * 1e-3) / 1e12
     total_f64 = sum(flops.values())
     return {'arithmetic': ("fp64 (v_mfma_f64_16x16x4_f64) for the encoders, all " + str(2 * L) + ' layers, final_proj and the score matrix; fp64 Sinkhorn, the '
-                           "extraction's arg-maxes decided on the fp64 Z (csrc/sinkhorn_f64.hip)") if tail64 else
+                           "extraction's arg-maxes decided on the fp64 Z (csrc/sinkhorn_f64.hip" + ('' if n <= 575 else ': the streaming form, K in memory, one launch per iteration') + ')') if tail64 else
                           ("fp64 (v_mfma_f64_16x16x4_f64) for the encoders and layers 0.." + str(n64 - 1) + ' of ' + str(2 * L) +
                            ' (through the last dynamic layer); split-f16 kernels behind it'),
             'pairs_per_s': B / dt, 'ms_per_pair': 1e3 * dt / B, 'ms_per_step': 1e3 * dt, 'batch': B, 'steps': steps, 'windows': windows,

@@ -93,8 +93,9 @@ typedef struct {
                                           MDGAT_F64_ENCODERS_ONLY (-1): none, the encoders only */
     int32_t f64_sinkhorn;              /* MDGAT_ARITH_FP64: the tail as well - EVERY layer, final_proj, the score matrix and the optimal
                                           transport in fp64, the extraction's arg-maxes decided on the fp64 Z (csrc/sinkhorn_f64.hip).
-                                          0 (a zero-initialised config): automatic - on for frames of at most 575 keypoints (and
-                                          f64_layers == 0), else the fp32-class tail; 1: required (larger frames are refused);
+                                          0 (a zero-initialised config): automatic - on for frames of at most 2175 keypoints (and
+                                          f64_layers == 0; up to 575 the Sinkhorn holds the couplings in registers, beyond that it
+                                          streams them from memory), else the fp32-class tail; 1: required (larger frames are refused);
                                           MDGAT_F64_SINKHORN_OFF (-1): the fp32-class tail behind the last dynamic layer (rounds 5 / 6:
                                           Z good to 7e-6, an arg-max whose candidates lie closer than that may fall the other way) */
 } mdgat_config;
@@ -261,6 +262,12 @@ int mdgat_set_f64_layer_fusion(int mode);
  * 32 queries; mode < -1: back to the environment's / default.  Process-wide.  Returns the previous value. */
 int mdgat_set_f64_attention_form(int mode);
 
+/* fp64 Sinkhorn: -1 (default; MDGAT_F64_SINKHORN_FORM in the environment selects another): the register-resident kernel wherever it
+ * holds the frames (<= 575 keypoints), the streaming form beyond; 1: the streaming form at every size (tests, measurements: the two sum
+ * in different orders and agree to rounding); anything else: back to the environment's / default.  Process-wide; sizes of workspaces
+ * asked for before a change are not valid after it.  Returns the previous value. */
+int mdgat_set_f64_sinkhorn_form(int mode);
+
 /* ---- per-op entry points (unit parity; the forward uses the same kernels) ---------------------- */
 
 /* log_optimal_transport + log_sinkhorn_iterations (mdgat.py:279-308): scores [B][N][M] -> Z. */
@@ -269,7 +276,8 @@ int mdgat_sinkhorn(int B, int N, int M, const float* scores, float bin_score, in
 size_t mdgat_sinkhorn_workspace_bytes(int B, int N, int M);
 
 /* The same in fp64 - the reference's own arithmetic (mdgat.py:279-308 run in float64, test.py:193) - on fp64 scores: Z [B][N+1][M+1]
- * fp64; M <= 575.  workspace: mdgat_sinkhorn_f64_workspace_bytes, 256-byte aligned. */
+ * fp64; N, M <= 2175.  Frames of at most 575 keypoints run in one launch with the couplings held in registers; larger ones stream them
+ * from memory, one launch per iteration (csrc/sinkhorn_f64.hip).  workspace: mdgat_sinkhorn_f64_workspace_bytes, 256-byte aligned. */
 int mdgat_sinkhorn_f64(int B, int N, int M, const double* scores, double bin_score, int iters,
                        double* Z, void* workspace, size_t workspace_bytes, void* stream);
 size_t mdgat_sinkhorn_f64_workspace_bytes(int B, int N, int M);

@@ -78,6 +78,7 @@ SIGNATURES = {
     'mdgat_set_layer_split_tiles': (C.c_int, [C.c_int]),
     'mdgat_set_f64_layer_fusion': (C.c_int, [C.c_int]),
     'mdgat_set_f64_attention_form': (C.c_int, [C.c_int]),
+    'mdgat_set_f64_sinkhorn_form': (C.c_int, [C.c_int]),
     'mdgat_sinkhorn_f64': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     'mdgat_sinkhorn_f64_workspace_bytes': (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     'mdgat_sinkhorn_f64_extract': (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_double, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p,

@@ -302,6 +302,7 @@ namespace {
 struct Workspace {
     float *x, *qkv, *hid, *msg, *scores, *Z, *sk;
     double *x64, *qkv64, *hid64, *msg64;   // MDGAT_ARITH_FP64 only: the residual stream, q|k|v, hidden layer and message of the fp64 layers
+    double* scores64;                      // ... the fp64 score matrix [B][N][M]: q | k | v's room where it fits, its own beyond (frames past ~770 keypoints)
     float* sk64; size_t sk64_bytes;        // ... and the workspace of the fp64 Sinkhorn + its arg-max arrays (0: the shape is beyond that kernel)
     _Float16* qkv16;
     size_t sk_bytes;
@@ -328,6 +329,7 @@ Workspace carve(float* base, int B, int N, int M, bool f64) {
         w.msg64 = reinterpret_cast<double*>(take(R * 128 * 2));
         w.sk64_bytes = sinkhorn_f64_supported(N, M) ? sinkhorn_f64_workspace_bytes(B, N, M) + sinkhorn_f64_bests_bytes(B, N, M) : 0;
         w.sk64 = take((w.sk64_bytes + 3) / 4);
+        w.scores64 = (size_t)N * M <= (size_t)384 * (N + M) || !w.sk64_bytes ? w.qkv64 : reinterpret_cast<double*>(take((size_t)B * N * M * 2));
     }
     w.total = o;
     return w;
@@ -487,7 +489,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         // the fp32-class tail Z is good to 7e-6 - inside the bar of 1e-4, but among 40 960 arg-maxes of a reference-held batch one had
         // its two candidates 1.3e-6 apart and fell the other way (profiles/NOTES_r6.md section 11).
         if (h->cfg.f64_sinkhorn > 0 && !ws.sk64_bytes) {
-            mdgat_set_error("mdgat_forward_f64: f64_sinkhorn = 1 and %d x %d keypoints are beyond the fp64 Sinkhorn kernel (575)", N, M);
+            mdgat_set_error("mdgat_forward_f64: f64_sinkhorn = 1 and %d x %d keypoints are beyond the fp64 Sinkhorn kernels (2175)", N, M);
             return MDGAT_ERR_UNSUPPORTED;
         }
         tail64 = h->cfg.f64_sinkhorn >= 0 && ws.sk64_bytes != 0 && h->cfg.f64_layers == 0;
@@ -555,7 +557,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         if (tail64) {
             // final_proj (mdgat.py:397), the score matrix (430-431), the optimal transport (434-436) and the extraction (441-483)
             double* mdesc64 = ws.msg64;          // (the message and q | k | v of the last layer are dead)
-            double* scores64 = ws.qkv64;         // [B][N][M]: N M <= 384 (N + M) for every shape the kernel takes
+            double* scores64 = ws.scores64;      // [B][N][M]: in q | k | v's room while N M <= 384 (N + M)
             if ((rc = gemm(ws.x64, 128, 128, nullptr, 0, bl.final_w, bl.final_b, 0, nullptr, mdesc64, 128, 128, 128))) return rc;
             if (taps && taps->mdesc)
                 if ((rc = launch_f64_to_f32(mdesc64, taps->mdesc, Rz * 128, nullptr, s))) return rc;

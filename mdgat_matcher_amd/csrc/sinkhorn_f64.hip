@@ -20,6 +20,8 @@
 // the G partials of a column in slab order - the same bits in every workgroup.  Two slot sets alternate by iteration parity (a workgroup can only be two
 // iterations ahead of a partner it has not heard from).  Spins are bounded: a timeout raises the error word and the call fails.
 // The partners of a pair sit on one XCD under round-robin dispatch (blockIdx % 8), which only matters for speed.
+//
+// Frames beyond 575 keypoints (to 2175) run the STREAMING form further down: K written to memory once, one launch per iteration.
 #include "common.hpp"
 #include "f64.hpp"
 #include "sinkhorn_f64.hpp"
@@ -362,31 +364,334 @@ __global__ __launch_bounds__(256) void sinkhorn_f64_merge_kernel(const int* sidx
     }
 }
 
+
+// ---- the STREAMING form: frames beyond what the register-resident kernel holds (M + 1 > 576 or N > 576), up to 2175 keypoints ----
+// The same iteration, K = exp(Z0 - row maximum) written to memory ONCE (fp64, rows padded to 128 columns: 35.6 MB for a pair of 2048
+// keypoints) and streamed once per iteration - one launch per iteration, no workgroup waits for another inside a launch:
+//   sinkhorn_f64_wide_b_kernel:    b_j = nu_j / sum over the slabs, in slab order, of the column partials the launch before left
+//                                  (b = 1 at the start) - one thread per column, the G partials in flight at once;
+//   sinkhorn_f64_wide_iter_kernel, workgroup (pair, slab g of 32 rows):   b -> LDS;  a_N = mu_N / sum_j b_j;  every wave takes a row at a
+//   time (four of the slab's rows each, the next row's loads in flight while this one is reduced): the row's K into registers with
+//   16-byte loads, the dot product with b, one wave reduction, a_i = mu / that, and K_ij a_i joins the wave's column partials in
+//   registers;  the eight waves' partials are summed through LDS and leave as the slab's partials (the last slab adds the dustbin
+//   row's share a_N).
+// Per iteration a pair moves its K once (8 pairs of 2048: 285 MB in 50 us - 5.7 TB/s, HBM-bound; one pair: 14.5 us) and the partials
+// twice (17 KB per slab).  The partial sets alternate by iteration parity.  The last launch forms Z, the arg-max of every row and per
+// slab of every column.  (First form measured: slabs of 64 rows, every workgroup summing the partials itself in its prologue - one
+// launch per iteration, but 0.56 MB of partials per workgroup against 1.1 MB of K: 62 / 38 us per iteration for 8 pairs / one pair
+// against 55 / 19 now.)
+constexpr int W64_ROWS = 32;                                          // rows per slab (four per wave)
+constexpr int W64_GMAX = 68;                                          // slabs at most: N <= 2176
+constexpr int W64_NC2MAX = 17;                                        // column pairs per lane at most: M + 1 <= 2176
+
+struct Wk64Args {
+    const double* scores; double alpha; const double* alpha_dev;
+    int B, N, M, Mp, G, it, iters, inner;
+    double* K;                 // [B][N][Mp]
+    double* rmax;              // [B][N]
+    double* av;                // [B][N + 1]: the row scalings of the latest iteration, a_N last
+    double* P;                 // [B][2][G][Mp]: column partials per slab, by iteration parity
+    double* bvec;              // [B][Mp]: the column scalings the coming launch works with (sinkhorn_f64_wide_b_kernel)
+    double* Z64; float* Z32; int* rbest_idx; float* rbest_val; int* cslab_idx; double* cslab_val;
+};
+
+typedef double w64x2 __attribute__((ext_vector_type(2)));
+
+// one wave per row: the row maximum (over the scores and the bin score of the dustbin column), K = exp(Z0 - it), zero in the padding
+__global__ __launch_bounds__(512) void sinkhorn_f64_wide_init_kernel(Wk64Args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int blocks = (a.N + 7) / 8;
+    const int pair = blockIdx.x / blocks, row = (blockIdx.x % blocks) * 8 + wave;
+    if (row >= a.N) return;
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
+    const double* sc = a.scores + ((size_t)pair * a.N + row) * a.M;
+    double m = alpha;
+    for (int j = lane; j < a.M; j += 64) m = fmax(m, sc[j]);
+#pragma unroll
+    for (int s = 1; s < 64; s <<= 1) m = fmax(m, shfl_xor_d(m, s));
+    double* k = a.K + ((size_t)pair * a.N + row) * a.Mp;
+    for (int j = lane; j < a.Mp; j += 64) k[j] = j < a.M ? exp(sc[j] - m) : j == a.M ? exp(alpha - m) : 0.0;
+    if (lane == 0) a.rmax[(size_t)pair * a.N + row] = m;
+}
+
+// b_j = nu_j / (sum over the slabs, in slab order, of the column partials launch `it` - 1 left) for launch `it` (it = iters: for the last
+// launch); b = 1 before the first iteration, 0 in the padding.  One thread per column, the G partials in flight at once.
+__global__ __launch_bounds__(128) void sinkhorn_f64_wide_b_kernel(Wk64Args a) {
+    const int M = a.M, Mp = a.Mp, G = a.G;
+    const int per = Mp >> 7;
+    const int pair = blockIdx.x / per, j = (blockIdx.x % per) * 128 + threadIdx.x;
+    const double nm = (double)(a.N + M);
+    const double mu = 1.0 / nm, nuM = (double)a.N / nm;
+    double bv = 0.0;
+    if (j <= M) {
+        if (a.it == 0) bv = 1.0;
+        else {
+            const double* Pp = a.P + (((size_t)pair * 2 + ((a.it + 1) & 1)) * G) * Mp + j;      // what launch it - 1 wrote
+            double v[W64_GMAX];
+#pragma unroll
+            for (int q = 0; q < W64_GMAX; ++q) v[q] = q < G ? Pp[(size_t)q * Mp] : 0.0;
+            double tot = v[0];
+#pragma unroll
+            for (int q = 1; q < W64_GMAX; ++q) tot += v[q];                                       // (+ 0.0 beyond G)
+            bv = (j < M ? mu : nuM) * recip_f64(tot);
+        }
+    }
+    a.bvec[(size_t)pair * Mp + j] = bv;
+}
+
+template <int NC2>
+__global__ __launch_bounds__(512) void sinkhorn_f64_wide_iter_kernel(Wk64Args a) {
+    extern __shared__ __attribute__((aligned(16))) double w64_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, M = a.M, Mp = a.Mp, G = a.G;
+    const int nc2 = Mp >> 7;
+    double* bl = w64_lds;                          // [Mp]
+    double* colbuf = w64_lds + Mp;                 // [8][Mp]
+    const int pair = blockIdx.x / G, g = blockIdx.x % G;
+    const double nm = (double)(N + M);
+    const double mu = 1.0 / nm, muN = (double)M / nm;
+    for (int j = 2 * tid; j < Mp; j += 1024) *reinterpret_cast<w64x2*>(bl + j) = *reinterpret_cast<const w64x2*>(a.bvec + (size_t)pair * Mp + j);
+    double acc[2 * NC2];
+#pragma unroll
+    for (int c = 0; c < 2 * NC2; ++c) acc[c] = 0.0;
+    const int rbeg = g * W64_ROWS, rend = rbeg + W64_ROWS < N ? rbeg + W64_ROWS : N;
+    const double* kbase = a.K + (size_t)pair * N * Mp + 2 * lane;
+    auto fetch = [&](w64x2 (&kv)[NC2], int row) {
+        const double* k = kbase + (size_t)row * Mp;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) kv[c] = (c < nc2 && row < rend) ? *reinterpret_cast<const w64x2*>(k + 128 * c) : w64x2{0.0, 0.0};
+    };
+    auto work = [&](const w64x2 (&kv)[NC2], int row) {
+        double p = 0.0;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c)
+            if (c < nc2) {
+                const w64x2 bb = *reinterpret_cast<const w64x2*>(bl + 128 * c + 2 * lane);
+                p = __builtin_fma(kv[c].x, bb.x, p);
+                p = __builtin_fma(kv[c].y, bb.y, p);
+            }
+        const double ai = mu * recip_f64(wave_sum_f64(p));
+        if (lane == 0) a.av[(size_t)pair * (N + 1) + row] = ai;
+#pragma unroll
+        for (int c = 0; c < NC2; ++c) {
+            acc[2 * c] = __builtin_fma(kv[c].x, ai, acc[2 * c]);
+            acc[2 * c + 1] = __builtin_fma(kv[c].y, ai, acc[2 * c + 1]);
+        }
+    };
+    // a row's K is in flight while the row before it is reduced (two register sets, the loop unrolled by two)
+    w64x2 ka[NC2], kb[NC2];
+    fetch(ka, rbeg + wave);
+    __syncthreads();
+    double sb = 0.0;
+    for (int j = lane; j <= M; j += 64) sb += bl[j];
+    const double aN = muN * recip_f64(wave_sum_f64(sb));      // (the same bits in every wave of every workgroup)
+    for (int row = rbeg + wave; row < rend; row += 16) {
+        fetch(kb, row + 8);
+        work(ka, row);
+        if (row + 8 < rend) {
+            fetch(ka, row + 16);
+            work(kb, row + 8);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC2; ++c)
+        if (c < nc2) *reinterpret_cast<w64x2*>(colbuf + (size_t)wave * Mp + 128 * c + 2 * lane) = w64x2{acc[2 * c], acc[2 * c + 1]};
+    __syncthreads();
+    const bool last = g == G - 1;
+    double* mine = a.P + (((size_t)pair * 2 + (a.it & 1)) * G + g) * Mp;
+    for (int j = tid; j < Mp; j += 512) {
+        double p = colbuf[j];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) p += colbuf[(size_t)w * Mp + j];
+        if (last) p += aN;                                      // the dustbin row's share (K = 1)
+        mine[j] = p;
+    }
+    if (last && tid == 0) a.av[(size_t)pair * (N + 1) + N] = aN;
+}
+
+// Z = Z0 - r + log a + log b - norm and the arg-maxes, decided on the fp64 values (as the register-resident kernel's epilogue)
+template <int NC2>
+__global__ __launch_bounds__(512) void sinkhorn_f64_wide_final_kernel(Wk64Args a) {
+    extern __shared__ __attribute__((aligned(16))) double w64_lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int N = a.N, M = a.M, Mp = a.Mp, G = a.G;
+    const int nc2 = Mp >> 7;
+    double* bl = w64_lds;                                        // [Mp]: log b - norm
+    double* cbv = w64_lds + Mp;                                  // [Mp]: column arg-max over the slab, value ...
+    int* cbi = reinterpret_cast<int*>(cbv + Mp);                 // ... and row
+    double* zN = reinterpret_cast<double*>(cbi + Mp);            // [Mp]: the dustbin row of Z (last slab)
+    const int pair = blockIdx.x / G, g = blockIdx.x % G;
+    const double norm = -log((double)(N + M));
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
+    const double* sc = a.scores + (size_t)pair * N * M;
+    for (int j = tid; j < Mp; j += 512) {
+        bl[j] = j <= M ? log(a.bvec[(size_t)pair * Mp + j]) - norm : 0.0;
+        cbv[j] = -__builtin_inf();
+        cbi[j] = 0x7fffffff;
+    }
+    __syncthreads();
+    const int jlim = a.inner ? M : M + 1;
+    double cb[2 * NC2];
+    int ci[2 * NC2];
+#pragma unroll
+    for (int c = 0; c < 2 * NC2; ++c) { cb[c] = -__builtin_inf(); ci[c] = 0x7fffffff; }
+    const int rbeg = g * W64_ROWS, rend = rbeg + W64_ROWS < N ? rbeg + W64_ROWS : N;
+    for (int row = rbeg + wave; row < rend; row += 8) {
+        const double la = a.iters ? log(a.av[(size_t)pair * (N + 1) + row]) - a.rmax[(size_t)pair * N + row] : 0.0;      // (no iteration: u = 0)
+        double best = -__builtin_inf();
+        int bj = 0x7fffffff;
+#pragma unroll
+        for (int c = 0; c < 2 * NC2; ++c) {
+            const int j = 128 * (c >> 1) + 2 * lane + (c & 1);
+            if ((c >> 1) >= nc2 || j > M) continue;
+            const double z = (j < M ? sc[(size_t)row * M + j] : alpha) + la + bl[j];
+            if (a.Z64) a.Z64[((size_t)pair * (N + 1) + row) * (M + 1) + j] = z;
+            if (a.Z32) a.Z32[((size_t)pair * (N + 1) + row) * (M + 1) + j] = (float)z;
+            if (j < jlim && z > best) { best = z; bj = j; }            // ascending j within the lane
+            if (z > cb[c]) { cb[c] = z; ci[c] = row; }                 // ascending rows within the wave
+        }
+        if (a.rbest_idx) {
+#pragma unroll
+            for (int s = 1; s < 64; s <<= 1) {
+                const double ob = shfl_xor_d(best, s);
+                const int oj = __shfl_xor(bj, s, 64);
+                if (ob > best || (ob == best && oj < bj)) { best = ob; bj = oj; }
+            }
+            if (lane == 0) { a.rbest_idx[(size_t)pair * N + row] = bj; a.rbest_val[(size_t)pair * N + row] = (float)best; }
+        }
+    }
+    const bool last = g == G - 1;
+    if (last && wave == 0) {
+        const double laN = a.iters ? log(a.av[(size_t)pair * (N + 1) + N]) : alpha;      // (no iteration: the dustbin row is the bin score)
+        for (int j = lane; j <= M; j += 64) {
+            const double z = laN + bl[j];
+            zN[j] = z;
+            if (a.Z64) a.Z64[((size_t)pair * (N + 1) + N) * (M + 1) + j] = z;
+            if (a.Z32) a.Z32[((size_t)pair * (N + 1) + N) * (M + 1) + j] = (float)z;
+        }
+    }
+    if (a.cslab_idx) {
+        // the waves' rows interleave (row = slab start + wave + 8 t): the first of equal maxima is the one with the smaller row
+        for (int w = 0; w < 8; ++w) {
+            if (wave == w) {
+#pragma unroll
+                for (int c = 0; c < 2 * NC2; ++c) {
+                    const int j = 128 * (c >> 1) + 2 * lane + (c & 1);
+                    if ((c >> 1) >= nc2 || j >= M) continue;
+                    if (cb[c] > cbv[j] || (cb[c] == cbv[j] && ci[c] < cbi[j])) { cbv[j] = cb[c]; cbi[j] = ci[c]; }
+                }
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < M; j += 512) {
+            double bv = cbv[j];
+            int bi = cbi[j];
+            if (last && !a.inner && zN[j] > bv) { bv = zN[j]; bi = N; }
+            a.cslab_val[((size_t)pair * G + g) * M + j] = bv;
+            a.cslab_idx[((size_t)pair * G + g) * M + j] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
+}
+
 }  // namespace
 
 static size_t s64_align(size_t v) { return (v + 255) & ~(size_t)255; }
 struct S64Serial { std::mutex m; hipEvent_t ev = nullptr; bool recorded = false; };
 static size_t s64_lds_bytes(int waves) { return ((size_t)waves * S64_SLOT + S64_SLOT) * sizeof(double) + (size_t)waves * S64_SLOT * sizeof(int); }
 
-// (sized for the eight-wave form: the larger slab count)
+static bool s64_resident_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= 32 * S64_GMAX; }
+static bool s64_wide_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 128 * W64_NC2MAX && N + 1 <= 128 * W64_NC2MAX; }
+
+// -1 (default): the register-resident kernel wherever it holds the shape, the streaming form beyond; 1: always the streaming form (tests
+// and measurements: the two agree to rounding, not bit for bit - other summation orders).  MDGAT_F64_SINKHORN_FORM in the environment.
+static std::atomic<int> g_s64_form{-2};
+static int s64_form() {
+    const int v = g_s64_form.load(std::memory_order_relaxed);
+    if (v != -2) return v;
+    static const int env = [] { const char* e = getenv("MDGAT_F64_SINKHORN_FORM"); return e && atoi(e) == 1 ? 1 : -1; }();
+    return env;
+}
+extern "C" int mdgat_set_f64_sinkhorn_form(int mode) {
+    const int prev = s64_form();
+    g_s64_form.store(mode == 1 ? 1 : mode == -1 ? -1 : -2, std::memory_order_relaxed);
+    return prev;
+}
+static bool s64_use_wide(int N, int M) { return !s64_resident_supported(N, M) || (s64_form() == 1 && s64_wide_supported(N, M)); }
+
+static size_t s64_wide_bytes(int B, int N, int M) {
+    const size_t Mp = ((size_t)M + 1 + 127) & ~(size_t)127, G = ((size_t)N + W64_ROWS - 1) / W64_ROWS;
+    return s64_align((size_t)B * N * Mp * sizeof(double)) + s64_align((size_t)B * N * sizeof(double)) + s64_align((size_t)B * (N + 1) * sizeof(double)) +
+           s64_align((size_t)B * 2 * G * Mp * sizeof(double)) + s64_align((size_t)B * Mp * sizeof(double)) + s64_align((size_t)B * G * M * sizeof(double)) + s64_align((size_t)B * G * M * sizeof(int));
+}
+
+// (the register-resident form sized for the eight-wave workgroups: the larger slab count)
 size_t sinkhorn_f64_workspace_bytes(int B, int N, int M) {
     if (B <= 0) return 0;
+    if (s64_use_wide(N, M)) return s64_wide_bytes(B, N, M);
     const size_t G = (N + 31) / 32;
     return s64_align((size_t)B * 2 * G * S64_SLOT * sizeof(double)) + s64_align((size_t)B * 3 * G * sizeof(unsigned)) +
            s64_align((size_t)B * G * M * sizeof(double)) + s64_align((size_t)B * G * M * sizeof(int));
 }
 
-bool sinkhorn_f64_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= 32 * S64_GMAX; }
+bool sinkhorn_f64_supported(int N, int M) { return s64_resident_supported(N, M) || s64_wide_supported(N, M); }
+
+template <int NC2>
+static int s64_wide_launches(const Wk64Args& a0, hipStream_t s) {
+    Wk64Args a = a0;
+    const size_t lds_it = (size_t)9 * a.Mp * sizeof(double), lds_fin = (size_t)a.Mp * (3 * sizeof(double) + sizeof(int));
+    static std::atomic<unsigned long long> optin_it{0}, optin_fin{0};
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_wide_iter_kernel<NC2>), lds_it, optin_it, "sinkhorn_f64 (streaming) LDS")) return rc;
+    if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_wide_final_kernel<NC2>), lds_fin, optin_fin, "sinkhorn_f64 (streaming, last) LDS")) return rc;
+    hipLaunchKernelGGL(sinkhorn_f64_wide_init_kernel, dim3((unsigned)(a.B * ((a.N + 7) / 8))), dim3(512), 0, s, a);
+    for (int it = 0; it <= a.iters; ++it) {
+        a.it = it;
+        hipLaunchKernelGGL(sinkhorn_f64_wide_b_kernel, dim3((unsigned)(a.B * (a.Mp >> 7))), dim3(128), 0, s, a);
+        if (it < a.iters) hipLaunchKernelGGL(sinkhorn_f64_wide_iter_kernel<NC2>, dim3((unsigned)(a.B * a.G)), dim3(512), lds_it, s, a);
+    }
+    hipLaunchKernelGGL(sinkhorn_f64_wide_final_kernel<NC2>, dim3((unsigned)(a.B * a.G)), dim3(512), lds_fin, s, a);
+    return mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 (streaming) launch");
+}
+
+static int launch_sinkhorn_f64_wide(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
+                                    float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, hipStream_t s, const double* alpha_dev) {
+    Wk64Args a{};
+    a.scores = scores; a.alpha = alpha; a.alpha_dev = alpha_dev; a.B = B; a.N = N; a.M = M; a.iters = iters; a.inner = inner;
+    a.Mp = (M + 1 + 127) & ~127; a.G = (N + W64_ROWS - 1) / W64_ROWS;
+    a.Z64 = Z64; a.Z32 = Z32; a.rbest_idx = rbest_idx; a.rbest_val = rbest_val;
+    char* w = static_cast<char*>(workspace);
+    a.K = reinterpret_cast<double*>(w); w += s64_align((size_t)B * N * a.Mp * sizeof(double));
+    a.rmax = reinterpret_cast<double*>(w); w += s64_align((size_t)B * N * sizeof(double));
+    a.av = reinterpret_cast<double*>(w); w += s64_align((size_t)B * (N + 1) * sizeof(double));
+    a.P = reinterpret_cast<double*>(w); w += s64_align((size_t)B * 2 * a.G * a.Mp * sizeof(double));
+    a.bvec = reinterpret_cast<double*>(w); w += s64_align((size_t)B * a.Mp * sizeof(double));
+    double* sval = reinterpret_cast<double*>(w); w += s64_align((size_t)B * a.G * M * sizeof(double));
+    int* sidx = reinterpret_cast<int*>(w);
+    a.cslab_idx = cbest_idx ? sidx : nullptr; a.cslab_val = cbest_idx ? sval : nullptr;
+    const int nc2 = a.Mp >> 7;
+    int rc = nc2 <= 5 ? s64_wide_launches<5>(a, s) : nc2 <= 9 ? s64_wide_launches<9>(a, s) : s64_wide_launches<W64_NC2MAX>(a, s);
+    if (rc) return rc;
+    if (cbest_idx) {
+        const size_t total = (size_t)B * M;
+        hipLaunchKernelGGL(sinkhorn_f64_merge_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, sidx, sval, B, a.G, M,
+                           cbest_idx, cbest_val);
+        if (int rc2 = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 merge launch")) return rc2;
+    }
+    return MDGAT_OK;
+}
 
 int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha, int iters, double* Z64, float* Z32, int inner, int* rbest_idx,
                         float* rbest_val, int* cbest_idx, float* cbest_val, void* workspace, size_t workspace_bytes, unsigned* error_word,
                         hipStream_t s, const double* alpha_dev) {
     if (B <= 0) return MDGAT_OK;
-    if (!sinkhorn_f64_supported(N, M)) { mdgat_set_error("fp64 Sinkhorn: %d x %d keypoints > %d supported", N, M, 64 * S64_NC - 1); return MDGAT_ERR_UNSUPPORTED; }
+    if (!sinkhorn_f64_supported(N, M)) { mdgat_set_error("fp64 Sinkhorn: %d x %d keypoints > %d supported", N, M, 128 * W64_NC2MAX - 1); return MDGAT_ERR_UNSUPPORTED; }
     if (!workspace || workspace_bytes < sinkhorn_f64_workspace_bytes(B, N, M) || (reinterpret_cast<uintptr_t>(workspace) & 255)) {
         mdgat_set_error("fp64 Sinkhorn: workspace too small or not 256-byte aligned");
         return MDGAT_ERR_BAD_ARG;
     }
+    if (s64_use_wide(N, M))
+        return launch_sinkhorn_f64_wide(B, N, M, scores, alpha, iters, Z64, Z32, inner, rbest_idx, rbest_val, cbest_idx, cbest_val, workspace, s, alpha_dev);
     // Eight-wave workgroups at every launch size.  Sixteen-wave ones (64 rows, half the partners, one per CU) were 7 % faster once the
     // launch no longer gives every workgroup a CU (32 pairs of 512: 818 against 878 us per 100 iterations; one pair 602 against 432) -
     // at 128 registers with spills, a second grouping of the column sums (so results that depend on the batch a pair travels in), and a

@@ -12,9 +12,9 @@ Host-side mirror of ``/root/reference/models/mdgat.py:315-603`` (class ``MDGAT``
 * the module's dtype is the arithmetic request, as it is in the reference: ``net.double()`` (what ``test.py:193`` and
   ``test_registration_metric.py:194`` call before every forward) runs the library's reference-exact mode - fp64 inputs,
   fp64 weights and fp64 matrix-core arithmetic, so that every ``logits.topk(k)`` (``mdgat.py:202``) selects what the
-  reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``) and, for frames of at most 575 keypoints,
-  an fp64 Sinkhorn whose arg-maxes are the reference's (``config['sinkhorn_arithmetic']``; beyond that fp64 runs through
-  the last dynamic layer and Z is within 1e-4); a float32 module runs the fp32-class throughput path (5x the rate, Z within
+  reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``) and an fp64 Sinkhorn whose arg-maxes
+  are the reference's (``config['sinkhorn_arithmetic']``; frames beyond 2175 keypoints: fp64 through the last dynamic
+  layer, Z within 1e-4); a float32 module runs the fp32-class throughput path (5x the rate, Z within
   1e-4 except around the ~1.5 keypoints per pair whose top-k near-tie falls the other way).  ``config['arithmetic']`` =
   ``'fp32'`` / ``'fp64'`` (not a reference key) or ``MDGAT_ARITHMETIC`` in the environment pin one path whatever the dtype;
   results are cast to the module's dtype either way.
@@ -174,7 +174,8 @@ class MDGAT(nn.Module):
         self.f64_layers = None if f64_layers is None or int(f64_layers) < 0 else int(f64_layers)
         # 'sinkhorn_arithmetic' (optional; MDGAT_SINKHORN_ARITHMETIC in the environment): the exact mode's TAIL - every layer, final_proj,
         # the score matrix and the optimal transport in fp64, every arg-max of the extraction decided on the fp64 Z (csrc/sinkhorn_f64.hip).
-        #   'auto' (default): on for frames of at most 575 keypoints, else the fp32-class tail behind the last dynamic layer;
+        #   'auto' (default): on for frames of at most 2175 keypoints (beyond 575 the Sinkhorn streams its couplings from memory, one launch
+        #   per iteration), else the fp32-class tail behind the last dynamic layer;
         #   'fp64': required (larger frames are refused);  'fp32': the fp32-class tail (Z good to 7e-6: inside the bar of 1e-4, but an
         #   arg-max whose two candidates lie closer than that may fall the other way - one in 40 960 on a reference-held batch).
         self.sinkhorn_arithmetic = str(self.config.get('sinkhorn_arithmetic') or os.environ.get('MDGAT_SINKHORN_ARITHMETIC') or 'auto')

@@ -14,7 +14,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from mdgat_matcher_amd import MDGAT, ops, synth  # noqa: E402
+from mdgat_matcher_amd import MDGAT, _lib, ops, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
 
 DEV = 'cuda:0'
@@ -169,12 +169,43 @@ def _build(g, **cfg_over):
 
 @pytest.mark.parametrize('B,N,M,iters,alpha,scale', [(1, 7, 5, 20, 1.0, 3.0), (2, 64, 64, 100, 0.37, 3.0), (2, 48, 64, 50, 1.0, 3.0), (3, 512, 512, 100, 1.0, 3.0),
                                                      (2, 400, 512, 100, 1.0, 6.0), (1, 100, 31, 10, 2.0, 1.0), (9, 256, 256, 20, 1.0, 3.0), (1, 1, 1, 5, 1.0, 1.0),
-                                                     (2, 575, 33, 30, 1.0, 2.0), (1, 33, 575, 30, 0.5, 10.0)])
+                                                     (2, 575, 33, 30, 1.0, 2.0), (1, 33, 575, 30, 0.5, 10.0),
+                                                     # beyond 575 keypoints: the streaming form (K in memory, one launch per iteration)
+                                                     (2, 600, 700, 100, 1.0, 3.0), (1, 577, 30, 50, 1.0, 3.0), (2, 30, 1200, 50, 1.0, 3.0),
+                                                     (1, 2048, 2048, 200, 1.0, 3.0), (1, 1500, 2000, 100, 0.5, 6.0), (2, 2175, 2175, 3, 1.0, 3.0)])
 def test_sinkhorn_f64(B, N, M, iters, alpha, scale):
     """csrc/sinkhorn_f64.hip (log_optimal_transport in the reference's own arithmetic, mdgat.py:279-308 run in float64) against the
     oracle: Z to 1e-12, and the match extraction of all four branches - every arg-max decided on the fp64 Z inside the kernel - equal to
     the extraction of the oracle's Z."""
     _sinkhorn_f64_case(B, N, M, iters, alpha, scale)
+
+
+@pytest.mark.parametrize('B,N,M,iters,alpha,scale', [(1, 7, 5, 20, 1.0, 3.0), (2, 64, 64, 100, 0.37, 3.0), (2, 48, 64, 50, 1.0, 3.0), (3, 512, 512, 100, 1.0, 3.0),
+                                                     (2, 400, 512, 100, 1.0, 6.0), (2, 65, 129, 0, 1.0, 3.0), (1, 1, 1, 5, 1.0, 1.0), (1, 33, 575, 30, 0.5, 10.0)])
+def test_sinkhorn_f64_streaming_form_on_small_frames(B, N, M, iters, alpha, scale):
+    """mdgat_set_f64_sinkhorn_form(1): the streaming form on frames the register-resident kernel holds - against the oracle like the
+    default, and against the resident kernel: equal to rounding (other summation orders), the extraction identical."""
+    lib = _lib.load()
+    rs = np.random.RandomState(N + 3 * M + iters)
+    s = torch.from_numpy(rs.standard_normal((B, N, M)) * scale).to(DEV)
+    res = ops.sinkhorn_f64(s, alpha, iters)
+    res_m = ops.sinkhorn_f64_extract(s, alpha, iters)
+    prev = lib.mdgat_set_f64_sinkhorn_form(1)
+    try:
+        _sinkhorn_f64_case(B, N, M, iters, alpha, scale)
+        wide = ops.sinkhorn_f64(s, alpha, iters)
+        wide_m = ops.sinkhorn_f64_extract(s, alpha, iters)
+    finally:
+        lib.mdgat_set_f64_sinkhorn_form(prev)
+    assert (wide - res).abs().max().item() < 1e-12
+    assert all(torch.equal(a, b) for a, b in zip(wide_m[:2], res_m[:2])) and all((a - b).abs().max().item() < 1e-6 for a, b in zip(wide_m[2:], res_m[2:]))
+
+
+def test_sinkhorn_f64_refuses_frames_beyond_its_kernels():
+    with pytest.raises(RuntimeError, match='supported'):
+        ops.sinkhorn_f64(torch.zeros(1, 8, 2176, dtype=torch.float64, device=DEV), 1.0, 2)
+    with pytest.raises(RuntimeError, match='supported'):
+        ops.sinkhorn_f64(torch.zeros(1, 2176, 8, dtype=torch.float64, device=DEV), 1.0, 2)
 
 
 def _sinkhorn_f64_case(B, N, M, iters, alpha, scale):
@@ -295,7 +326,8 @@ def test_literal_bar_on_every_reference_held_pair(golden_dir, name):
     bad = sum(r['bad_count'] for reps in cap.get('topk_report', {}).values() for r in reps)
     print(f'[parity-f64] {name}: top-k rows differing from the fp64 selection: {rows}; full Z max|d| {np.abs(Zc - cap["Z"].numpy()).max():.2e}')
     assert rows == 0 and bad == 0
-    assert np.abs(Zc - cap['Z'].numpy()).max() < Z_TOL
+    # the tail is fp64 at every size (beyond 575 keypoints the streaming fp64 Sinkhorn): Z is the fp32 rounding of an fp64 Z
+    assert np.abs(Zc - cap['Z'].numpy()).max() < 1.2e-7 * max(1.0, np.abs(cap['Z'].numpy()).max())
     assert torch.equal(m0.cpu(), ref['matches0']) and torch.equal(m1.cpu(), ref['matches1'])
     # the untapped kernels (what ships) give the same bits
     plain = net._run(dev['keypoints0'], dev['scores0'], dev['descriptors0'], dev['keypoints1'], dev['scores1'], dev['descriptors1'], want_Z=True)
@@ -387,8 +419,8 @@ def test_f64_tail_applies_the_batch_wide_dustbin_rule(B):
 
 
 def test_sinkhorn_arithmetic_key():
-    """config['sinkhorn_arithmetic']: 'fp64' refuses frames beyond the fp64 Sinkhorn kernel (575 keypoints), 'auto' falls back to the
-    fp32-class tail there, 'fp32' always takes it; the three agree on the matches of an ordinary pair."""
+    """config['sinkhorn_arithmetic']: 'auto' and 'fp64' are the fp64 tail (frames beyond 575 keypoints: the streaming form of the fp64
+    Sinkhorn), 'fp32' the fp32-class one; the three agree on the matches of an ordinary pair, the first two bit for bit."""
     L = 1
     sd = synth.make_state_dict(L=L, seed=4)
     outs = {}
@@ -401,14 +433,12 @@ def test_sinkhorn_arithmetic_key():
         net.check(DEV)
         big = synth.make_batch(1, 600, 600, device=DEV)
         args = (big['keypoints0'], big['descriptors0'], big['keypoints1'], big['descriptors1'], big['scores0'], big['scores1'])
-        if tail == 'fp64':
-            with pytest.raises(RuntimeError, match='beyond the fp64 Sinkhorn'):
-                net.match(*args)
-        else:
-            net.match(*args)
-            net.check(DEV)
-    assert torch.equal(outs['auto'][0], outs['fp64'][0]) and torch.equal(outs['auto'][4], outs['fp64'][4])
-    assert torch.equal(outs['auto'][0], outs['fp32'][0]) and (outs['auto'][4] - outs['fp32'][4]).abs().max().item() < 2e-5
+        outs[tail + '_big'] = net.match(*args, return_scores=True)
+        net.check(DEV)
+    for sfx in ('', '_big'):
+        assert torch.equal(outs['auto' + sfx][0], outs['fp64' + sfx][0]) and torch.equal(outs['auto' + sfx][4], outs['fp64' + sfx][4])
+        assert (outs['auto' + sfx][4] - outs['fp32' + sfx][4]).abs().max().item() < 2e-5
+    assert torch.equal(outs['auto'][0], outs['fp32'][0])
     with pytest.raises(ValueError):
         MDGAT(synth.default_config(L=1, sinkhorn_arithmetic='bf16'))
 
