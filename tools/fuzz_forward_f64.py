@@ -1,7 +1,7 @@
 """Randomised shapes / configurations through the whole forward in the REFERENCE-EXACT mode (arithmetic='fp64') against the
 UNFORCED fp64 oracle (GPU box):
     python tools/fuzz_forward_f64.py [seconds] [seed]
-Every case: B, N, M, L, Sinkhorn iterations, top-k schedule, extraction mode, bin score drawn at random (frames up to 700
+Every case: B, N, M, L, Sinkhorn iterations, top-k schedule, extraction mode, bin score drawn at random (frames up to 900
 keypoints, not multiples of anything).  The bar is the literal one - no attribution of top-k flips, because there are none:
 max|dZ| < 1e-4 against the oracle's own run, the kept keys of every dynamic layer equal to the oracle's (zero rows in its report
 when the library's selections are fed back), matches = the extraction rules applied to the library's own Z, and identical to the
@@ -22,7 +22,7 @@ from mdgat_matcher_amd import MDGAT, synth  # noqa: E402
 from oracle import mdgat_oracle as O  # noqa: E402
 from parity_util import hip_forward_with_selection  # noqa: E402
 
-SIZES = [1, 7, 31, 64, 100, 128, 129, 200, 256, 300, 512, 513, 700]
+SIZES = [1, 7, 31, 64, 100, 128, 129, 200, 256, 300, 512, 513, 577, 700, 900]
 MODES = [('triplet_loss', False), ('triplet_loss', True), ('superglue', False), ('superglue', True)]
 
 
