@@ -418,6 +418,44 @@ def test_f64_tail_applies_the_batch_wide_dustbin_rule(B):
     assert out['matching_scores0'].dtype == torch.int64 and (out['matching_scores0'] == 0).all() and (out['matching_scores1'] == 0).all()
 
 
+@pytest.mark.parametrize('B,n', [(3, 300), (2, 600)])
+def test_exact_mode_forward_is_capturable_as_a_hip_graph(B, n):
+    """The exact mode under stream capture (torch.cuda.CUDAGraph = hipGraph): the register-resident fp64 Sinkhorn (300 keypoints; its
+    launcher's one-launch-at-a-time chaining stands aside for a capturing stream) and the streaming form (600 keypoints: 2 S + 3
+    launches, nothing waits inside a launch).  The replay gives the bits of the eager call, also after the inputs changed in place."""
+    cfg = synth.default_config(L=2, k=[64, None, 32, None], sinkhorn_iterations=12)
+    net = MDGAT(cfg).double()
+    net.load_state_dict(synth.make_state_dict(L=2, seed=5))
+    net = net.eval().to(DEV)
+    assert net.exact()
+    keys = ('keypoints0', 'scores0', 'descriptors0', 'keypoints1', 'scores1', 'descriptors1')
+    d = synth.make_batch(B, n, n - 7, device=DEV, dtype=torch.float64)
+    other = synth.make_batch(B, n, n - 7, first_pair=300, device=DEV, dtype=torch.float64)
+    inputs = tuple(d[k] for k in keys)
+    with torch.no_grad():
+        eager = [t.clone() for t in net._run(*inputs, want_Z=True)]
+        eager_other = [t.clone() for t in net._run(*(other[k] for k in keys), want_Z=True)]
+        side = torch.cuda.Stream(DEV)
+        side.wait_stream(torch.cuda.current_stream(DEV))
+        with torch.cuda.stream(side):
+            net._run(*inputs, want_Z=True)
+        torch.cuda.current_stream(DEV).wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = net._run(*inputs, want_Z=True)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(eager, out))
+        for k, t in zip(keys, inputs):
+            t.copy_(other[k])
+        graph.replay()
+        torch.cuda.synchronize()
+        assert all(torch.equal(a, b) for a, b in zip(eager_other, out))
+        assert not all(torch.equal(a, b) for a, b in zip(eager, eager_other))
+    net.check(DEV)
+
+
 def test_sinkhorn_arithmetic_key():
     """config['sinkhorn_arithmetic']: 'auto' and 'fp64' are the fp64 tail (frames beyond 575 keypoints: the streaming form of the fp64
     Sinkhorn), 'fp32' the fp32-class one; the three agree on the matches of an ordinary pair, the first two bit for bit."""
