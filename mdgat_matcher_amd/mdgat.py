@@ -13,8 +13,7 @@ Host-side mirror of ``/root/reference/models/mdgat.py:315-603`` (class ``MDGAT``
   ``test_registration_metric.py:194`` call before every forward) runs the library's reference-exact mode - fp64 inputs,
   fp64 weights and fp64 matrix-core arithmetic, so that every ``logits.topk(k)`` (``mdgat.py:202``) selects what the
   reference's fp64 run selects (``include/mdgat_hip.h``: ``MDGAT_ARITH_FP64``) and an fp64 Sinkhorn whose arg-maxes
-  are the reference's (``config['sinkhorn_arithmetic']``; frames beyond 2175 keypoints: fp64 through the last dynamic
-  layer, Z within 1e-4); a float32 module runs the fp32-class throughput path (5x the rate, Z within
+  are the reference's (``config['sinkhorn_arithmetic']``) at every frame size the library takes; a float32 module runs the fp32-class throughput path (5x the rate, Z within
   1e-4 except around the ~1.5 keypoints per pair whose top-k near-tie falls the other way).  ``config['arithmetic']`` =
   ``'fp32'`` / ``'fp64'`` (not a reference key) or ``MDGAT_ARITHMETIC`` in the environment pin one path whatever the dtype;
   results are cast to the module's dtype either way.
