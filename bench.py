@@ -675,7 +675,7 @@ def main():
                 print(f'[bench] {e}', file=sys.stderr, flush=True)
                 out['status']['range_violation'] = True
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(n, L, S, max_pairs=64 if n <= 512 else 4)
+            out["cpu_baseline"] = cpu_baseline(n, L, S, max_pairs=128 if n <= 512 else 4)
         print(json.dumps(out), flush=True)
     shard.finalize(world)
 
