@@ -241,6 +241,12 @@ def exact_mode_block(dev, B, n, L, S, steps=6, windows=3):
         row = {'kernel': name, 'launches_per_step': launches // 3, 'step_ms': round(tms / 3, 3)}
         if name in flops and tms > 0:
             row['algorithmic_tflops'] = round(flops[name] / (tms / 3 * 1e-3) / 1e12, 1)
+        if name == 'sinkhorn' and tail64 and n > 575 and tms > 0:
+            # the streaming fp64 Sinkhorn reads its couplings once per iteration: 8 N (M + 1) bytes per pair; the class's
+            # time also holds its init / last launch, the per-iteration b launches, the arg-max merge and the extraction
+            gbs = B * 8.0 * n * (n + 1) * S / (tms / 3 * 1e-3) / 1e9
+            row['hbm'] = {'bound': 'hbm', 'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s', 'frac': round(gbs / PEAK_HBM_GBS, 3),
+                          'note': 'algorithmic bytes 8 N (M + 1) S per pair over the whole Sinkhorn class of the step'}
         kernels.append(row)
     f64_ms = sum(prof[k][0] for k in flops) / 3
     dom = max(flops, key=lambda k: prof[k][0])
