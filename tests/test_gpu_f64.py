@@ -418,11 +418,12 @@ def test_f64_tail_applies_the_batch_wide_dustbin_rule(B):
     assert out['matching_scores0'].dtype == torch.int64 and (out['matching_scores0'] == 0).all() and (out['matching_scores1'] == 0).all()
 
 
-@pytest.mark.parametrize('B,n', [(3, 300), (2, 600)])
+@pytest.mark.parametrize('B,n', [(3, 300), (2, 600), (40, 512)])
 def test_exact_mode_forward_is_capturable_as_a_hip_graph(B, n):
     """The exact mode under stream capture (torch.cuda.CUDAGraph = hipGraph): the register-resident fp64 Sinkhorn (300 keypoints; its
     launcher's one-launch-at-a-time chaining stands aside for a capturing stream) and the streaming form (600 keypoints: 2 S + 3
-    launches, nothing waits inside a launch).  The replay gives the bits of the eager call, also after the inputs changed in place."""
+    launches, nothing waits inside a launch); 40 pairs of 512: two lanes, a resident Sinkhorn launch on each, side by side in the graph.
+    The replay gives the bits of the eager call, also after the inputs changed in place."""
     cfg = synth.default_config(L=2, k=[64, None, 32, None], sinkhorn_iterations=12)
     net = MDGAT(cfg).double()
     net.load_state_dict(synth.make_state_dict(L=2, seed=5))
