@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "f64.hpp"
 #include "sinkhorn_f64.hpp"
+#include "coop_chain.hpp"
 
 // ---------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = "";
@@ -464,6 +465,9 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
         // ---- MDGAT_ARITH_FP64 (f64.hip): encoders and the layers up to the last dynamic one in the reference's arithmetic ----
         const double* w64 = h->weights64;
         const size_t Rz = (size_t)R;
+        // (the forward's launches of kernels whose workgroups wait for each other - clustered layer tails, the resident fp64 Sinkhorn - as
+        // one group of the device's chain: coop_chain.hpp)
+        CoopGroup coop_group(h->device, s, true);
         auto gemm = [&](const double* A0, int lda0, int K0, const double* A1, int lda1, size_t wofs, size_t bofs, int relu, const double* Rs, double* C, int ldc,
                         int cout, int K) {
             GemmF64Args g{A0, lda0, K0, A1, lda1, w64 + wofs, K, w64 + bofs, Rs, ldc, C, ldc, R, cout, K, relu, status_dev + MDGAT_STATUS_RANGE};
@@ -543,7 +547,7 @@ static int forward_impl(mdgat_handle* h, int B, int N, int M, const FwdIn& in,
                 const bool last = i + 1 == first;
                 const LayerF64Args t{ws.x64, ws.msg64, lf + WF64_W1, w64 + lo + bl.mlp1_b, lf + WF64_W2, w64 + lo + bl.mlp2_b,
                                      last ? nullptr : lf + layer_f64_frag_doubles() + WF64_QKV, last ? nullptr : w64 + lo + bl.layer_stride + bl.qkv_b,
-                                     ws.qkv64, last ? ws.x : nullptr, R, status_dev + MDGAT_STATUS_RANGE};
+                                     ws.qkv64, last ? ws.x : nullptr, R, status_dev + MDGAT_STATUS_RANGE, ws.hid64};
                 if ((rc = launch_layer_tail_f64(t, s))) return rc;
                 handed_over = last;
             } else {

@@ -59,6 +59,7 @@ struct LayerF64Args {
     float* x32;                // optional: the new x rounded to fp32 as well (the hand-over to the fp32-class layers)
     int R;
     unsigned* guard;           // as GemmF64Args::guard
+    double* hid = nullptr;     // optional scratch [R][256]: with it, launches of few 16-row blocks may run the clustered kernel (layer_f64.hip)
 };
 int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s);
 // both encoders, their sum and layer 0's q | k | v as one launch (mdgat.py:184-188, 152-155, 392-393, 227-232); weights in fragment order

@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "f64.hpp"
 #include "f64_dev.hpp"
+#include "coop_chain.hpp"
 
 namespace {
 
@@ -325,6 +326,199 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
     if (bad) f64_raise(a.guard);
 }
 
+// ---- launches of at most a quarter of the CUs in 16-row blocks (one pair per call, test.py:132): a block is shared by a CLUSTER ----
+// The kernel above gives a 16-row block to one workgroup: one pair of 512 keypoints is 64 workgroups on 256 CUs, each with the
+// block's whole chain of 2 304 matrix instructions (15 us of matrix pipe alone; 26 us per launch, 18 launches: 40 % of the forward).
+// Here FOUR workgroups (ranks) share the block and split the OUTPUT CHANNELS of every product between them - a quarter of the
+// chain each, one channel block per wave (4 + 2 + 6 waves busy) - and exchange the hidden layer and the new x through memory:
+// every rank stores its channels (plain stores when the four sit on one XCD - they do under round-robin dispatch, blockIdx % 8,
+// checked per launch through the ranks' XCC ids - they stay in that L2; write-through otherwise), waits for them to be acknowledged,
+// raises its flag, polls its partners' flags and fetches their channels with L1-bypassing loads.  Same operand roles, same order over
+// k, every channel block by exactly one wave: BIT-IDENTICAL to the kernel above (and to the three-launch form).
+// Flags: 64-bit words in a buffer the library owns per device, set to the launch's number (CoopChain::epoch) - nothing to clear per
+// launch; launches of waiting kernels are chained one at a time per device (coop_chain.hpp), graph capture takes the kernel above.
+constexpr int LC_RANKS = 4;
+constexpr int LC_WORDS = 4;             // per rank: XCC id word | hidden-layer flag | x flag | pad
+
+__device__ __forceinline__ bool lc_wait(const unsigned long long* f, unsigned long long want) {
+    long spins = 0;
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want)
+        if (++spins > (1L << 22)) return false;
+    return true;
+}
+
+// one channel block of a product with ALL its weights requested at once (a wave of the clustered kernel has one block and registers
+// to spare: JP loads of 1 KB in flight instead of four - at four the product runs at the L2's latency, 175 ns a pair of k-steps
+// against 53 ns of matrix pipe); the same order over k as lf_product
+template <int JP>
+__device__ __forceinline__ void lc_load_all(const double* wf, int lane, f64x2 (&w)[JP]) {
+    const f64x2* wp = reinterpret_cast<const f64x2*>(wf) + lane;
+#pragma unroll
+    for (int jp = 0; jp < JP; ++jp) w[jp] = wp[(size_t)jp * 64];
+}
+template <int JP>
+__device__ __forceinline__ void lc_product(const double* As, int lane, f64x4& acc, const f64x2 (&w)[JP]) {
+    const double* ap = As + (lane & 15) * LF_LD + (lane >> 4);
+#pragma unroll
+    for (int jp = 0; jp < JP; ++jp) {
+        acc = mfma64(ap[8 * jp], w[jp][0], acc);
+        acc = mfma64(ap[8 * jp + 4], w[jp][1], acc);
+    }
+}
+
+__global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_cluster_kernel(LayerF64Args a, unsigned long long* flags, unsigned long long epoch) {
+    extern __shared__ __attribute__((aligned(16))) double lfs[];      // [16][LF_LD]
+    __shared__ int lc_same, lc_dead;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l15 = lane & 15, g = lane >> 4;
+    // blockIdx = (cluster / 8) * 32 + rank * 8 + cluster % 8: the four ranks of a cluster share blockIdx % 8
+    const int cl = (blockIdx.x >> 5) * 8 + (blockIdx.x & 7), rank = (blockIdx.x >> 3) & 3;
+    const int row0 = cl * 16;
+    if (row0 >= a.R) return;                                          // (all four ranks)
+    unsigned long long* fl = flags + (size_t)cl * LC_RANKS * LC_WORDS;
+    bool bad = false;
+    if (tid == 0) {
+        lc_dead = 0;
+        const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf;      // HW_REG_XCC_ID[3:0]
+        __hip_atomic_store(fl + rank * LC_WORDS, (epoch << 8) | (xcc + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    f64x2 w1[32], w2[32], w3[16];
+    if (wave < 4) lc_load_all<32>(a.w1f + (size_t)(4 * rank + wave) * 32 * 128, lane, w1);
+    for (int e = tid; e < 16 * 128; e += 64 * LF_WAVES) {
+        const int r = e >> 7, c = (e & 127) * 2;
+        const int row = min(row0 + r, a.R - 1);
+        const double* src = c < 128 ? a.x + (size_t)row * 128 + c : a.msg + (size_t)row * 128 + (c - 128);
+        *reinterpret_cast<f64x2*>(lfs + r * LF_LD + c) = *reinterpret_cast<const f64x2*>(src);
+    }
+    __syncthreads();
+
+    // ---- hid = ReLU(W1 [x ; msg] + b1): channel blocks 4 rank .. 4 rank + 3, one per wave; an idle wave compares the ranks' XCDs ----
+    f64x4 acc = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (wave < 4) lc_product<32>(lfs, lane, acc, w1);
+    else if (wave == 7) {
+        bool same = true;
+        if (lane < LC_RANKS && lane != rank) {
+            const unsigned long long mine = (epoch << 8) | ((__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xf) + 1u);
+            if (!lc_wait(fl + lane * LC_WORDS, epoch << 8)) lc_dead = 1;
+            same = __hip_atomic_load(fl + lane * LC_WORDS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine;
+        }
+        const bool all_same = !__any(!same);
+        if (lane == 0) lc_same = all_same;
+    }
+    __syncthreads();                            // every wave has read the tile: the hidden layer takes its place
+    const bool same_xcd = lc_same != 0;
+    auto publish = [&](double* p, double v) {
+        if (same_xcd) *p = v;
+        else __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+    if (wave < 4) {
+        const int n = (4 * rank + wave) * 16 + l15;
+        const double bias = a.b1[n];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            double v = acc[i] + bias;
+            bad |= f64_out_of_range(v);
+            v = v > 0.0 ? v : 0.0;
+            const int r = g + 4 * i;
+            lfs[r * LF_LD + n] = v;
+            if (row0 + r < a.R) publish(a.hid + (size_t)(row0 + r) * 256 + n, v);
+        }
+    }
+    // the exchange: stores acknowledged (then the next product's weights are requested: they travel under the exchange), the
+    // workgroup's flag, the partners' flags
+    auto exchange = [&](int word) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (word == 1) { if (wave < 2) lc_load_all<32>(a.w2f + (size_t)(2 * rank + wave) * 32 * 128, lane, w2); }
+        else if (wave < 6) lc_load_all<16>(a.w3f + (size_t)(6 * rank + wave) * 16 * 128, lane, w3);
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fl + rank * LC_WORDS + word, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < LC_RANKS && tid != rank)
+            if (!lc_wait(fl + tid * LC_WORDS + word, epoch)) lc_dead = 1;
+        __syncthreads();
+    };
+    exchange(1);
+    {   // the partners' 3 x 64 hidden channels of the 16 rows: six doubles per thread, all in flight
+        double v[6];
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int e = tid + 512 * t, r = e / 192, q = e - r * 192;
+            const int p = q >> 6, pr = p + (p >= rank);
+            v[t] = __hip_atomic_load(a.hid + (size_t)min(row0 + r, a.R - 1) * 256 + pr * 64 + (q & 63), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int t = 0; t < 6; ++t) {
+            const int e = tid + 512 * t, r = e / 192, q = e - r * 192;
+            const int p = q >> 6, pr = p + (p >= rank);
+            lfs[r * LF_LD + pr * 64 + (q & 63)] = v[t];
+        }
+    }
+    __syncthreads();
+
+    // ---- x += W2 hid + b2: channel blocks 2 rank, 2 rank + 1 ----
+    {
+        acc = f64x4{0.0, 0.0, 0.0, 0.0};
+        const int n = (2 * rank + wave) * 16 + l15;                   // (waves 0, 1)
+        double res[4];
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) res[i] = a.x[(size_t)min(row0 + g + 4 * i, a.R - 1) * 128 + n];
+            lc_product<32>(lfs, lane, acc, w2);
+        }
+        __syncthreads();                        // every wave has read the hidden layer: the new x takes its place
+        if (wave < 2) {
+            const double bias = a.b2[n];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int r = g + 4 * i;
+                double v = acc[i] + bias;
+                bad |= f64_out_of_range(v);
+                v += res[i];
+                bad |= f64_out_of_range(v);
+                lfs[r * LF_LD + n] = v;
+                if (row0 + r < a.R) {
+                    publish(a.x + (size_t)(row0 + r) * 128 + n, v);
+                    if (a.x32) a.x32[(size_t)(row0 + r) * 128 + n] = (float)v;
+                }
+            }
+        }
+    }
+    if (a.w3f) {
+        exchange(2);
+        {   // the partners' 3 x 32 channels of the new x: three doubles per thread
+            double v[3];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = tid + 512 * t, r = e / 96, q = e - r * 96;
+                const int p = q >> 5, pr = p + (p >= rank);
+                v[t] = __hip_atomic_load(a.x + (size_t)min(row0 + r, a.R - 1) * 128 + pr * 32 + (q & 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                const int e = tid + 512 * t, r = e / 96, q = e - r * 96;
+                const int p = q >> 5, pr = p + (p >= rank);
+                lfs[r * LF_LD + pr * 32 + (q & 31)] = v[t];
+            }
+        }
+        __syncthreads();
+        // ---- q | k | v of the next layer: channel blocks 6 rank .. 6 rank + 5 ----
+        if (wave < 6) {
+            acc = f64x4{0.0, 0.0, 0.0, 0.0};
+            lc_product<16>(lfs, lane, acc, w3);
+            const int n = (6 * rank + wave) * 16 + l15;
+            const double bias = a.b3[n];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = row0 + g + 4 * i;
+                const double v = acc[i] + bias;
+                bad |= f64_out_of_range(v);
+                if (row < a.R) a.qkv[(size_t)row * 384 + n] = v;
+            }
+        }
+    }
+    if (bad || lc_dead) f64_raise(a.guard);          // (a partner that never answered: the call is refused, not wrong)
+}
+
 // W [N][K] row-major -> fragment order [N / 16][ceil(K / 8)][64 lanes][2]: lane (l15 = lane & 15, g = lane >> 4) of channel block cb
 // and k-step pair jp holds W[16 cb + l15][8 jp + 4 t + g], t = 0, 1 - the B operand of two consecutive v_mfma_f64_16x16x4_f64;
 // zero beyond K (the encoders' K = 4 and K = 33)
@@ -357,17 +551,18 @@ int launch_frag64(const double* W, double* out, int N, int K, hipStream_t s) {
     return mdgat_check_hip(hipGetLastError(), "frag64 launch");
 }
 
-// 0: three launches per layer tail (gemm_f64_kernel); 1: the fused kernel, rows per workgroup chosen by the launch (default);
-// 16 / 32 / 64: the fused kernel with that many rows per workgroup (tests, measurements).  MDGAT_F64_LAYER_FUSION in the environment.
+// 0: three launches per layer tail (gemm_f64_kernel); 1: the fused kernels, form and rows per workgroup chosen by the launch (default);
+// 2: the same without the clustered form of small launches; 16 / 32 / 64: the one-workgroup-per-block kernel with that many rows per
+// workgroup (tests, measurements).  MDGAT_F64_LAYER_FUSION in the environment.
 static std::atomic<int> g_fusion{-1};
 static int fusion_default() {
-    static const int v = [] { const char* e = getenv("MDGAT_F64_LAYER_FUSION"); const int m = e ? atoi(e) : 1; return (m == 16 || m == 32 || m == 64) ? m : (m != 0); }();
+    static const int v = [] { const char* e = getenv("MDGAT_F64_LAYER_FUSION"); const int m = e ? atoi(e) : 1; return (m == 16 || m == 32 || m == 64 || m == 2) ? m : (m != 0); }();
     return v;
 }
 static int fusion_mode() { const int v = g_fusion.load(std::memory_order_relaxed); return v < 0 ? fusion_default() : v; }
 bool layer_f64_fused() { return fusion_mode() != 0; }
 extern "C" int mdgat_set_f64_layer_fusion(int mode) {
-    const int m = mode < 0 ? -1 : (mode == 16 || mode == 32 || mode == 64) ? mode : (mode != 0);
+    const int m = mode < 0 ? -1 : (mode == 16 || mode == 32 || mode == 64 || mode == 2) ? mode : (mode != 0);
     const int prev = g_fusion.exchange(m, std::memory_order_relaxed);
     return prev < 0 ? fusion_default() : prev;
 }
@@ -388,7 +583,31 @@ int launch_layer_tail_f64(const LayerF64Args& a, hipStream_t s) {
     // keypoints is 64 workgroups instead of 32, and a workgroup's chain of products half as long (mdgat_set_f64_layer_fusion(16 | 32 |
     // 64) forces one).
     int tm = (long)((a.R + 31) / 32) >= 2L * lf_cu_count() ? 32 : 16;
-    if (fusion_mode() > 1) tm = fusion_mode();
+    if (fusion_mode() >= 16) tm = fusion_mode();
+    // Launches of at most a quarter of the CUs in 16-row blocks (one pair of 512 keypoints: 64): four workgroups per block
+    // (layer_tail_f64_cluster_kernel; bit-identical).  Not under graph capture (its flags count launches), not without the scratch,
+    // not when a tile height is forced or mdgat_set_f64_layer_fusion(2) asks for the one-workgroup-per-block kernel.
+    const int nblk = (a.R + 15) / 16;
+    if (fusion_mode() == 1 && a.hid && LC_RANKS * nblk <= lf_cu_count() && !coop_stream_capturing(s)) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        CoopChain& ch = coop_chain_of(dev);
+        std::lock_guard<std::recursive_mutex> lock(ch.m);
+        constexpr size_t flag_bytes = (size_t)256 * LC_RANKS * LC_WORDS * sizeof(unsigned long long);      // up to 256 clusters
+        if (!ch.cluster_flags) {
+            void* p = nullptr;
+            if (int rc = mdgat_check_hip(hipMalloc(&p, flag_bytes), "layer_tail_f64 cluster flags")) return rc;
+            if (int rc = mdgat_check_hip(hipMemset(p, 0, flag_bytes), "layer_tail_f64 cluster flags (clear)")) { (void)hipFree(p); return rc; }
+            ch.cluster_flags = static_cast<unsigned long long*>(p);
+        }
+        if (nblk <= 256) {
+            if (int rc = mdgat_check_hip(coop_chain_wait(ch, s), "layer_tail_f64: wait for the previous waiting launch")) return rc;
+            const size_t lds = (size_t)16 * LF_LD * sizeof(double);
+            hipLaunchKernelGGL(layer_tail_f64_cluster_kernel, dim3((unsigned)(((nblk + 7) / 8) * 32)), dim3(64 * LF_WAVES), lds, s, a, ch.cluster_flags, ++ch.epoch);
+            if (int rc = mdgat_check_hip(hipGetLastError(), "layer_tail_f64 (clustered) launch")) return rc;
+            return mdgat_check_hip(coop_chain_record(ch, s), "layer_tail_f64: record");
+        }
+    }
     const size_t lds = (size_t)tm * LF_LD * sizeof(double);
     const dim3 grid((a.R + tm - 1) / tm);
     auto go = [&](auto kern, auto tag) -> int {

@@ -25,7 +25,7 @@
 #include "common.hpp"
 #include "f64.hpp"
 #include "sinkhorn_f64.hpp"
-#include <mutex>
+#include "coop_chain.hpp"
 
 namespace {
 
@@ -598,7 +598,6 @@ __global__ __launch_bounds__(512) void sinkhorn_f64_wide_final_kernel(Wk64Args a
 }  // namespace
 
 static size_t s64_align(size_t v) { return (v + 255) & ~(size_t)255; }
-struct S64Serial { std::mutex m; hipEvent_t ev = nullptr; bool recorded = false; };
 static size_t s64_lds_bytes(int waves) { return ((size_t)waves * S64_SLOT + S64_SLOT) * sizeof(double) + (size_t)waves * S64_SLOT * sizeof(int); }
 
 static bool s64_resident_supported(int N, int M) { return N >= 1 && M >= 1 && M + 1 <= 64 * S64_NC && N <= 32 * S64_GMAX; }
@@ -717,17 +716,11 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     // 40 pairs: every spin ran into its bound and the results were garbage.  (Streams being captured into a graph are left alone.)
     int dev = 0;
     (void)hipGetDevice(&dev);
-    static S64Serial serial[16];
-    S64Serial& sr = serial[dev >= 0 && dev < 16 ? dev : 0];
-    std::lock_guard<std::mutex> lock(sr.m);
-    hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-    (void)hipStreamIsCapturing(s, &capturing);
-    const bool chain = capturing == hipStreamCaptureStatusNone;
-    if (chain) {
-        if (!sr.ev && hipEventCreateWithFlags(&sr.ev, hipEventDisableTiming) != hipSuccess) sr.ev = nullptr;
-        if (sr.ev && sr.recorded)
-            if (int rc = mdgat_check_hip(hipStreamWaitEvent(s, sr.ev, 0), "fp64 Sinkhorn: wait for the previous launch")) return rc;
-    }
+    CoopChain& sr = coop_chain_of(dev);                 // (shared with the clustered fp64 layer tail: coop_chain.hpp)
+    std::lock_guard<std::recursive_mutex> lock(sr.m);
+    const bool chain = !coop_stream_capturing(s);
+    if (chain)
+        if (int rc = mdgat_check_hip(coop_chain_wait(sr, s), "fp64 Sinkhorn: wait for the previous launch")) return rc;
     if (int rc = mdgat_check_hip(hipMemsetAsync(a.flags, 0, (size_t)B * 3 * G * sizeof(unsigned), s), "memset(fp64 Sinkhorn flags)")) return rc;
     const int groups = (B + 7) / 8;
     const size_t lds = s64_lds_bytes(waves);
@@ -735,10 +728,8 @@ int launch_sinkhorn_f64(int B, int N, int M, const double* scores, double alpha,
     if (int rc = mdgat_lds_optin(reinterpret_cast<const void*>(sinkhorn_f64_kernel<8>), lds, optin8, "sinkhorn_f64 LDS")) return rc;
     hipLaunchKernelGGL(sinkhorn_f64_kernel<8>, dim3(groups * 8 * G), dim3(512), lds, s, a);
     if (int rc = mdgat_check_hip(hipGetLastError(), "sinkhorn_f64 launch")) return rc;
-    if (chain && sr.ev) {
-        if (int rc = mdgat_check_hip(hipEventRecord(sr.ev, s), "fp64 Sinkhorn: record")) return rc;
-        sr.recorded = true;
-    }
+    if (chain)
+        if (int rc = mdgat_check_hip(coop_chain_record(sr, s), "fp64 Sinkhorn: record")) return rc;
     if (cbest_idx) {
         const size_t total = (size_t)B * M;
         hipLaunchKernelGGL(sinkhorn_f64_merge_kernel, dim3((unsigned)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024)), dim3(256), 0, s, sidx, sval, B, G, M,

@@ -586,10 +586,10 @@ def test_f64_fused_layer_tail_equals_three_launches(B, n, m, L, k):
             return out, t
         finally:
             lib.mdgat_set_f64_layer_fusion(-1)
-            assert prev in (0, 1, 16, 32, 64)
+            assert prev in (0, 1, 2, 16, 32, 64)
     for taps in (False, True):          # (taps run the whole batch unsliced)
         ref, rt = run(0, taps)
-        for mode in (1, 16, 32, 64):
+        for mode in (1, 2, 16, 32, 64):     # (1: launches of few 16-row blocks take the clustered kernel - four workgroups per block; 2: never)
             out, ot = run(mode, taps)
             for a, b, what in zip(ref, out, ('matches0', 'matches1', 'mscores0', 'mscores1', 'Z')):
                 assert torch.equal(a, b), (mode, taps, what)
