@@ -248,9 +248,11 @@ int mdgat_set_layer_split_tiles(int tiles);
 
 /* MDGAT_ARITH_FP64: how the tail of an fp64 layer (mlp.0 + ReLU, mlp.3 + residual; models/mdgat.py:246-248, 274) and the next
  * layer's q | k | v projection (227-232) are launched.  1 (default; MDGAT_F64_LAYER_FUSION=0 in the environment selects 0): one
- * launch per layer with the hidden activation kept on chip (csrc/layer_f64.hip); 0: three launches of the fp64 product kernel
- * (csrc/f64.hip); 16 / 32 / 64: one launch with that many keypoints per workgroup (default: by launch size); mode < 0: back to the
- * default.  Process-wide; the results are bit-identical either way.  Returns the previous value. */
+ * launch per layer with the hidden activation kept on chip (csrc/layer_f64.hip) - launches of at most a quarter of the compute
+ * units in 16-keypoint blocks (one pair per call) with FOUR workgroups per block that split the output channels and exchange the
+ * hidden layer and the new x through L2; 2: the same, one workgroup per block at every launch size; 0: three launches of the fp64
+ * product kernel (csrc/f64.hip); 16 / 32 / 64: one launch with that many keypoints per workgroup (default: by launch size);
+ * mode < 0: back to the default.  Process-wide; the results are bit-identical either way.  Returns the previous value. */
 int mdgat_set_f64_layer_fusion(int mode);
 
 /* MDGAT_ARITH_FP64: how full attention (models/mdgat.py:190-194) is launched.  -1 (default; MDGAT_F64_ATTENTION_FORM in the

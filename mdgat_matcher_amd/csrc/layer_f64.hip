@@ -227,8 +227,11 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
     bool bad = false;
     constexpr bool EARLY = NRB == 1;        // the first weights of a product requested before the barrier in front of it (registers: one-pair tiles only)
     constexpr int PF3 = NRB >= 4 ? 2 : 4;
-    f64x2 wb1[4][2], wb2[4][1], wb3[PF3][3];
-    if (EARLY) lf_prefetch<2, 32, 4>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
+    // (deeper weight prefetch at one row block per workgroup - 8 / 16 pairs of k-steps for mlp.0 / mlp.3 - changes nothing: B = 1, 2, 8
+    // within 0.5 % either way; the chain of 576 matrix instructions per SIMD is 15 us of its 26)
+    constexpr int PF1 = 4, PF2 = 4;
+    f64x2 wb1[PF1][2], wb2[PF2][1], wb3[PF3][3];
+    if (EARLY) lf_prefetch<2, 32, PF1>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
 
     // ---- input tile [x ; msg] -> LDS (rows beyond R: the last row again; their results are never written) ----
     for (int e = tid; e < TM * 128; e += 64 * LF_WAVES) {
@@ -244,9 +247,9 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
         f64x4 acc[NRB][2];
 #pragma unroll
         for (int rb = 0; rb < NRB; ++rb) { acc[rb][0] = f64x4{0.0, 0.0, 0.0, 0.0}; acc[rb][1] = acc[rb][0]; }
-        if (!EARLY) lf_prefetch<2, 32, 4>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
-        lf_product<NRB, 2, 32, 4>(lfs, a.w1f + (size_t)(2 * wave) * 32 * 128, lane, acc, wb1);
-        if (EARLY) lf_prefetch<1, 32, 4>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
+        if (!EARLY) lf_prefetch<2, 32, PF1>(a.w1f + (size_t)(2 * wave) * 32 * 128, lane, wb1);
+        lf_product<NRB, 2, 32, PF1>(lfs, a.w1f + (size_t)(2 * wave) * 32 * 128, lane, acc, wb1);
+        if (EARLY) lf_prefetch<1, 32, PF2>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
         __syncthreads();                        // every wave has read the tile: the hidden layer takes its place
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
@@ -277,8 +280,8 @@ __global__ __launch_bounds__(64 * LF_WAVES) void layer_tail_f64_kernel(LayerF64A
         for (int rb = 0; rb < NRB; ++rb)
 #pragma unroll
             for (int i = 0; i < 4; ++i) res[rb][i] = a.x[(size_t)min(row0 + rb * 16 + g + 4 * i, a.R - 1) * 128 + n];
-        if (!EARLY) lf_prefetch<1, 32, 4>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
-        lf_product<NRB, 1, 32, 4>(lfs, a.w2f + (size_t)wave * 32 * 128, lane, acc, wb2);
+        if (!EARLY) lf_prefetch<1, 32, PF2>(a.w2f + (size_t)wave * 32 * 128, lane, wb2);
+        lf_product<NRB, 1, 32, PF2>(lfs, a.w2f + (size_t)wave * 32 * 128, lane, acc, wb2);
         if (EARLY && a.w3f) lf_prefetch<3, 16, PF3>(a.w3f + (size_t)(3 * wave) * 16 * 128, lane, wb3);
         __syncthreads();                        // every wave has read the hidden layer: the new x takes its place
         const double bias = a.b2[n];

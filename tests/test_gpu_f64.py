@@ -244,6 +244,38 @@ def test_sinkhorn_f64_launches_on_concurrent_streams():
                 assert torch.equal(a, b), (rnd, ci)
 
 
+def test_exact_mode_small_forwards_on_concurrent_streams():
+    """One pair per call in the exact mode from four streams at once, two modules (two handles) on the device: every layer tail is a
+    clustered launch (four workgroups per 16-row block that wait for each other), every Sinkhorn a launch of waiting row slabs - all
+    admitted one at a time per device, a forward's launches as one group (csrc/coop_chain.hpp).  Every output bit-equal to the serial
+    run's; no spin runs into its bound (check() would raise)."""
+    L = 3
+    nets = []
+    for seed in (5, 6):
+        net = MDGAT(synth.default_config(L=L, k=[64, None, 32, None], sinkhorn_iterations=15)).double()
+        net.load_state_dict(synth.make_state_dict(L=L, seed=seed))
+        nets.append(net.eval().to(DEV))
+    keys = ('keypoints0', 'scores0', 'descriptors0', 'keypoints1', 'scores1', 'descriptors1')
+    cases = [synth.make_batch(B, n, m, first_pair=fp, device=DEV, dtype=torch.float64) for (B, n, m, fp) in
+             [(1, 512, 512, 0), (1, 256, 300, 3), (2, 200, 180, 5), (1, 512, 400, 9), (3, 100, 120, 11)]]
+    with torch.no_grad():
+        ref = [[[t.clone() for t in net._run(*(d[k] for k in keys), want_Z=True)] for d in cases] for net in nets]
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(DEV) for _ in range(4)]
+        for rnd in range(3):
+            outs = []
+            for i in range(4 * len(cases)):
+                ni, ci = i % 2, (i // 2 + rnd) % len(cases)
+                with torch.cuda.stream(streams[(i + rnd) % 4]):
+                    outs.append((ni, ci, [t.clone() for t in nets[ni]._run(*(cases[ci][k] for k in keys), want_Z=True)]))
+            torch.cuda.synchronize()
+            for ni, ci, o in outs:
+                for a, b in zip(o, ref[ni][ci]):
+                    assert torch.equal(a, b), (rnd, ni, ci)
+    for net in nets:
+        net.check(DEV)
+
+
 def test_sinkhorn_f64_decides_near_ties_like_fp64():
     """Two rows that are the same but for 1e-9 in one column: their potentials agree, so the two candidates of that column are 8e-10
     apart in the fp64 Z - equal as fp32 numbers.  The kernel's arg-max (superglue branch: over the inner block, mdgat.py:444) follows
