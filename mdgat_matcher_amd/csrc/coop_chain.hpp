@@ -9,6 +9,9 @@
 // event is recorded behind the group's last waiting launch).  Streams under graph capture are left alone (an event wait on foreign
 // work cannot be captured): the Sinkhorn launches unchained there, the clustered layer tail is not used at all (its flags count
 // launches: a replay would meet them already set).
+// The chain is per PROCESS (one process per GPU is the model): two processes that run such launches on one device are
+// not ordered against each other - a starved launch then runs into its spin bound (seconds) and the call is refused through the range
+// status, never answered wrongly; MDGAT_F64_LAYER_FUSION=2 keeps the layer tails out of it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <mutex>
